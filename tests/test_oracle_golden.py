@@ -1,0 +1,180 @@
+"""The CPU restatement (oracle/saunet_ref.py) must reproduce what the REAL reference
+produced in the build container (tests/golden/*.npz, made by oracle/make_golden.py).
+Runs anywhere (no GPU, no /root/reference)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import saunet_ref as R, weights as Wt
+from tests.golden_util import load, rnd, module_state, close
+
+MODULES = {
+    # name: (functional restatement taking (sd, xs, training) -> list of outputs)
+    "SEModule": lambda sd, xs, tr: [R.se_module(sd, "", xs[0])],
+    "SpatialAttentionBlock": lambda sd, xs, tr: [R.spatial_attention(sd, "", xs[0], tr)],
+    "DualAttBlock": lambda sd, xs, tr: list(R.dual_att_block(sd, "", xs[0], xs[1], tr)),
+    "GatedSpatialConv2d": lambda sd, xs, tr: list(R.gated_conv(sd, "", xs[0], xs[1], tr)),
+    "BasicBlock": lambda sd, xs, tr: [R.basic_block(sd, "", xs[0], tr)],
+    "DecoderBlock": lambda sd, xs, tr: [R.decoder_block(sd, "", xs[0], tr)],
+    "conv3x3_bn_relu": lambda sd, xs, tr: [R.conv3x3_bn_relu(sd, "", xs[0], tr)],
+}
+
+
+class _Pre(dict):
+    """state dict whose keys are looked up as '.<key>' (functional code prefixes with '')."""
+    def __getitem__(self, k):
+        return dict.__getitem__(self, k.lstrip("."))
+
+    def get(self, k, d=None):
+        return dict.get(self, k.lstrip("."), d)
+
+    def __contains__(self, k):
+        return dict.__contains__(self, k.lstrip("."))
+
+
+def run_restatement(name, gold):
+    seed = int(gold["meta.seed"])
+    sd = _Pre(module_state(gold, name, seed))
+    nin = sum(1 for k in gold if k.startswith("meta.shape"))
+    xs = [rnd(tuple(gold["meta.shape%d" % i]), seed, "%s.in%d" % (name, i)).requires_grad_(True) for i in range(nin)]
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    sd0 = {k: v.detach().clone() for k, v in sd.items()}
+    ys = MODULES[name](sd, xs, True)
+    cots = [rnd(tuple(t.shape), seed, "%s.cot%d" % (name, i)) for i, t in enumerate(ys)]
+    torch.autograd.backward(ys, cots)
+    res = {}
+    for i, t in enumerate(ys):
+        res["train.out%d" % i] = t.detach().numpy()
+    for i, x in enumerate(xs):
+        res["train.dx%d" % i] = x.grad.numpy()
+    for k, v in sd.items():
+        if v.requires_grad:
+            res["train.grad." + k] = v.grad.numpy() if v.grad is not None else np.zeros(tuple(v.shape), np.float32)
+        elif k.endswith(("running_mean", "running_var")):
+            res["train.buf." + k] = v.numpy()
+    sd_e = _Pre({k: v.clone() for k, v in sd0.items()})
+    with torch.no_grad():
+        ys = MODULES[name](sd_e, [x.detach() for x in xs], False)
+    for i, t in enumerate(ys):
+        res["eval.out%d" % i] = t.numpy()
+    return res
+
+
+@pytest.mark.parametrize("name", sorted(MODULES))
+def test_module_matches_reference_fixture(name):
+    gold = load("modules_%s.npz" % name)
+    res = run_restatement(name, gold)
+    for k, v in gold.items():
+        if k.startswith("meta."):
+            continue
+        ok, err, scale = close(res[k], v, rtol=2e-5, atol=1e-6)
+        assert ok, "%s %s: err %.3g (scale %.3g)" % (name, k, err, scale)
+
+
+def test_loss_and_metrics():
+    g = load("loss.npz")
+    seed = int(g["meta.seed"])
+    logits = rnd((3, 4, 16, 16), seed, "loss.logits", 2.0).requires_grad_(True)
+    edge = torch.sigmoid(rnd((3, 1, 16, 16), seed, "loss.edge", 2.0)).requires_grad_(True)
+    seg, edge_t = torch.from_numpy(g["seg"]), torch.from_numpy(g["edge_t"])
+    assert close(R.dice_loss(seg, logits).detach(), g["dice"], 1e-6, 1e-7)[0]
+    L = R.dual_loss(logits, edge, seg, edge_t)
+    L.backward()
+    assert close(L.detach(), g["dual"], 1e-6, 1e-7)[0]
+    assert close(logits.grad, g["dlogits"], 1e-5, 1e-8)[0]
+    assert close(edge.grad, g["dedge"], 1e-5, 1e-8)[0]
+    acc, jac = R.pixel_acc(logits.detach(), seg)
+    assert close(acc, g["acc"], 1e-6, 1e-7)[0]
+    assert close(np.array([float(j) for j in jac]), g["jac"], 1e-6, 1e-7)[0]
+    pred = logits.detach().argmax(1).numpy()
+    ai, au = R.intersection_and_union(pred[0], g["seg"][0], 4)
+    assert (ai == g["iau_i"]).all() and (au == g["iau_u"]).all()
+    assert (R.mask_to_edges(g["m2e_mask"]) == g["m2e_edge"]).all()
+
+
+def test_uint8_cast_matches_x86_numpy():
+    from oracle import canny
+    g = load("canny_cast.npz")
+    v = g["v"]
+    x = np.stack([v, v, v]).reshape(3, 1, -1)
+    # mean of three identical float32 values: ((v+v)+v)/3 is not always v; compare against numpy's own mean
+    want = np.mean(x, axis=0).astype(np.int32).astype(np.uint8)
+    assert (canny.gray_u8(x) == want).all()
+    exact = np.array([-2.0, -1.0, 0.0, 1.0, 3.0, 12.0, -255.0, 700.0], np.float32)
+    x = np.stack([exact] * 3).reshape(3, 1, -1)
+    assert (canny.gray_u8(x)[0] == np.array([254, 255, 0, 1, 3, 12, 1, 188], np.uint8)).all()
+    assert (g["u8"] == g["v"].astype(np.int32).astype(np.uint8)).all()  # the rule the oracle encodes
+
+
+@pytest.fixture(scope="module")
+def saunet_run():
+    g = load("saunet_128.npz")
+    seed, B, H = int(g["meta.seed"]), int(g["meta.B"]), int(g["meta.H"])
+    spec = R.state_dict_spec()
+    sd = Wt.make_state_dict(spec, seed)
+    keys = Wt.trainable_keys(spec)
+    for k in keys:
+        sd[k].requires_grad_(True)
+    img, seg, edge = Wt.synthetic_batch(B, H, H)
+    torch.set_num_threads(8)
+    loss, acc, logits, edge_out = R.segmentation_step(sd, img, seg, edge, True)
+    loss.backward()
+    return g, sd, keys, loss, acc, logits, edge_out
+
+
+def test_saunet_forward_loss(saunet_run):
+    g, sd, keys, loss, acc, logits, edge_out = saunet_run
+    assert close(loss.detach(), g["loss0"], 2e-6, 0)[0]
+    assert close(acc[0], g["acc0"], 1e-6, 1e-7)[0]
+    assert close(np.array([float(j) for j in acc[1]]), g["jac0"], 1e-6, 1e-7)[0]
+    assert close(logits.detach()[:, :, ::8, ::8], g["logits_s8"], 1e-5, 1e-6)[0]
+    assert close(edge_out.detach()[:, :, ::8, ::8], g["edge_s8"], 1e-5, 1e-6)[0]
+
+
+def test_saunet_gradients(saunet_run):
+    g, sd, keys, *_ = saunet_run
+    assert list(g["grad_keys"]) == keys
+    norms = np.array([float(sd[k].grad.double().norm()) for k in keys])
+    gmax = g["grad_norms"].max()
+    assert np.abs(norms - g["grad_norms"]).max() <= 1e-5 * gmax
+    for k in g:
+        if k.startswith("grad."):
+            assert close(sd[k[5:]].grad, g[k], 1e-4, 1e-7 * gmax)[0], k
+    for k in g:
+        if k.startswith("buf."):
+            assert close(sd[k[4:]], g[k], 1e-6, 1e-7)[0], k
+
+
+def _sgd_groups(spec, sd):
+    decay = [sd[k] for k, _, kind in spec if kind == "conv"]
+    no_decay = [sd[k] for k, _, kind in spec if kind in ("bias", "gamma", "beta")]
+    return [dict(params=decay), dict(params=no_decay, weight_decay=0.0)]
+
+
+def test_saunet_sgd_trajectory_and_eval_branch():
+    """config #1: B=2 128x128, 10 SGD steps (train.py:166-196 grouping), then the inference branch."""
+    g = load("saunet_128.npz")
+    seed, B, H = int(g["meta.seed"]), int(g["meta.B"]), int(g["meta.H"])
+    spec = R.state_dict_spec()
+    sd = Wt.make_state_dict(spec, seed)
+    for k in Wt.trainable_keys(spec):
+        sd[k].requires_grad_(True)
+    img, seg, edge = Wt.synthetic_batch(B, H, H)
+    canny = R.canny_branch(img)
+    opt = torch.optim.SGD(_sgd_groups(spec, sd), lr=5e-4, momentum=0.9, weight_decay=1e-4)
+    traj = []
+    for it in range(10):
+        opt.zero_grad()
+        loss, *_ = R.segmentation_step(sd, img, seg, edge, True, canny=canny)
+        loss.backward(); opt.step(); traj.append(float(loss))
+    d = np.abs(np.array(traj) - g["sgd_traj"])
+    # rounding differences amplify through 10 optimisation steps of a 120-layer net: tight early, loose late
+    assert d[:3].max() < 1e-5 and d.max() < 3e-3, (traj, g["sgd_traj"])
+    with torch.no_grad():
+        logits, eo = R.saunet_forward(sd, img[:1], training=False)
+        l_eval = R.dual_loss(logits, eo, seg[:1], edge[:1])
+        pred = torch.softmax(logits, 1)
+    assert close(l_eval, g["eval_loss"], 5e-3, 1e-3)[0]
+    assert close(pred[:, :, ::8, ::8], g["eval_pred_s8"], 2e-2, 5e-3)[0]
