@@ -192,6 +192,13 @@ def gen_saunet(ns, seed=3, B=2, H=128):
         lg, eo = net(img)
     out["logits_s8"] = lg[:, :, ::8, ::8].numpy(); out["edge_s8"] = eo[:, :, ::8, ::8].numpy()
     out["logits_sum"] = np.float64(lg.double().sum()); out["edge_sum"] = np.float64(eo.double().sum())
+    # inference branch (models/models.py:105-109) with the INITIAL weights, eval-mode BN (running stats)
+    net.load_state_dict(sd, strict=False)
+    sm.eval()
+    with torch.no_grad():
+        pred0, l_eval0 = sm({"image": img[:1], "mask": (seg[0], edge[0])}, epoch=0, segSize=(H, H))
+    out["eval0_pred_s8"] = pred0[:, :, ::8, ::8].numpy(); out["eval0_loss"] = l_eval0.numpy()
+    sm.train()
     # 10 SGD steps (config #1: lr 5e-4, m 0.9, wd 1e-4 on conv/linear weights only; train.py:166-196)
     net.load_state_dict(sd, strict=False); net.zero_grad()
     decay, no_decay = [], []

@@ -163,12 +163,16 @@ def test_saunet_sgd_trajectory_and_eval_branch():
         sd[k].requires_grad_(True)
     img, seg, edge = Wt.synthetic_batch(B, H, H)
     canny = R.canny_branch(img)
+    with torch.no_grad():  # inference branch on the initial weights: tight
+        logits, eo = R.saunet_forward(sd, img[:1], training=False)
+        assert close(R.dual_loss(logits, eo, seg[:1], edge[:1]), g["eval0_loss"], 1e-5, 1e-6)[0]
+        assert close(torch.softmax(logits, 1)[:, :, ::8, ::8], g["eval0_pred_s8"], 1e-4, 1e-5)[0]
     opt = torch.optim.SGD(_sgd_groups(spec, sd), lr=5e-4, momentum=0.9, weight_decay=1e-4)
     traj = []
     for it in range(10):
         opt.zero_grad()
         loss, *_ = R.segmentation_step(sd, img, seg, edge, True, canny=canny)
-        loss.backward(); opt.step(); traj.append(float(loss))
+        loss.backward(); opt.step(); traj.append(float(loss.detach()))
     d = np.abs(np.array(traj) - g["sgd_traj"])
     # rounding differences amplify through 10 optimisation steps of a 120-layer net: tight early, loose late
     assert d[:3].max() < 1e-5 and d.max() < 3e-3, (traj, g["sgd_traj"])
@@ -176,5 +180,6 @@ def test_saunet_sgd_trajectory_and_eval_branch():
         logits, eo = R.saunet_forward(sd, img[:1], training=False)
         l_eval = R.dual_loss(logits, eo, seg[:1], edge[:1])
         pred = torch.softmax(logits, 1)
-    assert close(l_eval, g["eval_loss"], 5e-3, 1e-3)[0]
-    assert close(pred[:, :, ::8, ::8], g["eval_pred_s8"], 2e-2, 5e-3)[0]
+    # after training the eval-mode net (running stats 10 steps old, SyncBN momentum 0.001) is chaotic: loose
+    assert close(l_eval, g["eval_loss"], 1e-2, 0)[0]
+    assert close(pred[:, :, ::8, ::8], g["eval_pred_s8"], 0.1, 0)[0]
