@@ -1,0 +1,162 @@
+/* libsaunet_hip.so -- C ABI of the MI355X-native SAUNet hot path (gfx950, wave64, MFMA).
+ *
+ * The reference (sunjesse/shape-attentive-unet) has no FFI: its seam is the Python
+ * torch.nn.Module API.  Every entry point below replaces the ATen op (or
+ * group of ops) that a reference module executes; the citation after each declaration is
+ * the reference call site it stands in for (paths relative to /root/reference).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; the CALLER owns all memory (PyTorch allocates), including
+ *    workspaces; nothing here allocates, synchronises or calls back to the host.
+ *  - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream and
+ *    re-entrant (forward runs on the Python thread, backward on autograd's thread).
+ *  - activations are NHWC ("channels_last"); a tensor view is (ptr, pixels/N,H,W, C, ld) where
+ *    ld >= C is the channel stride in ELEMENTS (so a channel slice of a wider buffer is a view:
+ *    this is how DenseNet's concat is made free).
+ *  - dtype: SAUNET_F32 (0) or SAUNET_BF16 (1) = storage type of activations / packed weights;
+ *    accumulation, statistics, losses and parameters are always float32 (statistics sums float64).
+ *  - return 0 on success, <0 = saunet_status; saunet_last_error() gives a thread-local message.
+ *    Nothing throws across the ABI.
+ */
+#ifndef SAUNET_HIP_H
+#define SAUNET_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum saunet_status { SAUNET_OK = 0, SAUNET_BAD_SHAPE = -1, SAUNET_BAD_DTYPE = -2, SAUNET_LAUNCH_FAILED = -3,
+                     SAUNET_BAD_ALIGN = -4, SAUNET_UNSUPPORTED = -5 };
+enum saunet_dtype { SAUNET_F32 = 0, SAUNET_BF16 = 1 };
+/* weight packings produced by saunet_pack_weight (K = reduction index, contiguous) */
+enum saunet_pack_mode {
+    SAUNET_PACK_FWD = 0,       /* Conv2d [Co,Ci,kh,kw]        -> [Co][kh][kw][Ci]                         */
+    SAUNET_PACK_DGRAD = 1,     /* Conv2d [Co,Ci,kh,kw]        -> [Ci][kh'][kw'][Co], taps flipped (stride 1) */
+    SAUNET_PACK_CONVT_FWD = 2, /* ConvTranspose2d [Ci,Co,4,4] -> [ph][pw][Co][th][tw][Ci]  (k4 s2 p1 phases) */
+    SAUNET_PACK_CONVT_DGRAD = 3/* ConvTranspose2d [Ci,Co,4,4] -> [Ci][kh][kw][Co]  (a stride-2 conv over dy) */
+};
+
+typedef struct saunet_conv_desc {
+    int32_t dtype;
+    int32_t N, H, W, Cin, ldx;     /* input view  [N,H,W,Cin]  stride ldx  */
+    int32_t Ho, Wo, Cout, ldy;     /* output view [N,Ho,Wo,Cout] stride ldy */
+    int32_t KH, KW, stride, pad;
+    int32_t transposed;            /* 1: ConvTranspose2d(k=4,s=2,p=1); x is the LOW-res input, y the 2x output */
+    int32_t pro_relu;              /* prologue: a = x*pro_scale[c]+pro_shift[c], then max(a,0) if set */
+} saunet_conv_desc;
+
+const char* saunet_last_error(void);
+int saunet_version(void);
+/* number of compute units seen on `device` (sanity / grid sizing); <0 on error */
+int saunet_init(int device);
+
+/* ---- convolution family ------------------------------------------------------------------
+ * replaces nn.Conv2d / nn.ConvTranspose2d forward, e.g. models/models.py:118-123, :203-237,
+ * attention_blocks.py:150-151,179-186,215-220, GSConv.py:40-42,56-57, resnet.py:24-27 and the
+ * DenseNet-121 convs of torchvision (models/models.py:271). */
+int saunet_pack_weight(int mode, int dtype, const float* w, int Co, int Ci, int KH, int KW, void* out, void* stream);
+/* y = conv(prologue(x), w) (+bias).  If stat_sum/stat_sumsq are non-NULL, per-output-channel
+ * sums of the un-biased accumulator and its square are ATOMICALLY added (float64) -- the batch
+ * statistics BatchNorm needs, taken in the producer's epilogue. */
+int saunet_conv2d_forward(const saunet_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                          const float* pro_scale, const float* pro_shift, void* y,
+                          double* stat_sum, double* stat_sumsq, void* stream);
+/* dw[...] += sum_pixels dy (x) prologue(x).  dw is the float32 gradient in the PARAMETER's own
+ * layout ([Co,Ci,kh,kw], or [Ci,Co,4,4] when d->transposed); it must be zero-initialised by the
+ * caller (split-K partial sums are added atomically).  replaces autograd's convolution_backward
+ * (weight part) behind loss.backward() at train.py:104. */
+int saunet_conv2d_wgrad(const saunet_conv_desc* d, const void* x, const void* dy,
+                        const float* pro_scale, const float* pro_shift, float* dw, void* stream);
+/* db[c] = sum_pixels dy[:,c]  (float64 atomics into a zeroed buffer, then cast by the caller) */
+int saunet_channel_sum(int dtype, const void* dy, int64_t pixels, int C, int ld, double* out, void* stream);
+
+/* ---- batch normalisation -------------------------------------------------------------------
+ * replaces nn.BatchNorm2d / SynchronizedBatchNorm2d (single-device path = F.batch_norm,
+ * lib/nn/modules/batchnorm.py:58-61) forward+backward; models/norm.py:16-22. */
+int saunet_bn_stats(int dtype, const void* x, int64_t pixels, int C, int ld, double* sum, double* sumsq, void* stream);
+/* training=1: mean/var from (sum,sumsq,count) [+conv_bias], updates running stats with `momentum`
+ * (unbiased var), writes scale=gamma*invstd, shift=beta-mean*scale, mean, invstd.
+ * training=0: scale/shift from the running statistics. */
+int saunet_bn_finalize(int C, const double* sum, const double* sumsq, double count, const float* conv_bias,
+                       const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, float* scale, float* shift,
+                       float* mean, float* invstd, int training, void* stream);
+/* y = act(x*scale+shift (+residual)) */
+int saunet_affine_act(int dtype, const void* x, int ldx, const float* scale, const float* shift,
+                      const void* residual, int ldr, int relu, void* y, int ldy, int64_t pixels, int C, void* stream);
+/* g = dy * [out>0] where out = x*scale+shift(+residual) (if relu);  sums[0:C] += sum g,
+ * sums[C:2C] += sum g*xhat  with xhat = (x-mean)*invstd   (float64 atomics, zeroed by caller) */
+int saunet_bn_backward_reduce(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,
+                              const float* scale, const float* shift, const float* mean, const float* invstd,
+                              int relu, double* sums, int64_t pixels, int C, void* stream);
+/* dx (+)= scale*(g - sum_g/count - xhat*sum_gxhat/count) (training) or scale*g (eval);
+ * optionally dres = g.  dgamma/dbeta are written from `sums` (float32) when non-NULL. */
+int saunet_bn_backward_apply(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,
+                             const float* scale, const float* shift, const float* mean, const float* invstd,
+                             int relu, const double* sums, double count, int training, int accumulate,
+                             void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta,
+                             int64_t pixels, int C, void* stream);
+
+/* ---- resampling / pooling ------------------------------------------------------------------
+ * F.interpolate(mode='bilinear', align_corners=True) models/models.py:337-356,372-374,386-389;
+ * nn.MaxPool2d(2,2) :270,376; AvgPool2d(2,2) in the DenseNet transitions. */
+int saunet_bilinear_forward(int dtype, const void* x, int N, int H, int W, int C, int ldx, void* y, int Ho, int Wo, int ldy, void* stream);
+int saunet_bilinear_backward(int dtype, const void* dy, int N, int Ho, int Wo, int C, int lddy, void* dx, int H, int W, int lddx, int accumulate, void* stream);
+int saunet_pool2x2_forward(int dtype, int is_max, const void* x, int N, int H, int W, int C, int ldx, void* y, int ldy, void* stream);
+int saunet_pool2x2_backward(int dtype, int is_max, const void* x, const void* dy, int N, int H, int W, int C, int ldx, int lddy, void* dx, int lddx, int accumulate, void* stream);
+
+/* ---- element-wise glue ----------------------------------------------------------------------*/
+/* dst[:, :C] (ld ldd) = src[:, :C] (ld lds) -- the only "cat" there is: writing a channel slice */
+int saunet_copy_channels(int dtype_src, int dtype_dst, const void* src, int lds, void* dst, int ldd, int64_t pixels, int C, int accumulate, void* stream);
+/* y = sigmoid(x) ; dx = dy*y*(1-y) */
+int saunet_sigmoid_forward(int dtype, const void* x, int ldx, void* y, int ldy, int64_t pixels, int C, void* stream);
+int saunet_sigmoid_backward(int dtype, const void* y, int ldyy, const void* dy, int lddy, void* dx, int lddx, int64_t pixels, int C, int accumulate, void* stream);
+/* gate multiply  y = x * (alpha + 1), alpha is a 1-channel map (GSConv.py:55) */
+int saunet_gate_mul_forward(int dtype, const void* x, int ldx, const void* alpha, void* y, int ldy, int64_t pixels, int C, void* stream);
+int saunet_gate_mul_backward(int dtype, const void* x, int ldx, const void* alpha, const void* dy, int lddy,
+                             void* dx, int lddx, void* dalpha, int64_t pixels, int C, void* stream);
+
+/* ---- dual attention tail (attention_blocks.py:50-57,165-173,237) ------------------------------
+ * pooled[n,c] = mean_hw F ;  out = (S+1) * F * se[n,c] */
+int saunet_global_avgpool(int dtype, const void* x, int N, int HW, int C, int ldx, float* pooled, void* stream);
+int saunet_se_excite(const float* pooled, int N, int C, int Cr, const float* w1, const float* b1,
+                     const float* w2, const float* b2, float* hidden, float* se, void* stream);
+int saunet_se_excite_backward(const float* pooled, const float* hidden, const float* se, const float* dse, int N, int C, int Cr,
+                              const float* w1, const float* w2, float* dpooled, float* dw1, float* db1, float* dw2, float* db2, void* stream);
+int saunet_att_combine_forward(int dtype, const void* F, int ldf, const void* S, const float* se, void* out, int ldo,
+                               int N, int HW, int C, void* stream);
+/* dF = dout*(S+1)*se + dpooled/HW (second pass) ; dS = sum_c dout*F*se ; dse[n,c] = sum_hw dout*(S+1)*F */
+int saunet_att_combine_backward(int dtype, const void* F, int ldf, const void* S, const float* se, const void* dout, int lddo,
+                                void* dF, int lddf, void* dS, float* dse, int N, int HW, int C, void* stream);
+int saunet_add_pooled_grad(int dtype, void* dF, int lddf, const float* dpooled, int N, int HW, int C, void* stream);
+
+/* ---- dual-task loss + metrics (loss.py:124-159, :51-88; models/models.py:51-74) ---------------
+ * one pass over logits [P,4] + edge [P,1]: partial sums -> sums[32] (float64, zeroed by caller):
+ *  [0] sum w*nll  [1] sum w  [2..5] I_c  [6..9] K_c  [10] sum bce  [11..13] acc_num, acc_den, (unused)
+ *  [14..16] |P_c & Y_c| c=1..3   [17..19] |Y_c|   [20..22] |P_c| */
+int saunet_dual_loss_forward(int dtype, const void* logits, int ldl, const void* edge, const int64_t* seg_t, const float* edge_t,
+                             int64_t pixels, double* sums, void* stream);
+/* loss[0] = dice + ce + bce ; metrics[0]=acc, [1..3]=jaccard */
+int saunet_dual_loss_finalize(const double* sums, int64_t pixels, float* loss, float* metrics, void* stream);
+int saunet_dual_loss_backward(int dtype, const void* logits, int ldl, const void* edge, const int64_t* seg_t, const float* edge_t,
+                              int64_t pixels, const double* sums, const float* dloss, void* dlogits, int lddl, void* dedge, void* stream);
+
+/* ---- Canny branch on device (models/models.py:359-363; replaces the host cv2.Canny round trip) --
+ * out[n,h,w] in {0,255} as dtype.  work: int32 [N][3][H][W] scratch. */
+int saunet_canny(int dtype, const float* image_nchw3, int N, int H, int W, int low, int high, void* out, int32_t* work, void* stream);
+
+/* ---- optimiser (train.py:166-216, radam.py:5-78) as multi-tensor kernels ------------------------*/
+typedef struct saunet_tensor_list { int32_t count; const void* ptrs[4][96]; int64_t numel[96]; } saunet_tensor_list;
+/* hyper-parameters live in a DEVICE float array so a captured hipGraph can be replayed after the host
+ * rewrites the learning rate:
+ *   SGD   hyper = {lr, momentum, weight_decay, first_step(0/1), grad_scale}
+ *   RAdam hyper = {beta1, beta2, eps, weight_decay*lr, step_size, rectified(0/1), grad_scale}  (radam.py:52-75) */
+int saunet_sgd_step(const saunet_tensor_list* tl /*0:param 1:grad 2:momentum*/, const float* hyper, void* stream);
+int saunet_radam_step(const saunet_tensor_list* tl /*0:param 1:grad 2:exp_avg 3:exp_avg_sq*/, const float* hyper, void* stream);
+/* flat[offset_i : offset_i+n_i] = grad_i (pack=1) or grad_i = flat[...]*scale (pack=0): all-reduce buckets */
+int saunet_bucket_copy(const saunet_tensor_list* tl /*0:tensor 1:flat+offset*/, int pack, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

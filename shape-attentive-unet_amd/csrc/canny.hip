@@ -1,0 +1,135 @@
+// Canny branch on the device: removes the D2H -> cv2.Canny -> H2D round trip the reference performs
+// inside SAUNet.forward (/root/reference/models/models.py:359-363).  Integer arithmetic, bit-exact with
+// oracle/canny.c:  gray = uint8(trunc(mean_c x)) (mod 256) ; Sobel 3x3 (replicate border) ; L1 magnitude ;
+// non-maximum suppression with the fixed-point tan(22.5deg) sector test ; hysteresis (low, high) ;
+// output {0,255}.
+#include "common.h"
+
+namespace saunet {
+
+#define CANNY_SHIFT 15
+#define CANNY_TG22 13573
+
+__device__ __forceinline__ int gray_u8(const float* __restrict__ img, int n, int H, int W, int y, int x)
+{
+    y = min(max(y, 0), H - 1); x = min(max(x, 0), W - 1);
+    const long plane = (long)H * W;
+    const float* b = img + (long)n * 3 * plane + (long)y * W + x;
+    float s = b[0] + b[plane];
+    s = s + b[2 * plane];
+    float m = __fdiv_rn(s, 3.0f);
+    return ((int)m) & 0xFF;   // trunc toward zero, low 8 bits (x86 numpy float32 -> uint8)
+}
+
+// pass 1: Sobel + magnitude.  work[0] = mag, work[1] = (dx & 0xffff) | (dy << 16)
+__global__ __launch_bounds__(256) void canny_sobel_kernel(const float* __restrict__ img, int N, int H, int W, int32_t* __restrict__ work)
+{
+    const long total = (long)N * H * W;
+    const long plane = (long)H * W;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int x = (int)(i % W); long t = i / W; int y = (int)(t % H); int n = (int)(t / H);
+        int p[3][3];
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) p[dy + 1][dx + 1] = gray_u8(img, n, H, W, y + dy, x + dx);
+        int gx = (p[0][2] + 2 * p[1][2] + p[2][2]) - (p[0][0] + 2 * p[1][0] + p[2][0]);
+        int gy = (p[2][0] + 2 * p[2][1] + p[2][2]) - (p[0][0] + 2 * p[0][1] + p[0][2]);
+        int32_t* w = work + (long)n * 3 * plane;
+        w[(long)y * W + x] = abs(gx) + abs(gy);
+        w[plane + (long)y * W + x] = (gx & 0xffff) | (gy << 16);
+    }
+}
+
+__device__ __forceinline__ int mag_at(const int32_t* mag, int H, int W, int y, int x)
+{
+    return ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? mag[(long)y * W + x] : 0;
+}
+
+// pass 2: NMS -> map (work[2]): 1 = not an edge, 0 = weak candidate, 2 = strong edge
+__global__ __launch_bounds__(256) void canny_nms_kernel(int N, int H, int W, int low, int high, int32_t* __restrict__ work)
+{
+    const long total = (long)N * H * W;
+    const long plane = (long)H * W;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int x = (int)(i % W); long t = i / W; int y = (int)(t % H); int n = (int)(t / H);
+        const int32_t* mag = work + (long)n * 3 * plane;
+        const int m = mag[(long)y * W + x];
+        int out = 1;
+        if (m > low) {
+            const int32_t d = mag[plane + (long)y * W + x];
+            const int xs = (int)(short)(d & 0xffff), ys = d >> 16;
+            const int ax = abs(xs), ay = abs(ys) << CANNY_SHIFT;
+            const int tg22x = ax * CANNY_TG22;
+            bool keep;
+            if (ay < tg22x) keep = (m > mag_at(mag, H, W, y, x - 1)) && (m >= mag_at(mag, H, W, y, x + 1));
+            else {
+                const int tg67x = tg22x + (ax << (CANNY_SHIFT + 1));
+                if (ay > tg67x) keep = (m > mag_at(mag, H, W, y - 1, x)) && (m >= mag_at(mag, H, W, y + 1, x));
+                else {
+                    const int s = ((xs ^ ys) < 0) ? -1 : 1;
+                    keep = (m > mag_at(mag, H, W, y - 1, x - s)) && (m > mag_at(mag, H, W, y + 1, x + s));
+                }
+            }
+            if (keep) out = (m > high) ? 2 : 0;
+        }
+        work[(long)n * 3 * plane + 2 * plane + (long)y * W + x] = out;
+    }
+}
+
+// pass 3: hysteresis by in-place relaxation (monotone: 0 -> 2 only), one workgroup per image, until a
+// sweep changes nothing; then emit {0,255}.  Result = pixels 8-connected to a strong pixel through
+// candidates, identical to the stack-based flood fill of the CPU algorithm.
+template <typename T>
+__global__ __launch_bounds__(1024) void canny_hyst_kernel(int H, int W, int32_t* __restrict__ work, T* __restrict__ out)
+{
+    const long plane = (long)H * W;
+    volatile int32_t* map = work + (long)blockIdx.x * 3 * plane + 2 * plane;
+    __shared__ int changed;
+    const int npix = H * W;
+    for (int it = 0; it < npix; ++it) {
+        if (threadIdx.x == 0) changed = 0;
+        __syncthreads();
+        int any = 0;
+        for (int i = threadIdx.x; i < npix; i += 1024) {
+            if (map[i] != 0) continue;
+            const int y = i / W, x = i - y * W;
+            bool hit = false;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    if ((dy | dx) != 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W && map[yy * W + xx] == 2) hit = true;
+                }
+            if (hit) { map[i] = 2; any = 1; }
+        }
+        if (any) changed = 1;
+        __threadfence_block();
+        __syncthreads();
+        const int c = changed;
+        __syncthreads();
+        if (!c) break;
+    }
+    T* o = out + (long)blockIdx.x * plane;
+    for (int i = threadIdx.x; i < npix; i += 1024) Elem<T>::store(o + i, map[i] == 2 ? 255.f : 0.f);
+}
+
+}  // namespace saunet
+
+using namespace saunet;
+
+extern "C" int saunet_canny(int dtype, const float* image, int N, int H, int W, int low, int high, void* out, int32_t* work, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (low > high) { int t = low; low = high; high = t; }
+    const long total = (long)N * H * W;
+    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(canny_sobel_kernel, dim3((unsigned)blocks), dim3(256), 0, st, image, N, H, W, work);
+    hipLaunchKernelGGL(canny_nms_kernel, dim3((unsigned)blocks), dim3(256), 0, st, N, H, W, low, high, work);
+    if (dtype == SAUNET_F32) hipLaunchKernelGGL(canny_hyst_kernel<float>, dim3(N), dim3(1024), 0, st, H, W, work, (float*)out);
+    else if (dtype == SAUNET_BF16) hipLaunchKernelGGL(canny_hyst_kernel<u16>, dim3(N), dim3(1024), 0, st, H, W, work, (u16*)out);
+    else return set_error(SAUNET_BAD_DTYPE, "canny: dtype %d", dtype);
+    SAUNET_CHECK_LAUNCH("canny");
+    return SAUNET_OK;
+}

@@ -1,0 +1,124 @@
+// Shared device/host helpers for libsaunet_hip.so (gfx950 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/saunet_hip.h"
+
+namespace saunet {
+
+typedef __hip_bfloat16 bf16;
+typedef unsigned short u16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+int set_error(int code, const char* fmt, ...);
+
+#define SAUNET_CHECK_LAUNCH(name)                                                     \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess)                                                        \
+            return saunet::set_error(SAUNET_LAUNCH_FAILED, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+// ---- bf16 <-> f32 bit tricks (round-to-nearest-even on the way down) -----------------------------
+__device__ __forceinline__ float bf16_lo(unsigned int packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned int packed) { return __uint_as_float(packed & 0xffff0000u); }
+__device__ __forceinline__ unsigned int f32_to_bf16_bits(float f)
+{
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi)
+{
+    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int dtype = SAUNET_F32;
+    __device__ static __forceinline__ float load(const float* p) { return *p; }
+    __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct Elem<u16> {  // bf16 stored as raw 16-bit words
+    static constexpr int dtype = SAUNET_BF16;
+    __device__ static __forceinline__ float load(const u16* p) { return __uint_as_float(((unsigned int)*p) << 16); }
+    __device__ static __forceinline__ void store(u16* p, float v) { *p = (u16)f32_to_bf16_bits(v); }
+};
+
+// 16-byte vector of T as floats: 4 f32 or 8 bf16
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    __device__ static __forceinline__ void unpack(const u32x4& v, float* f)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v[i]);
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f)
+    {
+        u32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = __float_as_uint(f[i]);
+        return v;
+    }
+};
+template <> struct Vec16<u16> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void unpack(const u32x4& v, float* f)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_lo(v[i]); f[2 * i + 1] = bf16_hi(v[i]); }
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f)
+    {
+        u32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+        return v;
+    }
+};
+
+// ---- wave64 reductions ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// fast unsigned divide by a runtime constant (host builds the magic): q = (n * mul) >> 32 >> shr
+struct FastDiv {
+    unsigned int mul, shr, d;
+    __host__ static FastDiv make(unsigned int d)
+    {
+        FastDiv f; f.d = d;
+        if (d == 1) { f.mul = 0; f.shr = 0; return f; }
+        unsigned int l = 0; while ((1ull << l) < d) ++l;            // ceil(log2 d)
+        unsigned long long m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
+        f.mul = (unsigned int)m; f.shr = l; return f;
+    }
+    __device__ __forceinline__ unsigned int div(unsigned int n) const
+    {
+        if (d == 1) return n;
+        unsigned int t = __umulhi(n, mul);
+        return (t + ((n - t) >> 1)) >> (shr - 1);
+    }
+};
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace saunet

@@ -1,0 +1,256 @@
+// C-ABI front for the convolution family: weight packing, dispatch between the MFMA implicit-GEMM
+// kernels (conv_igemm.hip) and the small-channel pointwise kernels below, bias gradient.
+#include "common.h"
+
+namespace saunet {
+
+static thread_local char g_err[512] = "";
+int set_error(int code, const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return code;
+}
+
+bool igemm_supported(const saunet_conv_desc* d);
+int igemm_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps, const float* psh,
+                  void* y, double* ssum, double* ssq, hipStream_t st);
+int igemm_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------- packing
+template <typename T>
+__global__ void pack_weight_kernel(int mode, const float* __restrict__ w, int Co, int Ci, int KH, int KW, T* __restrict__ out)
+{
+    const long total = (long)Co * Ci * KH * KW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float v;
+        if (mode == SAUNET_PACK_FWD) {            // out[co][kh][kw][ci] <- w[co][ci][kh][kw]
+            int ci = i % Ci; long t = i / Ci; int kw = t % KW; t /= KW; int kh = t % KH; int co = t / KH;
+            v = w[(((long)co * Ci + ci) * KH + kh) * KW + kw];
+        } else if (mode == SAUNET_PACK_DGRAD) {   // out[ci][kh'][kw'][co] <- w[co][ci][KH-1-kh'][KW-1-kw']
+            int co = i % Co; long t = i / Co; int kw = t % KW; t /= KW; int kh = t % KH; int ci = t / KH;
+            v = w[(((long)co * Ci + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
+        } else if (mode == SAUNET_PACK_CONVT_FWD) {  // w[ci][co][4][4] (Co = out ch, Ci = in ch) -> [ph][pw][co][th][tw][ci]
+            int ci = i % Ci; long t = i / Ci; int tw = t % 2; t /= 2; int th = t % 2; t /= 2; int co = t % Co; t /= Co;
+            int pw = t % 2, ph = t / 2;
+            int kh = (1 - ph) + 2 * th, kw = (1 - pw) + 2 * tw;
+            v = w[(((long)ci * Co + co) * 4 + kh) * 4 + kw];
+        } else {                                  // CONVT_DGRAD: w[ci][co][4][4] -> out[ci][kh][kw][co]
+            int co = i % Co; long t = i / Co; int kw = t % 4; t /= 4; int kh = t % 4; int ci = t / 4;
+            v = w[(((long)ci * Co + co) * 4 + kh) * 4 + kw];
+        }
+        Elem<T>::store(out + i, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- pointwise (1x1) small-channel path
+struct PwArgs {
+    const void* x; const void* w; void* y; const float* bias; const float* ps; const float* psh;
+    double* ssum; double* ssq;
+    long P; int Cin, Cout, ldx, ldy, pro_relu;
+};
+
+template <typename T> __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwArgs a)
+{
+    __shared__ float s_sum[64], s_sq[64];
+    const bool stats = a.ssum != nullptr;
+    if (stats && threadIdx.x < 64) { s_sum[threadIdx.x] = 0.f; s_sq[threadIdx.x] = 0.f; }
+    if (stats) __syncthreads();
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    const long total = a.P * a.Cout;
+    if (idx < total) {
+        const long p = idx / a.Cout; const int co = (int)(idx - p * a.Cout);
+        const T* xr = (const T*)a.x + p * a.ldx;
+        const T* wr = (const T*)a.w + (long)co * a.Cin;
+        float acc = 0.f;
+        if (a.ps != nullptr) {
+            for (int c = 0; c < a.Cin; ++c) {
+                float v = fmaf(Elem<T>::load(xr + c), a.ps[c], a.psh[c]);
+                if (a.pro_relu) v = fmaxf(v, 0.f);
+                acc = fmaf(v, Elem<T>::load(wr + c), acc);
+            }
+        } else {
+            for (int c = 0; c < a.Cin; ++c) acc = fmaf(Elem<T>::load(xr + c), Elem<T>::load(wr + c), acc);
+        }
+        if (stats) { atomicAdd(&s_sum[co], acc); atomicAdd(&s_sq[co], acc * acc); }
+        Elem<T>::store((T*)a.y + p * a.ldy + co, acc + (a.bias ? a.bias[co] : 0.f));
+    }
+    if (stats) {
+        __syncthreads();
+        if (threadIdx.x < a.Cout) {
+            atomicAdd(&a.ssum[threadIdx.x], (double)s_sum[threadIdx.x]);
+            atomicAdd(&a.ssq[threadIdx.x], (double)s_sq[threadIdx.x]);
+        }
+    }
+}
+
+// dw[co][ci] += sum_p dy[p][co] * a[p][ci]: rows staged in LDS, each thread owns <= WPT weights
+struct PwWgradArgs {
+    const void* x; const void* dy; float* dw; const float* ps; const float* psh;
+    long P; int Cin, Cout, ldx, lddy, pro_relu; long pix_per_block; long sM, sN; int rows;
+};
+template <typename T, int WPT> __global__ __launch_bounds__(256) void pointwise_wgrad_kernel(PwWgradArgs a)
+{
+    const int ROWS = a.rows;
+    extern __shared__ float sbuf[];  // [ROWS][Cin] then [ROWS][Cout]
+    float* sx = sbuf; float* sd = sbuf + ROWS * a.Cin;
+    const int nW = a.Cin * a.Cout;
+    float acc[WPT];
+    int wco[WPT], wci[WPT];
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {
+        int w = threadIdx.x + k * 256;
+        acc[k] = 0.f; wco[k] = (w < nW) ? w / a.Cin : -1; wci[k] = (w < nW) ? w % a.Cin : 0;
+    }
+    const long p0 = blockIdx.x * a.pix_per_block;
+    const long p1 = min(p0 + a.pix_per_block, a.P);
+    for (long pb = p0; pb < p1; pb += ROWS) {
+        const int rows = (int)min((long)ROWS, p1 - pb);
+        for (int i = threadIdx.x; i < rows * a.Cin; i += 256) {
+            int r = i / a.Cin, c = i - r * a.Cin;
+            float v = Elem<T>::load((const T*)a.x + (pb + r) * a.ldx + c);
+            if (a.ps != nullptr) { v = fmaf(v, a.ps[c], a.psh[c]); if (a.pro_relu) v = fmaxf(v, 0.f); }
+            sx[i] = v;
+        }
+        for (int i = threadIdx.x; i < rows * a.Cout; i += 256) {
+            int r = i / a.Cout, c = i - r * a.Cout;
+            sd[i] = Elem<T>::load((const T*)a.dy + (pb + r) * a.lddy + c);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            if (wco[k] >= 0) {
+                float s = acc[k];
+                for (int r = 0; r < rows; ++r) s = fmaf(sd[r * a.Cout + wco[k]], sx[r * a.Cin + wci[k]], s);
+                acc[k] = s;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < WPT; ++k)
+        if (wco[k] >= 0) atomicAdd(a.dw + wco[k] * a.sM + wci[k] * a.sN, acc[k]);
+}
+
+// out[c] += sum_p x[p][c]  (float64 atomics)
+template <typename T> __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ x, long P, int C, int ld,
+                                                                                long rows_per_block, double* __restrict__ out)
+{
+    // thread -> channel (tid % Cw) and row lane (tid / Cw); works for any C <= 1024 by looping channel groups
+    const long p0 = blockIdx.x * rows_per_block, p1 = min(p0 + rows_per_block, P);
+    for (int cb = 0; cb < C; cb += 256) {
+        const int cw = min(256, C - cb);
+        const int rl = 256 / cw;          // row lanes
+        const int c = threadIdx.x % cw, r0 = threadIdx.x / cw;
+        double s = 0.0;
+        if (r0 < rl) {
+            float fs = 0.f; int cnt = 0;
+            for (long p = p0 + r0; p < p1; p += rl) {
+                fs += Elem<T>::load(x + p * ld + cb + c);
+                if (++cnt == 256) { s += fs; fs = 0.f; cnt = 0; }
+            }
+            s += fs;
+            atomicAdd(&out[cb + c], s);
+        }
+    }
+}
+
+static bool is_pointwise(const saunet_conv_desc* d)
+{
+    return d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->transposed && d->Ho == d->H && d->Wo == d->W;
+}
+
+}  // namespace saunet
+
+using namespace saunet;
+
+extern "C" {
+
+const char* saunet_last_error(void) { return g_err; }
+int saunet_version(void) { return 1; }
+
+int saunet_init(int device)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return set_error(SAUNET_LAUNCH_FAILED, "no device %d", device);
+    return prop.multiProcessorCount;
+}
+
+int saunet_pack_weight(int mode, int dtype, const float* w, int Co, int Ci, int KH, int KW, void* out, void* stream)
+{
+    if ((mode == SAUNET_PACK_CONVT_FWD || mode == SAUNET_PACK_CONVT_DGRAD) && (KH != 4 || KW != 4))
+        return set_error(SAUNET_UNSUPPORTED, "pack: conv-transpose packing needs 4x4 kernels");
+    const long total = (long)Co * Ci * KH * KW;
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SAUNET_F32) hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, st, mode, w, Co, Ci, KH, KW, (float*)out);
+    else if (dtype == SAUNET_BF16) hipLaunchKernelGGL(pack_weight_kernel<u16>, dim3(blocks), dim3(256), 0, st, mode, w, Co, Ci, KH, KW, (u16*)out);
+    else return set_error(SAUNET_BAD_DTYPE, "pack: dtype %d", dtype);
+    SAUNET_CHECK_LAUNCH("pack_weight");
+    return SAUNET_OK;
+}
+
+int saunet_conv2d_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias,
+                          const float* ps, const float* psh, void* y, double* ssum, double* ssq, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->ldx < d->Cin || d->ldy < d->Cout)
+        return set_error(SAUNET_BAD_SHAPE, "conv: bad shape N=%d Cin=%d ldx=%d Cout=%d ldy=%d", d->N, d->Cin, d->ldx, d->Cout, d->ldy);
+    if (!d->transposed) {
+        int ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+        if (ho != d->Ho || wo != d->Wo) return set_error(SAUNET_BAD_SHAPE, "conv: Ho/Wo %dx%d != %dx%d", d->Ho, d->Wo, ho, wo);
+    }
+    if ((ps == nullptr) != (psh == nullptr)) return set_error(SAUNET_BAD_SHAPE, "conv: prologue needs scale and shift");
+    if (igemm_supported(d)) return igemm_forward(d, x, w, bias, ps, psh, y, ssum, ssq, st);
+    if (!is_pointwise(d)) return set_error(SAUNET_UNSUPPORTED, "conv: %dx%d s%d Cin=%d Cout=%d has no kernel", d->KH, d->KW, d->stride, d->Cin, d->Cout);
+    if (ssum != nullptr && d->Cout > 64) return set_error(SAUNET_UNSUPPORTED, "pointwise stats need Cout <= 64");
+    PwArgs a{x, w, y, bias, ps, psh, ssum, ssq, (long)d->N * d->H * d->W, d->Cin, d->Cout, d->ldx, d->ldy, d->pro_relu};
+    long total = a.P * a.Cout;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (d->dtype == SAUNET_F32) hipLaunchKernelGGL(pointwise_fwd_kernel<float>, grid, dim3(256), 0, st, a);
+    else if (d->dtype == SAUNET_BF16) hipLaunchKernelGGL(pointwise_fwd_kernel<u16>, grid, dim3(256), 0, st, a);
+    else return set_error(SAUNET_BAD_DTYPE, "conv: dtype %d", d->dtype);
+    SAUNET_CHECK_LAUNCH("pointwise_fwd");
+    return SAUNET_OK;
+}
+
+int saunet_conv2d_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (igemm_supported(d)) return igemm_wgrad(d, x, dy, ps, psh, dw, st);
+    if (!is_pointwise(d)) return set_error(SAUNET_UNSUPPORTED, "wgrad: %dx%d Cin=%d Cout=%d has no kernel", d->KH, d->KW, d->Cin, d->Cout);
+    const int nW = d->Cin * d->Cout;
+    PwWgradArgs a{x, dy, dw, ps, psh, (long)d->N * d->H * d->W, d->Cin, d->Cout, d->ldx, d->ldy, d->pro_relu, 0, (long)d->Cin, 1, 32};
+    long blocks = (a.P + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    a.pix_per_block = ((a.P + blocks - 1) / blocks + 31) / 32 * 32;
+    blocks = (a.P + a.pix_per_block - 1) / a.pix_per_block;
+    a.rows = 32;
+    while (a.rows > 1 && (size_t)a.rows * (d->Cin + d->Cout) * sizeof(float) > 60 * 1024) a.rows /= 2;
+    size_t lds = (size_t)a.rows * (d->Cin + d->Cout) * sizeof(float);
+    if (lds > 64 * 1024) return set_error(SAUNET_UNSUPPORTED, "pointwise wgrad: Cin+Cout too large (%d)", d->Cin + d->Cout);
+#define PW_WGRAD(TT, WPT) hipLaunchKernelGGL((pointwise_wgrad_kernel<TT, WPT>), dim3((unsigned)blocks), dim3(256), lds, st, a)
+    if (d->dtype == SAUNET_F32) {
+        if (nW <= 256) PW_WGRAD(float, 1); else if (nW <= 1280) PW_WGRAD(float, 5); else if (nW <= 4096) PW_WGRAD(float, 16);
+        else return set_error(SAUNET_UNSUPPORTED, "pointwise wgrad: %d weights", nW);
+    } else if (d->dtype == SAUNET_BF16) {
+        if (nW <= 256) PW_WGRAD(u16, 1); else if (nW <= 1280) PW_WGRAD(u16, 5); else if (nW <= 4096) PW_WGRAD(u16, 16);
+        else return set_error(SAUNET_UNSUPPORTED, "pointwise wgrad: %d weights", nW);
+    } else return set_error(SAUNET_BAD_DTYPE, "wgrad: dtype %d", d->dtype);
+#undef PW_WGRAD
+    SAUNET_CHECK_LAUNCH("pointwise_wgrad");
+    return SAUNET_OK;
+}
+
+int saunet_channel_sum(int dtype, const void* x, int64_t pixels, int C, int ld, double* out, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    long blocks = (pixels + 511) / 512; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    long rpb = (pixels + blocks - 1) / blocks;
+    blocks = (pixels + rpb - 1) / rpb;
+    if (dtype == SAUNET_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (long)pixels, C, ld, rpb, out);
+    else if (dtype == SAUNET_BF16) hipLaunchKernelGGL(channel_sum_kernel<u16>, dim3((unsigned)blocks), dim3(256), 0, st, (const u16*)x, (long)pixels, C, ld, rpb, out);
+    else return set_error(SAUNET_BAD_DTYPE, "channel_sum: dtype %d", dtype);
+    SAUNET_CHECK_LAUNCH("channel_sum");
+    return SAUNET_OK;
+}
+
+}  // extern "C"

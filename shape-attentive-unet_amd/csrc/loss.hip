@@ -1,0 +1,169 @@
+// Dual-task loss (weighted CE + soft Dice + BCE on the edge map) and the training metrics in ONE
+// pass over logits [P,4] / edge [P,1]; backward in one more pass.
+// Replaces DualLoss.forward (/root/reference/loss.py:149-159), dice_loss (:51-88) and
+// SegmentationModuleBase.pixel_acc (/root/reference/models/models.py:51-74).
+#include "common.h"
+
+namespace saunet {
+
+constexpr int NSUM = 23;
+// sums: [0] sum w*nll [1] sum w [2..5] I_c [6..9] K_c [10] sum bce [11] acc_num [12] acc_den [13] unused
+//       [14..16] |P_c & Y_c| c=1..3  [17..19] |Y_c|  [20..22] |P_c|
+__constant__ float c_ce_w[4] = {1.f, 4.f, 5.f, 1.f};  // loss.py:130
+
+__device__ __forceinline__ void softmax4(const float* z, float* p, float& m, float& logs)
+{
+    m = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));
+    float e[4], s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { e[c] = expf(z[c] - m); s += e[c]; }
+    logs = logf(s);
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) p[c] = e[c] * inv;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dual_loss_fwd_kernel(const T* __restrict__ logits, int ldl, const T* __restrict__ edge,
+                                                            const int64_t* __restrict__ seg, const float* __restrict__ edge_t, long P,
+                                                            double* __restrict__ sums)
+{
+    float acc[NSUM];
+#pragma unroll
+    for (int k = 0; k < NSUM; ++k) acc[k] = 0.f;
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        float z[4], pr[4], m, logs;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) z[c] = Elem<T>::load(logits + p * ldl + c);
+        softmax4(z, pr, m, logs);
+        const int y = (int)seg[p];
+        float zy = 0.f, wy = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float t = (c == y) ? 1.f : 0.f;
+            if (c == y) { zy = z[c]; wy = c_ce_w[c]; }
+            acc[2 + c] += pr[c] * t;
+            acc[6 + c] += pr[c] + t;
+        }
+        acc[0] += wy * (logs - (zy - m));
+        acc[1] += wy;
+        const float e = Elem<T>::load(edge + p), et = edge_t[p];
+        acc[10] -= et * fmaxf(logf(e), -100.f) + (1.f - et) * fmaxf(logf(1.f - e), -100.f);
+        // metrics: argmax(round(softmax)) -> the class with p > 0.5 (round-half-even: 0.5 -> 0), else 0
+        int pred = 0;
+#pragma unroll
+        for (int c = 3; c >= 1; --c) if (pr[c] > 0.5f) pred = c;
+        if (y >= 1) { acc[12] += 1.f; if (pred == y) acc[11] += 1.f; }
+#pragma unroll
+        for (int c = 1; c < 4; ++c) {
+            const bool v = (y == c), q = (pred == c);
+            if (v && q) acc[13 + c] += 1.f;
+            if (v) acc[16 + c] += 1.f;
+            if (q) acc[19 + c] += 1.f;
+        }
+    }
+    __shared__ double red[4][NSUM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NSUM; ++k) {
+        double v = wave_sum((double)acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NSUM) atomicAdd(&sums[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void dual_loss_finalize_kernel(const double* __restrict__ s, long P, float* __restrict__ loss, float* __restrict__ metrics)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float ce = (float)(s[0] / s[1]);
+    float dsum = 0.f;
+    for (int c = 0; c < 4; ++c) dsum += 2.f * (float)s[2 + c] / ((float)s[6 + c] + 1e-7f);
+    const float dice = 1.f - dsum * 0.25f;
+    const float bce = (float)(s[10] / (double)P);
+    loss[0] = dice + ce + bce;
+    if (metrics) {
+        metrics[0] = (float)s[11] / ((float)s[12] + 1e-10f);
+        for (int c = 1; c < 4; ++c) {
+            float anb = (float)s[13 + c];
+            metrics[c] = anb / ((float)s[16 + c] + (float)s[19 + c] - anb + 1e-10f);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dual_loss_bwd_kernel(const T* __restrict__ logits, int ldl, const T* __restrict__ edge,
+                                                            const int64_t* __restrict__ seg, const float* __restrict__ edge_t, long P,
+                                                            const double* __restrict__ sums, const float* __restrict__ dloss,
+                                                            T* __restrict__ dlogits, int lddl, T* __restrict__ dedge)
+{
+    const float go = dloss ? dloss[0] : 1.f;
+    const float inv_w = (float)(1.0 / sums[1]);
+    float qa[4], qb[4];  // d dice / d p_c = -(1/4) * (2 t_c /(K_c+eps) - 2 I_c/(K_c+eps)^2) = qa*t_c + qb
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float K = (float)sums[6 + c] + 1e-7f, I = (float)sums[2 + c];
+        qa[c] = -0.5f / K; qb[c] = 0.5f * I / (K * K);
+    }
+    const float inv_p = 1.f / (float)P;
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        float z[4], pr[4], m, logs;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) z[c] = Elem<T>::load(logits + p * ldl + c);
+        softmax4(z, pr, m, logs);
+        const int y = (int)seg[p];
+        float wy = 0.f, q[4], dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c == y) wy = c_ce_w[c];
+            q[c] = qb[c] + ((c == y) ? qa[c] : 0.f);
+            dot = fmaf(pr[c], q[c], dot);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float g = inv_w * wy * (pr[c] - ((c == y) ? 1.f : 0.f)) + pr[c] * (q[c] - dot);
+            Elem<T>::store(dlogits + p * lddl + c, g * go);
+        }
+        const float e = Elem<T>::load(edge + p), et = edge_t[p];
+        Elem<T>::store(dedge + p, go * inv_p * (e - et) / fmaxf((1.f - e) * e, 1e-12f));
+    }
+}
+
+}  // namespace saunet
+
+using namespace saunet;
+
+extern "C" {
+
+int saunet_dual_loss_forward(int dtype, const void* logits, int ldl, const void* edge, const int64_t* seg_t, const float* edge_t,
+                             int64_t pixels, double* sums, void* stream)
+{
+    long blocks = (pixels + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SAUNET_F32) hipLaunchKernelGGL(dual_loss_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)logits, ldl, (const float*)edge, seg_t, edge_t, (long)pixels, sums);
+    else if (dtype == SAUNET_BF16) hipLaunchKernelGGL(dual_loss_fwd_kernel<u16>, dim3((unsigned)blocks), dim3(256), 0, st, (const u16*)logits, ldl, (const u16*)edge, seg_t, edge_t, (long)pixels, sums);
+    else return set_error(SAUNET_BAD_DTYPE, "dual_loss: dtype %d", dtype);
+    SAUNET_CHECK_LAUNCH("dual_loss_forward");
+    return SAUNET_OK;
+}
+
+int saunet_dual_loss_finalize(const double* sums, int64_t pixels, float* loss, float* metrics, void* stream)
+{
+    hipLaunchKernelGGL(dual_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, (long)pixels, loss, metrics);
+    SAUNET_CHECK_LAUNCH("dual_loss_finalize");
+    return SAUNET_OK;
+}
+
+int saunet_dual_loss_backward(int dtype, const void* logits, int ldl, const void* edge, const int64_t* seg_t, const float* edge_t,
+                              int64_t pixels, const double* sums, const float* dloss, void* dlogits, int lddl, void* dedge, void* stream)
+{
+    long blocks = (pixels + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SAUNET_F32) hipLaunchKernelGGL(dual_loss_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)logits, ldl, (const float*)edge, seg_t, edge_t, (long)pixels, sums, dloss, (float*)dlogits, lddl, (float*)dedge);
+    else if (dtype == SAUNET_BF16) hipLaunchKernelGGL(dual_loss_bwd_kernel<u16>, dim3((unsigned)blocks), dim3(256), 0, st, (const u16*)logits, ldl, (const u16*)edge, seg_t, edge_t, (long)pixels, sums, dloss, (u16*)dlogits, lddl, (u16*)dedge);
+    else return set_error(SAUNET_BAD_DTYPE, "dual_loss: dtype %d", dtype);
+    SAUNET_CHECK_LAUNCH("dual_loss_backward");
+    return SAUNET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,348 @@
+// BatchNorm (training + eval) as reduce / finalise / apply kernels for NHWC activations.
+// Statistics are taken either in the producing convolution's epilogue (conv_igemm.hip) or by
+// bn_stats_kernel below; the normalise(+ReLU) step is either folded into the consuming convolution's
+// operand load (prologue) or materialised by affine_act_kernel.  Sums are float64 end to end.
+// Replaces nn.BatchNorm2d / SynchronizedBatchNorm2d fwd+bwd (/root/reference/models/norm.py:16-22,
+// lib/nn/modules/batchnorm.py:58-61).
+#include "common.h"
+#include <initializer_list>
+
+namespace saunet {
+
+// Work decomposition shared by the per-channel kernels: a block owns rows [p0,p1); channel chunks are
+// processed in groups of <=256; inside a group thread -> (row lane, chunk) so a wave touches contiguous
+// bytes.  V = elements per chunk (16-byte vectors when the view is aligned, else 1).
+template <typename T, int V> struct ChunkIO {
+    __device__ static __forceinline__ void load(const T* p, float* f)
+    {
+        if constexpr (V == 1) f[0] = Elem<T>::load(p);
+        else Vec16<T>::unpack(*(const u32x4*)p, f);
+    }
+    __device__ static __forceinline__ void store(T* p, const float* f)
+    {
+        if constexpr (V == 1) Elem<T>::store(p, f[0]);
+        else *(u32x4*)p = Vec16<T>::pack(f);
+    }
+};
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, long P, int C, int ld, long rpb,
+                                                       double* __restrict__ gsum, double* __restrict__ gsq)
+{
+    extern __shared__ double s_red[];  // [2][C]
+    for (int i = threadIdx.x; i < 2 * C; i += 256) s_red[i] = 0.0;
+    __syncthreads();
+    const long p0 = blockIdx.x * rpb, p1 = min(p0 + rpb, P);
+    const int CH = C / V;
+    for (int cb = 0; cb < CH; cb += 256) {
+        const int cw = min(256, CH - cb), rl = 256 / cw;
+        const int ch = cb + threadIdx.x % cw, r0 = threadIdx.x / cw;
+        if (r0 >= rl) continue;
+        double ds[V], dq[V];
+        float fs[V], fq[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { ds[j] = dq[j] = 0.0; fs[j] = fq[j] = 0.f; }
+        int cnt = 0;
+        for (long p = p0 + r0; p < p1; p += rl) {
+            float f[V];
+            ChunkIO<T, V>::load(x + p * ld + ch * V, f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { fs[j] += f[j]; fq[j] = fmaf(f[j], f[j], fq[j]); }
+            if (++cnt == 128) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) { ds[j] += fs[j]; dq[j] += fq[j]; fs[j] = fq[j] = 0.f; }
+                cnt = 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            atomicAdd(&s_red[ch * V + j], ds[j] + (double)fs[j]);
+            atomicAdd(&s_red[C + ch * V + j], dq[j] + (double)fq[j]);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) { atomicAdd(&gsum[c], s_red[c]); atomicAdd(&gsq[c], s_red[C + c]); }
+}
+
+__global__ void bn_finalize_kernel(int C, const double* __restrict__ sum, const double* __restrict__ sq, double count,
+                                   const float* __restrict__ cbias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
+                                   float* __restrict__ invstd_o, int training)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean, invstd;
+    if (training) {
+        double m = sum[c] / count;
+        double var = sq[c] / count - m * m;
+        if (var < 0.0) var = 0.0;
+        if (cbias) m += (double)cbias[c];
+        mean = (float)m;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (rmean) {
+            double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+    } else {
+        mean = rmean[c];
+        invstd = 1.f / sqrtf(rvar[c] + eps);
+    }
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float s = g * invstd;
+    scale[c] = s; shift[c] = b - mean * s;
+    if (mean_o) mean_o[c] = mean;
+    if (invstd_o) invstd_o[c] = invstd;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const T* __restrict__ res, int ldr, int relu,
+                                                         T* __restrict__ y, int ldy, long P, int C, long rpb)
+{
+    const long p0 = blockIdx.x * rpb, p1 = min(p0 + rpb, P);
+    const int CH = C / V;
+    for (int cb = 0; cb < CH; cb += 256) {
+        const int cw = min(256, CH - cb), rl = 256 / cw;
+        const int ch = cb + threadIdx.x % cw, r0 = threadIdx.x / cw;
+        if (r0 >= rl) continue;
+        float s[V], t[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { s[j] = scale ? scale[ch * V + j] : 1.f; t[j] = shift ? shift[ch * V + j] : 0.f; }
+        for (long p = p0 + r0; p < p1; p += rl) {
+            float f[V], r[V];
+            ChunkIO<T, V>::load(x + p * ldx + ch * V, f);
+            if (res) ChunkIO<T, V>::load(res + p * ldr + ch * V, r);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float v = fmaf(f[j], s[j], t[j]);
+                if (res) v += r[j];
+                f[j] = relu ? fmaxf(v, 0.f) : v;
+            }
+            ChunkIO<T, V>::store(y + p * ldy + ch * V, f);
+        }
+    }
+}
+
+struct BnBwdArgs {
+    const void* dy; int lddy; const void* x; int ldx; const void* res; int ldr;
+    const float* scale; const float* shift; const float* mean; const float* invstd; int relu;
+    double* sums; double count; int training, accumulate;
+    void* dx; int lddx; void* dres; int lddres; float* dgamma; float* dbeta;
+    long P; int C; long rpb;
+};
+
+template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a)
+{
+    extern __shared__ double s_red[];  // [2][C]
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) s_red[i] = 0.0;
+    __syncthreads();
+    const long p0 = blockIdx.x * a.rpb, p1 = min(p0 + a.rpb, a.P);
+    const int CH = a.C / V;
+    const T* dy = (const T*)a.dy; const T* x = (const T*)a.x; const T* res = (const T*)a.res;
+    for (int cb = 0; cb < CH; cb += 256) {
+        const int cw = min(256, CH - cb), rl = 256 / cw;
+        const int ch = cb + threadIdx.x % cw, r0 = threadIdx.x / cw;
+        if (r0 >= rl) continue;
+        float s[V], t[V], mu[V], is[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            s[j] = a.scale[ch * V + j]; t[j] = a.shift[ch * V + j]; mu[j] = a.mean[ch * V + j]; is[j] = a.invstd[ch * V + j];
+        }
+        double d1[V], d2[V]; float f1[V], f2[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { d1[j] = d2[j] = 0.0; f1[j] = f2[j] = 0.f; }
+        int cnt = 0;
+        for (long p = p0 + r0; p < p1; p += rl) {
+            float g[V], xv[V], r[V];
+            ChunkIO<T, V>::load(dy + p * a.lddy + ch * V, g);
+            ChunkIO<T, V>::load(x + p * a.ldx + ch * V, xv);
+            if (res) ChunkIO<T, V>::load(res + p * a.ldr + ch * V, r);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float gv = g[j];
+                if (a.relu) {
+                    float o = fmaf(xv[j], s[j], t[j]);
+                    if (res) o += r[j];
+                    if (!(o > 0.f)) gv = 0.f;
+                }
+                f1[j] += gv;
+                f2[j] = fmaf(gv, (xv[j] - mu[j]) * is[j], f2[j]);
+            }
+            if (++cnt == 128) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) { d1[j] += f1[j]; d2[j] += f2[j]; f1[j] = f2[j] = 0.f; }
+                cnt = 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            atomicAdd(&s_red[ch * V + j], d1[j] + (double)f1[j]);
+            atomicAdd(&s_red[a.C + ch * V + j], d2[j] + (double)f2[j]);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * a.C; c += 256) atomicAdd(&a.sums[c], s_red[c]);
+}
+
+template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a)
+{
+    const long p0 = blockIdx.x * a.rpb, p1 = min(p0 + a.rpb, a.P);
+    const int CH = a.C / V;
+    const T* dy = (const T*)a.dy; const T* x = (const T*)a.x; const T* res = (const T*)a.res;
+    T* dx = (T*)a.dx; T* dres = (T*)a.dres;
+    if (blockIdx.x == 0 && a.dgamma) {
+        for (int c = threadIdx.x; c < a.C; c += 256) { a.dbeta[c] = (float)a.sums[c]; a.dgamma[c] = (float)a.sums[a.C + c]; }
+    }
+    for (int cb = 0; cb < CH; cb += 256) {
+        const int cw = min(256, CH - cb), rl = 256 / cw;
+        const int ch = cb + threadIdx.x % cw, r0 = threadIdx.x / cw;
+        if (r0 >= rl) continue;
+        float s[V], t[V], mu[V], is[V], c1[V], c2[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int c = ch * V + j;
+            s[j] = a.scale[c]; t[j] = a.shift[c]; mu[j] = a.mean[c]; is[j] = a.invstd[c];
+            c1[j] = a.training ? (float)(a.sums[c] / a.count) : 0.f;
+            c2[j] = a.training ? (float)(a.sums[a.C + c] / a.count) : 0.f;
+        }
+        for (long p = p0 + r0; p < p1; p += rl) {
+            float g[V], xv[V], r[V], o[V];
+            ChunkIO<T, V>::load(dy + p * a.lddy + ch * V, g);
+            ChunkIO<T, V>::load(x + p * a.ldx + ch * V, xv);
+            if (res) ChunkIO<T, V>::load(res + p * a.ldr + ch * V, r);
+            if (a.accumulate) ChunkIO<T, V>::load(dx + p * a.lddx + ch * V, o);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float gv = g[j];
+                if (a.relu) {
+                    float ov = fmaf(xv[j], s[j], t[j]);
+                    if (res) ov += r[j];
+                    if (!(ov > 0.f)) gv = 0.f;
+                }
+                g[j] = gv;
+                float d = s[j] * (gv - c1[j] - (xv[j] - mu[j]) * is[j] * c2[j]);
+                o[j] = a.accumulate ? o[j] + d : d;
+            }
+            ChunkIO<T, V>::store(dx + p * a.lddx + ch * V, o);
+            if (dres) ChunkIO<T, V>::store(dres + p * a.lddres + ch * V, g);
+        }
+    }
+}
+
+static inline long rows_per_block(long P, int C, int V, int* blocks)
+{
+    // enough blocks to fill the chip, each with a few thousand elements per thread at most
+    long nb = (P * (long)(C / V) + 256L * 8 - 1) / (256L * 8);
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    long rpb = (P + nb - 1) / nb;
+    *blocks = (int)((P + rpb - 1) / rpb);
+    return rpb;
+}
+
+// vector path needs every view 16-byte aligned with channel counts/strides multiples of the chunk
+static inline bool vec_ok(int dtype, int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs)
+{
+    const int epc = dtype == SAUNET_BF16 ? 8 : 4;
+    if (C % epc) return false;
+    for (int l : lds) if (l % epc) return false;
+    for (const void* p : ptrs) if (((uintptr_t)p) & 15) return false;
+    return true;
+}
+
+}  // namespace saunet
+
+using namespace saunet;
+
+#define DISPATCH_TV(dtype, vec, CALL)                                                     \
+    do {                                                                                  \
+        if ((dtype) == SAUNET_F32) { if (vec) { CALL(float, 4); } else { CALL(float, 1); } } \
+        else if ((dtype) == SAUNET_BF16) { if (vec) { CALL(u16, 8); } else { CALL(u16, 1); } } \
+        else return set_error(SAUNET_BAD_DTYPE, "dtype %d", (dtype));                     \
+    } while (0)
+
+extern "C" {
+
+int saunet_bn_stats(int dtype, const void* x, int64_t pixels, int C, int ld, double* sum, double* sumsq, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (C > 4096) return set_error(SAUNET_UNSUPPORTED, "bn_stats: C=%d > 4096", C);
+    const bool vec = vec_ok(dtype, C, {ld}, {x});
+    int blocks; const int V = vec ? (dtype == SAUNET_BF16 ? 8 : 4) : 1;
+    long rpb = rows_per_block(pixels, C, V, &blocks);
+#define CALL(TT, VV) hipLaunchKernelGGL((bn_stats_kernel<TT, VV>), dim3(blocks), dim3(256), 2 * C * sizeof(double), st, (const TT*)x, (long)pixels, C, ld, rpb, sum, sumsq)
+    DISPATCH_TV(dtype, vec, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("bn_stats");
+    return SAUNET_OK;
+}
+
+int saunet_bn_finalize(int C, const double* sum, const double* sumsq, double count, const float* conv_bias,
+                       const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, float* scale, float* shift,
+                       float* mean, float* invstd, int training, void* stream)
+{
+    if (!training && (!running_mean || !running_var)) return set_error(SAUNET_BAD_SHAPE, "bn_finalize: eval mode needs running stats");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, sum, sumsq, count, conv_bias,
+                       gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd, training);
+    SAUNET_CHECK_LAUNCH("bn_finalize");
+    return SAUNET_OK;
+}
+
+int saunet_affine_act(int dtype, const void* x, int ldx, const float* scale, const float* shift,
+                      const void* residual, int ldr, int relu, void* y, int ldy, int64_t pixels, int C, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = residual ? vec_ok(dtype, C, {ldx, ldy, ldr}, {x, y, residual}) : vec_ok(dtype, C, {ldx, ldy}, {x, y});
+    int blocks; const int V = vec ? (dtype == SAUNET_BF16 ? 8 : 4) : 1;
+    long rpb = rows_per_block(pixels, C, V, &blocks);
+#define CALL(TT, VV) hipLaunchKernelGGL((affine_act_kernel<TT, VV>), dim3(blocks), dim3(256), 0, st, (const TT*)x, ldx, scale, shift, (const TT*)residual, ldr, relu, (TT*)y, ldy, (long)pixels, C, rpb)
+    DISPATCH_TV(dtype, vec, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("affine_act");
+    return SAUNET_OK;
+}
+
+int saunet_bn_backward_reduce(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,
+                              const float* scale, const float* shift, const float* mean, const float* invstd,
+                              int relu, double* sums, int64_t pixels, int C, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = residual ? vec_ok(dtype, C, {lddy, ldx, ldr}, {dy, x, residual}) : vec_ok(dtype, C, {lddy, ldx}, {dy, x});
+    BnBwdArgs a{}; a.dy = dy; a.lddy = lddy; a.x = x; a.ldx = ldx; a.res = residual; a.ldr = ldr; a.scale = scale; a.shift = shift;
+    a.mean = mean; a.invstd = invstd; a.relu = relu; a.sums = sums; a.P = pixels; a.C = C;
+    int blocks; const int V = vec ? (dtype == SAUNET_BF16 ? 8 : 4) : 1;
+    a.rpb = rows_per_block(pixels, C, V, &blocks);
+#define CALL(TT, VV) hipLaunchKernelGGL((bn_bwd_reduce_kernel<TT, VV>), dim3(blocks), dim3(256), 2 * C * sizeof(double), st, a)
+    DISPATCH_TV(dtype, vec, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("bn_backward_reduce");
+    return SAUNET_OK;
+}
+
+int saunet_bn_backward_apply(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,
+                             const float* scale, const float* shift, const float* mean, const float* invstd,
+                             int relu, const double* sums, double count, int training, int accumulate,
+                             void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta,
+                             int64_t pixels, int C, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    bool vec = vec_ok(dtype, C, {lddy, ldx, lddx}, {dy, x, dx});
+    if (residual) vec = vec && vec_ok(dtype, C, {ldr}, {residual});
+    if (dres) vec = vec && vec_ok(dtype, C, {lddres}, {dres});
+    BnBwdArgs a{}; a.dy = dy; a.lddy = lddy; a.x = x; a.ldx = ldx; a.res = residual; a.ldr = ldr; a.scale = scale; a.shift = shift;
+    a.mean = mean; a.invstd = invstd; a.relu = relu; a.sums = (double*)sums; a.count = count; a.training = training;
+    a.accumulate = accumulate; a.dx = dx; a.lddx = lddx; a.dres = dres; a.lddres = lddres; a.dgamma = dgamma; a.dbeta = dbeta;
+    a.P = pixels; a.C = C;
+    int blocks; const int V = vec ? (dtype == SAUNET_BF16 ? 8 : 4) : 1;
+    a.rpb = rows_per_block(pixels, C, V, &blocks);
+#define CALL(TT, VV) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, VV>), dim3(blocks), dim3(256), 0, st, a)
+    DISPATCH_TV(dtype, vec, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("bn_backward_apply");
+    return SAUNET_OK;
+}
+
+}  // extern "C"

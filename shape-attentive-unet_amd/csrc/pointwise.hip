@@ -1,0 +1,503 @@
+// Bandwidth kernels of the SAUNet path: bilinear resampling (align_corners=True), 2x2 pooling,
+// channel-slice copies (the only "cat"), sigmoid, the gate multiply, and the dual-attention tail
+// (global average pool -> SE excitation -> (S+1)*F*se).  All NHWC, float32 or bf16 storage.
+// Reference call sites: /root/reference/models/models.py:337-389, models/GSConv.py:53-57,
+// models/attention_blocks.py:50-57,165-173,233-238.
+#include "common.h"
+
+namespace saunet {
+
+// ------------------------------------------------------------------------------------------ bilinear
+struct BilArgs {
+    const void* src; void* dst; int N, H, W, C, lds, Ho, Wo, ldd; float sy, sx; int accumulate;
+};
+
+__device__ __forceinline__ void bil_coord(int o, float scale, int in, int& i0, int& i1, float& l1)
+{
+    float s = scale * (float)o;
+    i0 = (int)s;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+// one thread per (output pixel, channel): y = hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11)
+template <typename T> __global__ __launch_bounds__(256) void bilinear_fwd_kernel(BilArgs a)
+{
+    const long total = (long)a.N * a.Ho * a.Wo * a.C;
+    const T* x = (const T*)a.src; T* y = (T*)a.dst;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c = (int)(i % a.C); long t = i / a.C;
+        int ow = (int)(t % a.Wo); t /= a.Wo; int oh = (int)(t % a.Ho); int n = (int)(t / a.Ho);
+        int y0, y1, x0, x1; float ly, lx;
+        bil_coord(oh, a.sy, a.H, y0, y1, ly); bil_coord(ow, a.sx, a.W, x0, x1, lx);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const T* b = x + (long)n * a.H * a.W * a.lds + c;
+        float v00 = Elem<T>::load(b + ((long)y0 * a.W + x0) * a.lds), v01 = Elem<T>::load(b + ((long)y0 * a.W + x1) * a.lds);
+        float v10 = Elem<T>::load(b + ((long)y1 * a.W + x0) * a.lds), v11 = Elem<T>::load(b + ((long)y1 * a.W + x1) * a.lds);
+        float v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+        Elem<T>::store(y + (((long)n * a.Ho + oh) * a.Wo + ow) * a.ldd + c, v);
+    }
+}
+
+// gather form of the adjoint (deterministic, no atomics, dtype-agnostic): for every INPUT pixel visit
+// the output pixels whose two source rows/cols can include it and re-derive their weights exactly.
+template <typename T> __global__ __launch_bounds__(256) void bilinear_bwd_kernel(BilArgs a)
+{
+    // here src = dy [N,Ho,Wo,C] (lds), dst = dx [N,H,W,C] (ldd)
+    const long total = (long)a.N * a.H * a.W * a.C;
+    const T* dy = (const T*)a.src; T* dx = (T*)a.dst;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c = (int)(i % a.C); long t = i / a.C;
+        int ix = (int)(t % a.W); t /= a.W; int iy = (int)(t % a.H); int n = (int)(t / a.H);
+        int oy_lo = 0, oy_hi = a.Ho - 1, ox_lo = 0, ox_hi = a.Wo - 1;
+        if (a.sy > 0.f) { oy_lo = max(0, (int)floorf((iy - 1) / a.sy) - 1); oy_hi = min(a.Ho - 1, (int)ceilf((iy + 1) / a.sy) + 1); }
+        if (a.sx > 0.f) { ox_lo = max(0, (int)floorf((ix - 1) / a.sx) - 1); ox_hi = min(a.Wo - 1, (int)ceilf((ix + 1) / a.sx) + 1); }
+        float acc = 0.f;
+        const T* b = dy + (long)n * a.Ho * a.Wo * a.lds + c;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1; float ly; bil_coord(oy, a.sy, a.H, y0, y1, ly);
+            float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1; float lx; bil_coord(ox, a.sx, a.W, x0, x1, lx);
+                float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+                if (wx == 0.f) continue;
+                acc = fmaf(wy * wx, Elem<T>::load(b + ((long)oy * a.Wo + ox) * a.lds), acc);
+            }
+        }
+        T* o = dx + (((long)n * a.H + iy) * a.W + ix) * a.ldd + c;
+        if (a.accumulate) acc += Elem<T>::load(o);
+        Elem<T>::store(o, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ 2x2 pooling
+struct PoolArgs { const void* x; const void* dy; void* out; int N, H, W, C, ldx, lddy, ldo, is_max, accumulate; };
+
+template <typename T> __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs a)
+{
+    const int Ho = a.H / 2, Wo = a.W / 2;
+    const long total = (long)a.N * Ho * Wo * a.C;
+    const T* x = (const T*)a.x; T* y = (T*)a.out;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c = (int)(i % a.C); long t = i / a.C;
+        int ow = (int)(t % Wo); t /= Wo; int oh = (int)(t % Ho); int n = (int)(t / Ho);
+        const T* b = x + (((long)n * a.H + 2 * oh) * a.W + 2 * ow) * a.ldx + c;
+        float v0 = Elem<T>::load(b), v1 = Elem<T>::load(b + a.ldx), v2 = Elem<T>::load(b + (long)a.W * a.ldx), v3 = Elem<T>::load(b + (long)(a.W + 1) * a.ldx);
+        float v = a.is_max ? fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)) : (v0 + v1 + v2 + v3) * 0.25f;
+        Elem<T>::store(y + i / a.C * a.ldo + c, v);
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolArgs a)
+{
+    const int Ho = a.H / 2, Wo = a.W / 2;
+    const long total = (long)a.N * Ho * Wo * a.C;
+    const T* x = (const T*)a.x; const T* dy = (const T*)a.dy; T* dx = (T*)a.out;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c = (int)(i % a.C); long t = i / a.C;
+        int ow = (int)(t % Wo); t /= Wo; int oh = (int)(t % Ho); int n = (int)(t / Ho);
+        const long off = (((long)n * a.H + 2 * oh) * a.W + 2 * ow);
+        const float g = Elem<T>::load(dy + i / a.C * a.lddy + c);
+        float d[4];
+        if (a.is_max) {
+            const T* b = x + off * a.ldx + c;
+            float v[4] = {Elem<T>::load(b), Elem<T>::load(b + a.ldx), Elem<T>::load(b + (long)a.W * a.ldx), Elem<T>::load(b + (long)(a.W + 1) * a.ldx)};
+            int k = 0; float m = v[0];
+#pragma unroll
+            for (int j = 1; j < 4; ++j) if (v[j] > m) { m = v[j]; k = j; }   // first maximum wins (ATen order)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = (j == k) ? g : 0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = 0.25f * g;
+        }
+        T* o = dx + off * a.ldo + c;
+        const long offs[4] = {0, (long)a.ldo, (long)a.W * a.ldo, (long)(a.W + 1) * a.ldo};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = d[j];
+            if (a.accumulate) v += Elem<T>::load(o + offs[j]);
+            Elem<T>::store(o + offs[j], v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ element-wise
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const TS* __restrict__ s, int lds, TD* __restrict__ d, int ldd, long P, int C, int acc)
+{
+    const long total = P * C;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long p = i / C; int c = (int)(i - p * C);
+        float v = Elem<TS>::load(s + p * lds + c);
+        if (acc) v += Elem<TD>::load(d + p * ldd + c);
+        Elem<TD>::store(d + p * ldd + c, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sigmoid_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, long P, int C)
+{
+    const long total = P * C;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long p = i / C; int c = (int)(i - p * C);
+        float v = Elem<T>::load(x + p * ldx + c);
+        Elem<T>::store(y + p * ldy + c, 1.f / (1.f + expf(-v)));
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const T* __restrict__ y, int ldyy, const T* __restrict__ dy, int lddy,
+                                                          T* __restrict__ dx, int lddx, long P, int C, int acc)
+{
+    const long total = P * C;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long p = i / C; int c = (int)(i - p * C);
+        float s = Elem<T>::load(y + p * ldyy + c), g = Elem<T>::load(dy + p * lddy + c);
+        float v = g * s * (1.f - s);
+        if (acc) v += Elem<T>::load(dx + p * lddx + c);
+        Elem<T>::store(dx + p * lddx + c, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gate_mul_fwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ al, T* __restrict__ y, int ldy, long P, int C)
+{
+    const long total = P * C;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long p = i / C; int c = (int)(i - p * C);
+        Elem<T>::store(y + p * ldy + c, Elem<T>::load(x + p * ldx + c) * (Elem<T>::load(al + p) + 1.f));
+    }
+}
+// one wave per pixel: dx = dy*(alpha+1);  dalpha = sum_c dy*x
+template <typename T>
+__global__ __launch_bounds__(256) void gate_mul_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ al, const T* __restrict__ dy, int lddy,
+                                                           T* __restrict__ dx, int lddx, T* __restrict__ dal, long P, int C)
+{
+    const int lane = threadIdx.x & 63;
+    for (long p = blockIdx.x * 4L + (threadIdx.x >> 6); p < P; p += (long)gridDim.x * 4) {
+        const float a1 = Elem<T>::load(al + p) + 1.f;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            float g = Elem<T>::load(dy + p * lddy + c);
+            s = fmaf(g, Elem<T>::load(x + p * ldx + c), s);
+            Elem<T>::store(dx + p * lddx + c, g * a1);
+        }
+        s = wave_sum(s);
+        if (lane == 0) Elem<T>::store(dal + p, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dual attention tail
+// pooled[n][c] = mean over HW.  grid = (N, row splits); float atomics into zeroed pooled (scaled by 1/HW)
+template <typename T>
+__global__ __launch_bounds__(256) void global_avgpool_kernel(const T* __restrict__ x, int HW, int C, int ld, float* __restrict__ pooled, int rows_per_block)
+{
+    const int n = blockIdx.x;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, HW);
+    const float inv = 1.f / (float)HW;
+    for (int cb = 0; cb < C; cb += 256) {
+        const int cw = min(256, C - cb), rl = 256 / cw;
+        const int c = cb + threadIdx.x % cw, rr = threadIdx.x / cw;
+        if (rr >= rl) continue;
+        float s = 0.f;
+        for (int r = r0 + rr; r < r1; r += rl) s += Elem<T>::load(x + ((long)n * HW + r) * ld + c);
+        atomicAdd(&pooled[n * C + c], s * inv);
+    }
+}
+
+// one block per sample: hidden = relu(W1 pooled + b1); se = sigmoid(W2 hidden + b2)
+__global__ __launch_bounds__(256) void se_excite_kernel(const float* __restrict__ pooled, int C, int Cr, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                        float* __restrict__ hidden, float* __restrict__ se)
+{
+    __shared__ float sh[64];
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* pv = pooled + (long)n * C;
+    for (int j = wave; j < Cr; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(w1[(long)j * C + c], pv[c], s);
+        s = wave_sum(s);
+        if (lane == 0) { float h = fmaxf(s + b1[j], 0.f); sh[j] = h; hidden[(long)n * Cr + j] = h; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = b2[c];
+        for (int j = 0; j < Cr; ++j) s = fmaf(w2[(long)c * Cr + j], sh[j], s);
+        se[(long)n * C + c] = 1.f / (1.f + expf(-s));
+    }
+}
+
+__global__ __launch_bounds__(256) void se_excite_bwd_kernel(const float* __restrict__ pooled, const float* __restrict__ hidden, const float* __restrict__ se,
+                                                            const float* __restrict__ dse, int C, int Cr, const float* __restrict__ w1,
+                                                            const float* __restrict__ w2, float* __restrict__ dpooled, float* __restrict__ dw1,
+                                                            float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2)
+{
+    extern __shared__ float sm[];   // dz2[C], dz1[Cr]
+    float* dz2 = sm; float* dz1 = sm + C;
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* pv = pooled + (long)n * C; const float* hv = hidden + (long)n * Cr;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = se[(long)n * C + c];
+        float d = dse[(long)n * C + c] * s * (1.f - s);
+        dz2[c] = d;
+        atomicAdd(&db2[c], d);
+        for (int j = 0; j < Cr; ++j) atomicAdd(&dw2[(long)c * Cr + j], d * hv[j]);
+    }
+    __syncthreads();
+    for (int j = wave; j < Cr; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(w2[(long)c * Cr + j], dz2[c], s);
+        s = wave_sum(s);
+        if (lane == 0) { float d = hv[j] > 0.f ? s : 0.f; dz1[j] = d; atomicAdd(&db1[j], d); }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int j = 0; j < Cr; ++j) { s = fmaf(w1[(long)j * C + c], dz1[j], s); atomicAdd(&dw1[(long)j * C + c], dz1[j] * pv[c]); }
+        dpooled[(long)n * C + c] = s;
+    }
+}
+
+// out = (S+1) * F * se[n][c]
+template <typename T>
+__global__ __launch_bounds__(256) void att_combine_fwd_kernel(const T* __restrict__ F, int ldf, const T* __restrict__ S, const float* __restrict__ se,
+                                                              T* __restrict__ out, int ldo, int HW, int C, long total)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long p = i / C; int c = (int)(i - p * C); int n = (int)(p / HW);
+        float v = (Elem<T>::load(S + p) + 1.f) * Elem<T>::load(F + p * ldf + c) * se[(long)n * C + c];
+        Elem<T>::store(out + p * ldo + c, v);
+    }
+}
+// block = (sample n, row range): dF = dout*(S+1)*se ; dS[p] = sum_c dout*F*se ; dse[n][c] += sum_p dout*(S+1)*F
+template <typename T>
+__global__ __launch_bounds__(256) void att_combine_bwd_kernel(const T* __restrict__ F, int ldf, const T* __restrict__ S, const float* __restrict__ se,
+                                                              const T* __restrict__ dout, int lddo, T* __restrict__ dF, int lddf, T* __restrict__ dS,
+                                                              float* __restrict__ dse, int HW, int C, int rows_per_block)
+{
+    extern __shared__ float s_dse[];  // [C]
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < C; c += 256) s_dse[c] = 0.f;
+    __syncthreads();
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, HW);
+    const float* sev = se + (long)n * C;
+    // a wave walks rows; lanes walk channels; per-lane partial dse kept in registers for up to 16 channel strips
+    float part[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) part[k] = 0.f;
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const long p = (long)n * HW + r;
+        const float s1 = Elem<T>::load(S + p) + 1.f;
+        float ds = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) {
+                float g = Elem<T>::load(dout + p * lddo + c), f = Elem<T>::load(F + p * ldf + c), e = sev[c];
+                Elem<T>::store(dF + p * lddf + c, g * s1 * e);
+                ds = fmaf(g * f, e, ds);
+                part[k] = fmaf(g * s1, f, part[k]);
+            }
+        }
+        ds = wave_sum(ds);
+        if (lane == 0) Elem<T>::store(dS + p, ds);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int c = lane + 64 * k; if (c < C) atomicAdd(&s_dse[c], part[k]); }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(&dse[(long)n * C + c], s_dse[c]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_pooled_grad_kernel(T* __restrict__ dF, int lddf, const float* __restrict__ dpooled, int HW, int C, long total)
+{
+    const float inv = 1.f / (float)HW;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        long p = i / C; int c = (int)(i - p * C); int n = (int)(p / HW);
+        T* o = dF + p * lddf + c;
+        Elem<T>::store(o, Elem<T>::load(o) + dpooled[(long)n * C + c] * inv);
+    }
+}
+
+static inline int grid_for(long total) { long b = (total + 255) / 256; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
+
+}  // namespace saunet
+
+using namespace saunet;
+
+#define DISPATCH_T(dtype, CALL)                                            \
+    do {                                                                   \
+        if ((dtype) == SAUNET_F32) { CALL(float); }                        \
+        else if ((dtype) == SAUNET_BF16) { CALL(u16); }                    \
+        else return set_error(SAUNET_BAD_DTYPE, "dtype %d", (dtype));      \
+    } while (0)
+
+extern "C" {
+
+int saunet_bilinear_forward(int dtype, const void* x, int N, int H, int W, int C, int ldx, void* y, int Ho, int Wo, int ldy, void* stream)
+{
+    BilArgs a{x, y, N, H, W, C, ldx, Ho, Wo, ldy, Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f, 0};
+    const long total = (long)N * Ho * Wo * C;
+#define CALL(TT) hipLaunchKernelGGL(bilinear_fwd_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a)
+    DISPATCH_T(dtype, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("bilinear_forward");
+    return SAUNET_OK;
+}
+
+int saunet_bilinear_backward(int dtype, const void* dy, int N, int Ho, int Wo, int C, int lddy, void* dx, int H, int W, int lddx, int accumulate, void* stream)
+{
+    BilArgs a{dy, dx, N, H, W, C, lddy, Ho, Wo, lddx, Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f, accumulate};
+    const long total = (long)N * H * W * C;
+#define CALL(TT) hipLaunchKernelGGL(bilinear_bwd_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a)
+    DISPATCH_T(dtype, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("bilinear_backward");
+    return SAUNET_OK;
+}
+
+int saunet_pool2x2_forward(int dtype, int is_max, const void* x, int N, int H, int W, int C, int ldx, void* y, int ldy, void* stream)
+{
+    if ((H | W) & 1) return set_error(SAUNET_BAD_SHAPE, "pool2x2: odd size %dx%d", H, W);
+    PoolArgs a{x, nullptr, y, N, H, W, C, ldx, 0, ldy, is_max, 0};
+    const long total = (long)N * (H / 2) * (W / 2) * C;
+#define CALL(TT) hipLaunchKernelGGL(pool_fwd_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a)
+    DISPATCH_T(dtype, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("pool2x2_forward");
+    return SAUNET_OK;
+}
+
+int saunet_pool2x2_backward(int dtype, int is_max, const void* x, const void* dy, int N, int H, int W, int C, int ldx, int lddy, void* dx, int lddx, int accumulate, void* stream)
+{
+    if ((H | W) & 1) return set_error(SAUNET_BAD_SHAPE, "pool2x2: odd size %dx%d", H, W);
+    PoolArgs a{x, dy, dx, N, H, W, C, ldx, lddy, lddx, is_max, accumulate};
+    const long total = (long)N * (H / 2) * (W / 2) * C;
+#define CALL(TT) hipLaunchKernelGGL(pool_bwd_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a)
+    DISPATCH_T(dtype, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("pool2x2_backward");
+    return SAUNET_OK;
+}
+
+int saunet_copy_channels(int dtype_src, int dtype_dst, const void* src, int lds, void* dst, int ldd, int64_t pixels, int C, int accumulate, void* stream)
+{
+    const long total = pixels * C;
+    hipStream_t st = (hipStream_t)stream; dim3 g(grid_for(total)), b(256);
+    if (dtype_src == SAUNET_F32 && dtype_dst == SAUNET_F32) hipLaunchKernelGGL((copy_channels_kernel<float, float>), g, b, 0, st, (const float*)src, lds, (float*)dst, ldd, (long)pixels, C, accumulate);
+    else if (dtype_src == SAUNET_F32 && dtype_dst == SAUNET_BF16) hipLaunchKernelGGL((copy_channels_kernel<float, u16>), g, b, 0, st, (const float*)src, lds, (u16*)dst, ldd, (long)pixels, C, accumulate);
+    else if (dtype_src == SAUNET_BF16 && dtype_dst == SAUNET_F32) hipLaunchKernelGGL((copy_channels_kernel<u16, float>), g, b, 0, st, (const u16*)src, lds, (float*)dst, ldd, (long)pixels, C, accumulate);
+    else if (dtype_src == SAUNET_BF16 && dtype_dst == SAUNET_BF16) hipLaunchKernelGGL((copy_channels_kernel<u16, u16>), g, b, 0, st, (const u16*)src, lds, (u16*)dst, ldd, (long)pixels, C, accumulate);
+    else return set_error(SAUNET_BAD_DTYPE, "copy_channels: dtypes %d %d", dtype_src, dtype_dst);
+    SAUNET_CHECK_LAUNCH("copy_channels");
+    return SAUNET_OK;
+}
+
+int saunet_sigmoid_forward(int dtype, const void* x, int ldx, void* y, int ldy, int64_t pixels, int C, void* stream)
+{
+    const long total = pixels * C;
+#define CALL(TT) hipLaunchKernelGGL(sigmoid_fwd_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const TT*)x, ldx, (TT*)y, ldy, (long)pixels, C)
+    DISPATCH_T(dtype, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("sigmoid_forward");
+    return SAUNET_OK;
+}
+
+int saunet_sigmoid_backward(int dtype, const void* y, int ldyy, const void* dy, int lddy, void* dx, int lddx, int64_t pixels, int C, int accumulate, void* stream)
+{
+    const long total = pixels * C;
+#define CALL(TT) hipLaunchKernelGGL(sigmoid_bwd_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const TT*)y, ldyy, (const TT*)dy, lddy, (TT*)dx, lddx, (long)pixels, C, accumulate)
+    DISPATCH_T(dtype, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("sigmoid_backward");
+    return SAUNET_OK;
+}
+
+int saunet_gate_mul_forward(int dtype, const void* x, int ldx, const void* alpha, void* y, int ldy, int64_t pixels, int C, void* stream)
+{
+    const long total = pixels * C;
+#define CALL(TT) hipLaunchKernelGGL(gate_mul_fwd_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const TT*)x, ldx, (const TT*)alpha, (TT*)y, ldy, (long)pixels, C)
+    DISPATCH_T(dtype, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("gate_mul_forward");
+    return SAUNET_OK;
+}
+
+int saunet_gate_mul_backward(int dtype, const void* x, int ldx, const void* alpha, const void* dy, int lddy,
+                             void* dx, int lddx, void* dalpha, int64_t pixels, int C, void* stream)
+{
+    long blocks = (pixels + 3) / 4; if (blocks > 16384) blocks = 16384;
+#define CALL(TT) hipLaunchKernelGGL(gate_mul_bwd_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const TT*)x, ldx, (const TT*)alpha, (const TT*)dy, lddy, (TT*)dx, lddx, (TT*)dalpha, (long)pixels, C)
+    DISPATCH_T(dtype, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("gate_mul_backward");
+    return SAUNET_OK;
+}
+
+int saunet_global_avgpool(int dtype, const void* x, int N, int HW, int C, int ldx, float* pooled, void* stream)
+{
+    int splits = (HW + 255) / 256; if (splits > 64) splits = 64;
+    int rpb = (HW + splits - 1) / splits; splits = (HW + rpb - 1) / rpb;
+    if (hipMemsetAsync(pooled, 0, sizeof(float) * (size_t)N * C, (hipStream_t)stream) != hipSuccess) return set_error(SAUNET_LAUNCH_FAILED, "avgpool memset");
+#define CALL(TT) hipLaunchKernelGGL(global_avgpool_kernel<TT>, dim3(N, splits), dim3(256), 0, (hipStream_t)stream, (const TT*)x, HW, C, ldx, pooled, rpb)
+    DISPATCH_T(dtype, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("global_avgpool");
+    return SAUNET_OK;
+}
+
+int saunet_se_excite(const float* pooled, int N, int C, int Cr, const float* w1, const float* b1,
+                     const float* w2, const float* b2, float* hidden, float* se, void* stream)
+{
+    if (Cr > 64) return set_error(SAUNET_UNSUPPORTED, "se_excite: reduced channels %d > 64", Cr);
+    hipLaunchKernelGGL(se_excite_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, pooled, C, Cr, w1, b1, w2, b2, hidden, se);
+    SAUNET_CHECK_LAUNCH("se_excite");
+    return SAUNET_OK;
+}
+
+int saunet_se_excite_backward(const float* pooled, const float* hidden, const float* se, const float* dse, int N, int C, int Cr,
+                              const float* w1, const float* w2, float* dpooled, float* dw1, float* db1, float* dw2, float* db2, void* stream)
+{
+    hipLaunchKernelGGL(se_excite_bwd_kernel, dim3(N), dim3(256), sizeof(float) * (C + Cr), (hipStream_t)stream, pooled, hidden, se, dse, C, Cr, w1, w2,
+                       dpooled, dw1, db1, dw2, db2);
+    SAUNET_CHECK_LAUNCH("se_excite_backward");
+    return SAUNET_OK;
+}
+
+int saunet_att_combine_forward(int dtype, const void* F, int ldf, const void* S, const float* se, void* out, int ldo, int N, int HW, int C, void* stream)
+{
+    const long total = (long)N * HW * C;
+#define CALL(TT) hipLaunchKernelGGL(att_combine_fwd_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const TT*)F, ldf, (const TT*)S, se, (TT*)out, ldo, HW, C, total)
+    DISPATCH_T(dtype, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("att_combine_forward");
+    return SAUNET_OK;
+}
+
+int saunet_att_combine_backward(int dtype, const void* F, int ldf, const void* S, const float* se, const void* dout, int lddo,
+                                void* dF, int lddf, void* dS, float* dse, int N, int HW, int C, void* stream)
+{
+    if (C > 1024) return set_error(SAUNET_UNSUPPORTED, "att_combine_backward: C=%d > 1024", C);
+    int splits = (HW + 63) / 64; if (splits > 128) splits = 128;
+    int rpb = (HW + splits - 1) / splits; splits = (HW + rpb - 1) / rpb;
+    if (hipMemsetAsync(dse, 0, sizeof(float) * (size_t)N * C, (hipStream_t)stream) != hipSuccess) return set_error(SAUNET_LAUNCH_FAILED, "att memset");
+#define CALL(TT) hipLaunchKernelGGL(att_combine_bwd_kernel<TT>, dim3(N, splits), dim3(256), sizeof(float) * C, (hipStream_t)stream, (const TT*)F, ldf, (const TT*)S, se, (const TT*)dout, lddo, (TT*)dF, lddf, (TT*)dS, dse, HW, C, rpb)
+    DISPATCH_T(dtype, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("att_combine_backward");
+    return SAUNET_OK;
+}
+
+int saunet_add_pooled_grad(int dtype, void* dF, int lddf, const float* dpooled, int N, int HW, int C, void* stream)
+{
+    const long total = (long)N * HW * C;
+#define CALL(TT) hipLaunchKernelGGL(add_pooled_grad_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (TT*)dF, lddf, dpooled, HW, C, total)
+    DISPATCH_T(dtype, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("add_pooled_grad");
+    return SAUNET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,165 @@
+"""Data parallelism for the SAUNet step: one process per GPU, gradients all-reduced over RCCL/xGMI.
+
+Replaces the reference's single-process ``UserScatteredDataParallel`` + ``patch_replication_callback``
+(/root/reference/lib/nn/parallel/data_parallel.py:48-62, lib/nn/modules/replicate.py:70-94,
+train.py:272-277), which re-broadcasts all weights every step and reduces gradients to GPU 0.
+Here every rank keeps a replica; gradients are packed into a few large buckets (xGMI is point-to-point:
+few, large messages) in reverse-topological order and each bucket's all-reduce is launched as soon as its
+last gradient has been produced, overlapping the remaining backward kernels.  SyncBN statistics of the
+three shape-stream ResBlocks are all-reduced inside functional.conv_bn_act.
+
+Semantics: per-replica loss on the local shard, gradients averaged over ranks,
+local batch statistics for the 144 nn.BatchNorm2d layers, global statistics for the 6 SyncBN layers.
+"""
+import ctypes as C
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import lib as L
+
+
+def init_from_env(backend=None):
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and join the default group.
+    Returns (rank, local_rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, local, world
+
+
+def shard_indices(n, rank, world, epoch=0, seed=304, shuffle=True, drop_last=True):
+    """Disjoint per-rank shards of a (seeded) permutation, equal length on every rank."""
+    g = torch.Generator()
+    g.manual_seed(seed + epoch)
+    idx = torch.randperm(n, generator=g).tolist() if shuffle else list(range(n))
+    per = n // world if drop_last else (n + world - 1) // world
+    if not drop_last:
+        idx += idx[: per * world - n]
+    return idx[rank * per:(rank + 1) * per]
+
+
+def broadcast_parameters(module, src=0):
+    """Make every replica start from rank `src`'s parameters and buffers."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)
+
+
+def _copy(tl_cols, pack, scale):
+    """pack=True: flat <- grads ; pack=False: grads <- flat * scale."""
+    tensors, flats = tl_cols
+    if tensors[0].is_cuda:
+        for s in range(0, len(tensors), 96):
+            tl = L.TensorList()
+            cnt = min(96, len(tensors) - s)
+            tl.count = cnt
+            for i in range(cnt):
+                tl.ptrs[0][i] = tensors[s + i].data_ptr()
+                tl.ptrs[1][i] = flats[s + i].data_ptr()
+                tl.numel[i] = tensors[s + i].numel()
+            L.call("saunet_bucket_copy", C.byref(tl), 1 if pack else 0, float(scale), L.stream())
+    else:  # host tensors (gloo tests of the bucketing logic): plain copies
+        for t, f in zip(tensors, flats):
+            if pack:
+                f.copy_(t.reshape(-1))
+            else:
+                t.copy_((f * scale).view_as(t))
+
+
+class GradientBuckets:
+    """Bucketed, backward-overlapped gradient averaging."""
+
+    def __init__(self, params, bucket_mb=32.0, group=None, overlap=True):
+        self.group = group
+        self.params = [p for p in params if p.requires_grad]
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        # reverse registration order ~ order in which backward produces gradients (final ... conv0)
+        self.buckets, cur, cur_n = [], [], 0
+        for p in reversed(self.params):
+            if cur and cur_n + p.numel() > cap:
+                self.buckets.append(cur); cur, cur_n = [], 0
+            cur.append(p); cur_n += p.numel()
+        if cur:
+            self.buckets.append(cur)
+        self.flat = [None] * len(self.buckets)
+        self.bucket_of = {}
+        for b, ps in enumerate(self.buckets):
+            for p in ps:
+                self.bucket_of[id(p)] = b
+        self.pending = [0] * len(self.buckets)
+        self.handles = [None] * len(self.buckets)
+        self.hooks = []
+        if overlap and self.world > 1:
+            for p in self.params:
+                self.hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self.reset()
+
+    def reset(self):
+        self.pending = [len(ps) for ps in self.buckets]
+        self.handles = [None] * len(self.buckets)
+
+    def _views(self, b):
+        ps = self.buckets[b]
+        n = sum(p.numel() for p in ps)
+        if self.flat[b] is None or self.flat[b].device != ps[0].device:
+            self.flat[b] = torch.empty(n, dtype=torch.float32, device=ps[0].device)
+        views, o = [], 0
+        for p in ps:
+            views.append(self.flat[b][o:o + p.numel()]); o += p.numel()
+        return views
+
+    def _launch(self, b):
+        ps = self.buckets[b]
+        for p in ps:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        _copy(([p.grad for p in ps], self._views(b)), True, 1.0)
+        self.handles[b] = dist.all_reduce(self.flat[b], group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        b = self.bucket_of[id(p)]
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            self._launch(b)
+
+    def finish(self):
+        """Call after backward: launches whatever has not been sent, waits, writes the averaged gradients back."""
+        if self.world <= 1:
+            return
+        for b in range(len(self.buckets)):
+            if self.handles[b] is None:
+                self._launch(b)
+        for b, ps in enumerate(self.buckets):
+            self.handles[b].wait()
+            _copy(([p.grad for p in ps], self._views(b)), False, 1.0 / self.world)
+        self.reset()
+
+    def remove_hooks(self):
+        for h in self.hooks:
+            h.remove()
+        self.hooks = []
+
+
+def all_reduce_scalars(values, group=None):
+    """Average a small vector of logging scalars over ranks (the reference gathers them to GPU 0)."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return values
+    dist.all_reduce(values, group=group)
+    return values / dist.get_world_size(group)

@@ -1,0 +1,768 @@
+"""Autograd layer over the C ABI: every forward/backward below is a sequence of libsaunet_hip.so calls.
+
+PyTorch supplies tensors, streams and the autograd tape only.  Activations are logical NCHW tensors in
+``torch.channels_last`` memory (= NHWC), possibly channel slices of a wider buffer (``ld`` > C).
+Backward passes are written by hand so that producer/consumer fusion survives differentiation:
+  * BatchNorm statistics are taken in the producing convolution's epilogue,
+  * BatchNorm+ReLU is applied in the consuming convolution's operand load inside DenseNet,
+  * concatenation is a write into a channel slice.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+_CL = torch.channels_last
+
+
+# ------------------------------------------------------------------------------------------------ views
+def nhwc(t):
+    """Return t as a dense channels_last tensor (no copy if it already is one / a channel slice)."""
+    if t.dim() != 4:
+        raise RuntimeError("saunet_amd expects 4-D NCHW tensors, got %s" % (tuple(t.shape),))
+    n, c, h, w = t.shape
+    s = t.stride()
+    if c == 1:
+        if t.is_contiguous() or t.is_contiguous(memory_format=_CL):
+            return t
+    if s[1] == 1 and s[2] == w * s[3] and s[0] == h * w * s[3] and s[3] >= c:
+        return t
+    return t.contiguous(memory_format=_CL)
+
+
+def ld_of(t):
+    return 1 if t.shape[1] == 1 else t.stride(3)
+
+
+def new_act(n, c, h, w, dtype, device, zero=False):
+    f = torch.zeros if zero else torch.empty
+    return f((n, c, h, w), dtype=dtype, device=device, memory_format=_CL)
+
+
+def _check_dev(t):
+    if not t.is_cuda:
+        raise RuntimeError("saunet_amd ops run only on the GPU through libsaunet_hip.so (no CPU fallback)")
+
+
+# ------------------------------------------------------------------------------------------------ raw op wrappers
+class PackedWeights:
+    """Per-parameter cache of MFMA-friendly weight packings, invalidated by the tensor version counter."""
+
+    def __init__(self):
+        self.cache = {}
+
+    def get(self, w, mode, dtype):
+        # only leaf Parameters are cached (temporaries may reuse an address with the same version counter)
+        cacheable = isinstance(w, torch.nn.Parameter)
+        key = (w.data_ptr(), mode, dtype)
+        ent = self.cache.get(key) if cacheable else None
+        ver = w._version
+        if ent is not None and ent[0] == ver and ent[1].device == w.device:
+            return ent[1]
+        out = torch.empty(w.numel(), dtype=dtype, device=w.device)
+        wd = w.detach()
+        if not wd.is_contiguous():
+            wd = wd.contiguous()
+        if mode in (L.PACK_CONVT_FWD, L.PACK_CONVT_DGRAD):
+            ci, co, kh, kw = w.shape
+        else:
+            co, ci, kh, kw = w.shape
+        L.call("saunet_pack_weight", mode, L.BF16 if dtype == torch.bfloat16 else L.F32, wd.data_ptr(), co, ci, kh, kw,
+               out.data_ptr(), L.stream())
+        if cacheable:
+            self.cache[key] = (ver, out)
+        return out
+
+    def clear(self):
+        self.cache.clear()
+
+
+PACKS = PackedWeights()
+
+
+def _desc(x, cout, ldy, ho, wo, kh, kw, stride, pad, transposed=False, pro_relu=False, cin=None):
+    d = L.ConvDesc()
+    d.dtype = L.dtype_code(x)
+    d.N, d.H, d.W = x.shape[0], x.shape[2], x.shape[3]
+    d.Cin = x.shape[1] if cin is None else cin
+    d.ldx = ld_of(x)
+    d.Ho, d.Wo, d.Cout, d.ldy = ho, wo, cout, ldy
+    d.KH, d.KW, d.stride, d.pad = kh, kw, stride, pad
+    d.transposed = 1 if transposed else 0
+    d.pro_relu = 1 if pro_relu else 0
+    return d
+
+
+def conv_out_hw(h, w, kh, kw, stride, pad, transposed):
+    if transposed:
+        return 2 * h, 2 * w
+    return (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+
+
+def conv_forward_raw(x, weight, bias, stride, pad, transposed=False, pro=None, out=None, stats=None):
+    """y = conv(prologue(x), weight) + bias.  pro = (scale, shift, relu) or None.
+    out: optional pre-allocated (channel-slice) destination.  stats = (sum, sumsq) float64 accumulators."""
+    _check_dev(x)
+    x = nhwc(x)
+    if transposed:
+        cin_w, cout, kh, kw = weight.shape
+    else:
+        cout, cin_w, kh, kw = weight.shape
+    if cin_w != x.shape[1]:
+        raise RuntimeError("conv: weight expects %d input channels, got %d" % (cin_w, x.shape[1]))
+    ho, wo = conv_out_hw(x.shape[2], x.shape[3], kh, kw, stride, pad, transposed)
+    if out is None:
+        out = new_act(x.shape[0], cout, ho, wo, x.dtype, x.device)
+    wp = PACKS.get(weight, L.PACK_CONVT_FWD if transposed else L.PACK_FWD, x.dtype)
+    d = _desc(x, cout, ld_of(out), ho, wo, kh, kw, stride, pad, transposed, bool(pro and pro[2]))
+    L.call("saunet_conv2d_forward", C.byref(d), x.data_ptr(), wp.data_ptr(), L.ptr(bias),
+           L.ptr(pro[0]) if pro else None, L.ptr(pro[1]) if pro else None, out.data_ptr(),
+           L.ptr(stats[0]) if stats else None, L.ptr(stats[1]) if stats else None, L.stream())
+    return out
+
+
+def conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed=False, out=None):
+    """dx of y = conv(x, weight): a forward convolution over dy with re-packed weights."""
+    dy = nhwc(dy)
+    n, cin, h, w = x_shape
+    if out is None:
+        out = new_act(n, cin, h, w, dy.dtype, dy.device)
+    if transposed:
+        # y = convT(x): dx[n,ih,iw,ci] = sum dy[n,2ih-1+kh,2iw-1+kw,co] w[ci,co,kh,kw]  -> stride-2 pad-1 4x4 conv over dy
+        wp = PACKS.get(weight, L.PACK_CONVT_DGRAD, dy.dtype)
+        d = _desc(dy, cin, ld_of(out), h, w, 4, 4, 2, 1)
+    else:
+        cout, _, kh, kw = weight.shape
+        if stride != 1:
+            raise RuntimeError("dgrad: only stride-1 convolutions need an input gradient on this path")
+        wp = PACKS.get(weight, L.PACK_DGRAD, dy.dtype)
+        d = _desc(dy, cin, ld_of(out), h, w, kh, kw, 1, kh - 1 - pad)
+    L.call("saunet_conv2d_forward", C.byref(d), dy.data_ptr(), wp.data_ptr(), None, None, None, out.data_ptr(), None, None,
+           L.stream())
+    return out
+
+
+def conv_wgrad_raw(x, dy, weight, stride, pad, transposed=False, pro=None):
+    x = nhwc(x); dy = nhwc(dy)
+    dw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+    if transposed:
+        _, cout, kh, kw = weight.shape
+    else:
+        cout, _, kh, kw = weight.shape
+    d = _desc(x, cout, ld_of(dy), dy.shape[2], dy.shape[3], kh, kw, stride, pad, transposed, bool(pro and pro[2]))
+    L.call("saunet_conv2d_wgrad", C.byref(d), x.data_ptr(), dy.data_ptr(), L.ptr(pro[0]) if pro else None,
+           L.ptr(pro[1]) if pro else None, dw.data_ptr(), L.stream())
+    return dw
+
+
+def channel_sum(t):
+    t = nhwc(t)
+    n, c, h, w = t.shape
+    acc = torch.zeros(c, dtype=torch.float64, device=t.device)
+    L.call("saunet_channel_sum", L.dtype_code(t), t.data_ptr(), n * h * w, c, ld_of(t), acc.data_ptr(), L.stream())
+    return acc.float()
+
+
+def bn_stats(x, stats=None):
+    x = nhwc(x)
+    n, c, h, w = x.shape
+    if stats is None:
+        stats = torch.zeros(2, c, dtype=torch.float64, device=x.device)
+    L.call("saunet_bn_stats", L.dtype_code(x), x.data_ptr(), n * h * w, c, ld_of(x), stats[0].data_ptr(), stats[1].data_ptr(), L.stream())
+    return stats
+
+
+class BNParams:
+    """scale/shift/mean/invstd vectors [4,C] float32 produced by bn_finalize."""
+    __slots__ = ("buf",)
+
+    def __init__(self, c, device):
+        self.buf = torch.empty(4, c, dtype=torch.float32, device=device)
+
+    scale = property(lambda s: s.buf[0])
+    shift = property(lambda s: s.buf[1])
+    mean = property(lambda s: s.buf[2])
+    invstd = property(lambda s: s.buf[3])
+
+
+def bn_finalize(stats_sum, stats_sq, count, gamma, beta, rmean, rvar, momentum, eps, training, conv_bias=None):
+    c = gamma.shape[0]
+    p = BNParams(c, gamma.device)
+    L.call("saunet_bn_finalize", c, L.ptr(stats_sum), L.ptr(stats_sq), float(count), L.ptr(conv_bias), gamma.data_ptr(),
+           beta.data_ptr(), float(eps), float(momentum), L.ptr(rmean), L.ptr(rvar), p.scale.data_ptr(), p.shift.data_ptr(),
+           p.mean.data_ptr(), p.invstd.data_ptr(), 1 if training else 0, L.stream())
+    return p
+
+
+def affine_act(x, scale, shift, relu, residual=None, out=None):
+    x = nhwc(x)
+    n, c, h, w = x.shape
+    if out is None:
+        out = new_act(n, c, h, w, x.dtype, x.device)
+    if residual is not None:
+        residual = nhwc(residual)
+    L.call("saunet_affine_act", L.dtype_code(x), x.data_ptr(), ld_of(x), L.ptr(scale), L.ptr(shift), L.ptr(residual),
+           ld_of(residual) if residual is not None else 0, 1 if relu else 0, out.data_ptr(), ld_of(out), n * h * w, c, L.stream())
+    return out
+
+
+def bn_backward(dy, x, p, relu, count, training, residual=None, dx=None, accumulate=False, want_dres=False, sync_group=None):
+    """Returns (dx, dres, dgamma, dbeta).  x is the tensor BN normalised (pre-affine).
+    sync_group: all-reduce the two per-channel sums over that process group between the reduce and the
+    apply kernel (SynchronizedBatchNorm semantics, lib/nn/modules/batchnorm.py:98-139); `count` must then
+    already be the global element count."""
+    dy = nhwc(dy); x = nhwc(x)
+    n, c, h, w = x.shape
+    P = n * h * w
+    dev = x.device
+    sums = torch.zeros(2 * c, dtype=torch.float64, device=dev)
+    if residual is not None:
+        residual = nhwc(residual)
+    rp, rl = L.ptr(residual), (ld_of(residual) if residual is not None else 0)
+    dt = L.dtype_code(x)
+    L.call("saunet_bn_backward_reduce", dt, dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), rp, rl, p.scale.data_ptr(),
+           p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), 1 if relu else 0, sums.data_ptr(), P, c, L.stream())
+    if sync_group is not None and training:
+        torch.distributed.all_reduce(sums, group=sync_group)
+    if dx is None:
+        dx = new_act(n, c, h, w, x.dtype, dev)
+    dres = new_act(n, c, h, w, x.dtype, dev) if want_dres else None
+    dgb = torch.empty(2, c, dtype=torch.float32, device=dev)
+    L.call("saunet_bn_backward_apply", dt, dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), rp, rl, p.scale.data_ptr(),
+           p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), 1 if relu else 0, sums.data_ptr(), float(count),
+           1 if training else 0, 1 if accumulate else 0, dx.data_ptr(), ld_of(dx), L.ptr(dres),
+           ld_of(dres) if dres is not None else 0, dgb[0].data_ptr(), dgb[1].data_ptr(), P, c, L.stream())
+    return dx, dres, dgb[0], dgb[1]
+
+
+def copy_channels(src, dst, accumulate=False):
+    src = nhwc(src)
+    n, c, h, w = src.shape
+    L.call("saunet_copy_channels", L.dtype_code(src), L.dtype_code(dst), src.data_ptr(), ld_of(src), dst.data_ptr(), ld_of(dst),
+           n * h * w, c, 1 if accumulate else 0, L.stream())
+    return dst
+
+
+# ------------------------------------------------------------------------------------------------ autograd functions
+class _Conv(torch.autograd.Function):
+    """Plain convolution / transposed convolution (no normalisation)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, transposed):
+        x = nhwc(x)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, transposed, bias is not None)
+        return conv_forward_raw(x, weight, bias, stride, pad, transposed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad, transposed, has_bias = ctx.cfg
+        dy = nhwc(dy)
+        dx = conv_dgrad_raw(dy, weight, x.shape, stride, pad, transposed) if ctx.needs_input_grad[0] else None
+        dw = conv_wgrad_raw(x, dy, weight, stride, pad, transposed) if ctx.needs_input_grad[1] else None
+        db = channel_sum(dy) if has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0):
+    return _Conv.apply(x, weight, bias, stride, padding, False)
+
+
+def conv_transpose2d(x, weight, bias=None):
+    return _Conv.apply(x, weight, bias, 2, 1, True)
+
+
+class _ConvBNAct(torch.autograd.Function):
+    """y = act(BN(conv(x)) [+ residual]) with the batch statistics taken in the conv epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, rmean, rvar, residual, stride, pad, transposed, relu, momentum, eps, training, group):
+        x = nhwc(x)
+        cout = weight.shape[1] if transposed else weight.shape[0]
+        stats = torch.zeros(2, cout, dtype=torch.float64, device=x.device) if training else None
+        z = conv_forward_raw(x, weight, bias, stride, pad, transposed, stats=(stats[0], stats[1]) if training else None)
+        count = z.shape[0] * z.shape[2] * z.shape[3]
+        if group is not None and training:
+            # SynchronizedBatchNorm: global batch statistics = all-reduce of (sum, sumsq); count scales with the world
+            torch.distributed.all_reduce(stats, group=group)
+            count *= torch.distributed.get_world_size(group)
+        p = bn_finalize(stats[0] if training else None, stats[1] if training else None, count, gamma, beta, rmean, rvar,
+                        momentum, eps, training, conv_bias=bias)
+        y = affine_act(z, p.scale, p.shift, relu, residual)
+        ctx.save_for_backward(x, weight, z, p.buf, residual if residual is not None else z.new_empty(0))
+        ctx.cfg = (stride, pad, transposed, relu, training, count, bias is not None, residual is not None, group)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, z, pbuf, residual = ctx.saved_tensors
+        stride, pad, transposed, relu, training, count, has_bias, has_res, group = ctx.cfg
+        p = BNParams.__new__(BNParams); p.buf = pbuf
+        need_res = has_res and ctx.needs_input_grad[7]
+        dz, dres, dgamma, dbeta = bn_backward(dy, z, p, relu, count, training, residual if has_res else None, want_dres=need_res,
+                                              sync_group=group)
+        dx = conv_dgrad_raw(dz, weight, x.shape, stride, pad, transposed) if ctx.needs_input_grad[0] else None
+        dw = conv_wgrad_raw(x, dz, weight, stride, pad, transposed)
+        db = channel_sum(dz) if has_bias else None
+        return dx, dw, db, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
+
+
+def conv_bn_act(x, weight, bias, bn, relu=True, residual=None, stride=1, padding=0, transposed=False):
+    """bn: an nn.BatchNorm2d-like module (weight, bias, running_mean, running_var, momentum, eps, training).
+    A bn with a truthy ``sync`` attribute (SynchronizedBatchNorm2d) reduces its statistics over the default
+    process group when one with more than one rank exists."""
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    group = None
+    if getattr(bn, "sync", False) and bn.training and torch.distributed.is_available() and torch.distributed.is_initialized() \
+            and torch.distributed.get_world_size() > 1:
+        group = torch.distributed.group.WORLD
+    return _ConvBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, stride, padding,
+                            transposed, relu, bn.momentum, bn.eps, bn.training, group)
+
+
+class _BNAct(torch.autograd.Function):
+    """Stand-alone BatchNorm (+ReLU) over a materialised tensor; optional precomputed statistics."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, stats, relu, momentum, eps, training):
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        count = n * h * w
+        if training and stats is None:
+            stats = bn_stats(x)
+        p = bn_finalize(stats[0] if training else None, stats[1] if training else None, count, gamma, beta, rmean, rvar,
+                        momentum, eps, training)
+        y = affine_act(x, p.scale, p.shift, relu)
+        ctx.save_for_backward(x, p.buf)
+        ctx.cfg = (relu, training, count)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pbuf = ctx.saved_tensors
+        relu, training, count = ctx.cfg
+        p = BNParams.__new__(BNParams); p.buf = pbuf
+        dx, _, dgamma, dbeta = bn_backward(dy, x, p, relu, count, training)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def batch_norm_act(x, bn, relu=False, stats=None):
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, stats, relu, bn.momentum, bn.eps, bn.training)
+
+
+class _Bilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ho, wo):
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        y = new_act(n, c, ho, wo, x.dtype, x.device)
+        L.call("saunet_bilinear_forward", L.dtype_code(x), x.data_ptr(), n, h, w, c, ld_of(x), y.data_ptr(), ho, wo, ld_of(y), L.stream())
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = nhwc(dy)
+        n, c, h, w = ctx.shape
+        dx = new_act(n, c, h, w, dy.dtype, dy.device)
+        L.call("saunet_bilinear_backward", L.dtype_code(dy), dy.data_ptr(), n, dy.shape[2], dy.shape[3], c, ld_of(dy), dx.data_ptr(),
+               h, w, ld_of(dx), 0, L.stream())
+        return dx, None, None
+
+
+def interpolate_bilinear(x, size=None, scale_factor=None):
+    """F.interpolate(mode='bilinear', align_corners=True)."""
+    if size is None:
+        size = (int(x.shape[2] * scale_factor), int(x.shape[3] * scale_factor))
+    return _Bilinear.apply(x, int(size[0]), int(size[1]))
+
+
+class _Pool2x2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, is_max):
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        y = new_act(n, c, h // 2, w // 2, x.dtype, x.device)
+        L.call("saunet_pool2x2_forward", L.dtype_code(x), 1 if is_max else 0, x.data_ptr(), n, h, w, c, ld_of(x), y.data_ptr(), ld_of(y), L.stream())
+        ctx.is_max = is_max
+        ctx.save_for_backward(x if is_max else x.new_empty(0))
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = nhwc(dy)
+        n, c, h, w = ctx.shape
+        dx = new_act(n, c, h, w, dy.dtype, dy.device)
+        L.call("saunet_pool2x2_backward", L.dtype_code(dy), 1 if ctx.is_max else 0, x.data_ptr() if ctx.is_max else None, dy.data_ptr(),
+               n, h, w, c, ld_of(x) if ctx.is_max else 0, ld_of(dy), dx.data_ptr(), ld_of(dx), 0, L.stream())
+        return dx, None
+
+
+def max_pool2x2(x):
+    return _Pool2x2.apply(x, True)
+
+
+def avg_pool2x2(x):
+    return _Pool2x2.apply(x, False)
+
+
+class _Sigmoid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        y = new_act(n, c, h, w, x.dtype, x.device)
+        L.call("saunet_sigmoid_forward", L.dtype_code(x), x.data_ptr(), ld_of(x), y.data_ptr(), ld_of(y), n * h * w, c, L.stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = nhwc(dy)
+        n, c, h, w = y.shape
+        dx = new_act(n, c, h, w, y.dtype, y.device)
+        L.call("saunet_sigmoid_backward", L.dtype_code(y), y.data_ptr(), ld_of(y), dy.data_ptr(), ld_of(dy), dx.data_ptr(), ld_of(dx),
+               n * h * w, c, 0, L.stream())
+        return dx
+
+
+def sigmoid(x):
+    return _Sigmoid.apply(x)
+
+
+class _Cat(torch.autograd.Function):
+    """torch.cat(dim=1) as channel-slice writes; backward hands out slice views of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        xs = [nhwc(x) for x in xs]
+        n, _, h, w = xs[0].shape
+        cs = [x.shape[1] for x in xs]
+        out = new_act(n, sum(cs), h, w, xs[0].dtype, xs[0].device)
+        o = 0
+        for x, c in zip(xs, cs):
+            copy_channels(x, out[:, o:o + c])
+            o += c
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = nhwc(dy)
+        outs, o = [], 0
+        for c in ctx.cs:
+            outs.append(dy[:, o:o + c])
+            o += c
+        return tuple(outs)
+
+
+def cat(xs):
+    return _Cat.apply(*xs)
+
+
+class _GateMul(torch.autograd.Function):
+    """x * (alpha + 1) with a one-channel alpha (GSConv.py:55)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha):
+        x = nhwc(x); alpha = nhwc(alpha)
+        n, c, h, w = x.shape
+        y = new_act(n, c, h, w, x.dtype, x.device)
+        L.call("saunet_gate_mul_forward", L.dtype_code(x), x.data_ptr(), ld_of(x), alpha.data_ptr(), y.data_ptr(), ld_of(y), n * h * w, c, L.stream())
+        ctx.save_for_backward(x, alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, alpha = ctx.saved_tensors
+        dy = nhwc(dy)
+        n, c, h, w = x.shape
+        dx = new_act(n, c, h, w, x.dtype, x.device)
+        dal = new_act(n, 1, h, w, x.dtype, x.device)
+        L.call("saunet_gate_mul_backward", L.dtype_code(x), x.data_ptr(), ld_of(x), alpha.data_ptr(), dy.data_ptr(), ld_of(dy),
+               dx.data_ptr(), ld_of(dx), dal.data_ptr(), n * h * w, c, L.stream())
+        return dx, dal
+
+
+def gate_mul(x, alpha):
+    return _GateMul.apply(x, alpha)
+
+
+class _DualAttTail(torch.autograd.Function):
+    """out = (S + 1) * F * sigmoid(fc2(relu(fc1(avgpool(F)))))  (attention_blocks.py:50-57, 237)."""
+
+    @staticmethod
+    def forward(ctx, F, S, w1, b1, w2, b2):
+        F = nhwc(F); S = nhwc(S)
+        n, c, h, w = F.shape
+        cr = w1.shape[0]
+        dev = F.device
+        pooled = torch.empty(n, c, dtype=torch.float32, device=dev)
+        L.call("saunet_global_avgpool", L.dtype_code(F), F.data_ptr(), n, h * w, c, ld_of(F), pooled.data_ptr(), L.stream())
+        hidden = torch.empty(n, cr, dtype=torch.float32, device=dev)
+        se = torch.empty(n, c, dtype=torch.float32, device=dev)
+        w1c, w2c = w1.detach().reshape(cr, c), w2.detach().reshape(c, cr)
+        L.call("saunet_se_excite", pooled.data_ptr(), n, c, cr, w1c.data_ptr(), b1.data_ptr(), w2c.data_ptr(), b2.data_ptr(),
+               hidden.data_ptr(), se.data_ptr(), L.stream())
+        out = new_act(n, c, h, w, F.dtype, dev)
+        L.call("saunet_att_combine_forward", L.dtype_code(F), F.data_ptr(), ld_of(F), S.data_ptr(), se.data_ptr(), out.data_ptr(),
+               ld_of(out), n, h * w, c, L.stream())
+        ctx.save_for_backward(F, S, w1, w2, pooled, hidden, se)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        F, S, w1, w2, pooled, hidden, se = ctx.saved_tensors
+        dout = nhwc(dout)
+        n, c, h, w = F.shape
+        cr = w1.shape[0]
+        dev = F.device
+        dF = new_act(n, c, h, w, F.dtype, dev)
+        dS = new_act(n, 1, h, w, F.dtype, dev)
+        dse = torch.empty(n, c, dtype=torch.float32, device=dev)
+        dt = L.dtype_code(F)
+        L.call("saunet_att_combine_backward", dt, F.data_ptr(), ld_of(F), S.data_ptr(), se.data_ptr(), dout.data_ptr(), ld_of(dout),
+               dF.data_ptr(), ld_of(dF), dS.data_ptr(), dse.data_ptr(), n, h * w, c, L.stream())
+        g = torch.zeros(2 * c * cr + c + cr, dtype=torch.float32, device=dev)
+        dw1, db1 = g[:cr * c], g[cr * c:cr * c + cr]
+        dw2, db2 = g[cr * c + cr:2 * cr * c + cr], g[2 * cr * c + cr:]
+        dpooled = torch.empty(n, c, dtype=torch.float32, device=dev)
+        w1c, w2c = w1.detach().reshape(cr, c), w2.detach().reshape(c, cr)
+        L.call("saunet_se_excite_backward", pooled.data_ptr(), hidden.data_ptr(), se.data_ptr(), dse.data_ptr(), n, c, cr,
+               w1c.data_ptr(), w2c.data_ptr(), dpooled.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), L.stream())
+        L.call("saunet_add_pooled_grad", dt, dF.data_ptr(), ld_of(dF), dpooled.data_ptr(), n, h * w, c, L.stream())
+        return dF, dS, dw1.view(w1.shape), db1, dw2.view(w2.shape), db2
+
+
+def dual_att_tail(F, S, fc1, fc2):
+    return _DualAttTail.apply(F, S, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
+
+
+class _DualLoss(torch.autograd.Function):
+    """dice + weighted CE + BCE(edge) and the pixel_acc metrics from one pass (loss.py:149-159)."""
+
+    @staticmethod
+    def forward(ctx, logits, edge, seg_t, edge_t):
+        logits = nhwc(logits); edge = nhwc(edge)
+        n, c, h, w = logits.shape
+        if c != 4:
+            raise RuntimeError("DualLoss kernel is specialised for 4 classes, got %d" % c)
+        P = n * h * w
+        dev = logits.device
+        seg_t = seg_t.to(device=dev, dtype=torch.int64).contiguous()
+        edge_t = edge_t.to(device=dev, dtype=torch.float32).contiguous()
+        sums = torch.zeros(32, dtype=torch.float64, device=dev)
+        dt = L.dtype_code(logits)
+        L.call("saunet_dual_loss_forward", dt, logits.data_ptr(), ld_of(logits), edge.data_ptr(), seg_t.data_ptr(), edge_t.data_ptr(), P,
+               sums.data_ptr(), L.stream())
+        out = torch.empty(5, dtype=torch.float32, device=dev)
+        L.call("saunet_dual_loss_finalize", sums.data_ptr(), P, out.data_ptr(), out[1:].data_ptr(), L.stream())
+        ctx.save_for_backward(logits, edge, seg_t, edge_t, sums)
+        loss, metrics = out[0], out[1:]
+        ctx.mark_non_differentiable(metrics)
+        return loss, metrics
+
+    @staticmethod
+    def backward(ctx, dloss, _dmetrics):
+        logits, edge, seg_t, edge_t, sums = ctx.saved_tensors
+        n, c, h, w = logits.shape
+        dl = new_act(n, c, h, w, logits.dtype, logits.device)
+        de = new_act(n, 1, h, w, logits.dtype, logits.device)
+        dloss = dloss.to(torch.float32).contiguous()
+        L.call("saunet_dual_loss_backward", L.dtype_code(logits), logits.data_ptr(), ld_of(logits), edge.data_ptr(), seg_t.data_ptr(),
+               edge_t.data_ptr(), n * h * w, sums.data_ptr(), dloss.data_ptr(), dl.data_ptr(), ld_of(dl), de.data_ptr(), L.stream())
+        return dl, de, None, None
+
+
+def dual_loss(logits, edge, seg_t, edge_t):
+    """-> (loss scalar tensor, metrics tensor [acc, j1, j2, j3])."""
+    return _DualLoss.apply(logits, edge, seg_t, edge_t)
+
+
+def canny(image, low=10, high=100, dtype=None):
+    """image: float32 [N,3,H,W] (contiguous NCHW, as the loader delivers it) -> [N,1,H,W] in {0,255}."""
+    _check_dev(image)
+    img = image.detach().to(torch.float32).contiguous()
+    n, c, h, w = img.shape
+    if c != 3:
+        raise RuntimeError("canny expects 3-channel input")
+    dtype = dtype or image.dtype
+    out = torch.empty((n, 1, h, w), dtype=dtype, device=img.device)
+    work = torch.empty((n, 3, h, w), dtype=torch.int32, device=img.device)
+    L.call("saunet_canny", L.BF16 if dtype == torch.bfloat16 else L.F32, img.data_ptr(), n, h, w, int(low), int(high), out.data_ptr(),
+           work.data_ptr(), L.stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ relu
+_CONST = {}
+
+
+def _const_vec(c, device, value):
+    key = (c, str(device), value)
+    v = _CONST.get(key)
+    if v is None:
+        v = torch.full((c,), float(value), dtype=torch.float32, device=device)
+        _CONST[key] = v
+    return v
+
+
+class _Relu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = nhwc(x)
+        y = affine_act(x, None, None, True)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = nhwc(dy)
+        n, c, h, w = y.shape
+        dev = y.device
+        one, zero = _const_vec(c, dev, 1.0), _const_vec(c, dev, 0.0)
+        dx = new_act(n, c, h, w, y.dtype, dev)
+        dummy = torch.zeros(2 * c, dtype=torch.float64, device=dev)
+        # identity-statistics BN backward in eval mode == dy * [y > 0]
+        L.call("saunet_bn_backward_apply", L.dtype_code(y), dy.data_ptr(), ld_of(dy), y.data_ptr(), ld_of(y), None, 0, one.data_ptr(),
+               zero.data_ptr(), zero.data_ptr(), one.data_ptr(), 1, dummy.data_ptr(), 1.0, 0, 0, dx.data_ptr(), ld_of(dx), None, 0, None, None,
+               n * h * w, c, L.stream())
+        return dx
+
+
+def relu(x):
+    return _Relu.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------ DenseNet
+class _DenseBlock(torch.autograd.Function):
+    """One DenseNet block: L x [BN-ReLU-conv1x1(->128)-BN-ReLU-conv3x3(->32)] over a growing concat.
+
+    The concat is ONE preallocated NHWC buffer; every layer's 32 new channels are written into their
+    slice by the conv kernel itself, together with their batch statistics (computed once, reused by every
+    later norm1 -- only gamma/beta differ per layer).  BN+ReLU are applied inside the consuming conv's
+    operand load, so normalised tensors are never materialised.  torchvision _DenseBlock/_DenseLayer
+    (third-party, used at /root/reference/models/models.py:271,306-313)."""
+
+    @staticmethod
+    def forward(ctx, x0, training, cfgs, *tensors):
+        # tensors: per layer (n1w, n1b, c1w, n2w, n2b, c2w) then per layer (n1rm, n1rv, n2rm, n2rv)
+        nl = len(cfgs)
+        params, bufs = tensors[:6 * nl], tensors[6 * nl:]
+        x0 = nhwc(x0)
+        n, c0, h, w = x0.shape
+        growth = params[5].shape[0]
+        ctot = c0 + growth * nl
+        dev = x0.device
+        buf = new_act(n, ctot, h, w, x0.dtype, dev)
+        stats = torch.zeros(2, ctot, dtype=torch.float64, device=dev)
+        copy_channels(x0, buf[:, :c0])
+        count = n * h * w
+        if training:
+            bn_stats(buf[:, :c0], stats[:, :c0])
+        saved = []
+        for l in range(nl):
+            n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
+            n1rm, n1rv, n2rm, n2rv = bufs[4 * l:4 * l + 4]
+            mom, eps = cfgs[l]
+            cin = c0 + growth * l
+            p1 = bn_finalize(stats[0, :cin], stats[1, :cin], count, n1w, n1b, n1rm, n1rv, mom, eps, training)
+            st2 = torch.zeros(2, c1w.shape[0], dtype=torch.float64, device=dev) if training else None
+            z1 = conv_forward_raw(buf[:, :cin], c1w, None, 1, 0, pro=(p1.scale, p1.shift, True),
+                                  stats=(st2[0], st2[1]) if training else None)
+            p2 = bn_finalize(st2[0] if training else None, st2[1] if training else None, count, n2w, n2b, n2rm, n2rv, mom, eps, training)
+            conv_forward_raw(z1, c2w, None, 1, 1, pro=(p2.scale, p2.shift, True), out=buf[:, cin:cin + growth],
+                             stats=(stats[0, cin:cin + growth], stats[1, cin:cin + growth]) if training else None)
+            saved += [z1, p1.buf, p2.buf]
+        ctx.save_for_backward(buf, *params, *saved)
+        ctx.meta = (nl, c0, growth, count, training)
+        ctx.mark_non_differentiable(stats)
+        return buf, stats
+
+    @staticmethod
+    def backward(ctx, dbuf, _dstats):
+        nl, c0, growth, count, training = ctx.meta
+        t = ctx.saved_tensors
+        buf, params, saved = t[0], t[1:1 + 6 * nl], t[1 + 6 * nl:]
+        n, ctot, h, w = buf.shape
+        dbuf = nhwc(dbuf)
+        if not dbuf.is_contiguous(memory_format=_CL) or dbuf.shape[1] != ctot:
+            dbuf = dbuf.contiguous(memory_format=_CL)
+        grads = [None] * (6 * nl)
+        for l in reversed(range(nl)):
+            n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
+            z1, p1b, p2b = saved[3 * l:3 * l + 3]
+            p1 = BNParams.__new__(BNParams); p1.buf = p1b
+            p2 = BNParams.__new__(BNParams); p2.buf = p2b
+            cin = c0 + growth * l
+            xin = buf[:, :cin]
+            dz2 = dbuf[:, cin:cin + growth]
+            dw2 = conv_wgrad_raw(z1, dz2, c2w, 1, 1, pro=(p2.scale, p2.shift, True))
+            da2 = conv_dgrad_raw(dz2, c2w, z1.shape, 1, 1)
+            dz1, _, dg2, db2 = bn_backward(da2, z1, p2, True, count, training, dx=da2)
+            dw1 = conv_wgrad_raw(xin, dz1, c1w, 1, 0, pro=(p1.scale, p1.shift, True))
+            da1 = conv_dgrad_raw(dz1, c1w, (n, cin, h, w), 1, 0)
+            _, _, dg1, db1 = bn_backward(da1, xin, p1, True, count, training, dx=dbuf[:, :cin], accumulate=True)
+            grads[6 * l:6 * l + 6] = [dg1, db1, dw1, dg2, db2, dw2]
+        dx0 = dbuf[:, :c0] if ctx.needs_input_grad[0] else None
+        return (dx0, None, None) + tuple(grads) + (None,) * (4 * nl)
+
+
+def dense_block(x0, layers, training):
+    """layers: list of modules with norm1, conv1, norm2, conv2.  Returns (concat buffer, its channel statistics)."""
+    params, bufs, cfgs = [], [], []
+    for m in layers:
+        params += [m.norm1.weight, m.norm1.bias, m.conv1.weight, m.norm2.weight, m.norm2.bias, m.conv2.weight]
+        bufs += [m.norm1.running_mean, m.norm1.running_var, m.norm2.running_mean, m.norm2.running_var]
+        cfgs.append((m.norm1.momentum, m.norm1.eps))
+        if training:
+            m.norm1.num_batches_tracked.add_(1); m.norm2.num_batches_tracked.add_(1)
+    return _DenseBlock.apply(x0, training, tuple(cfgs), *params, *bufs)
+
+
+class _Transition(torch.autograd.Function):
+    """BN-ReLU-conv1x1(C -> C/2)-AvgPool2 over a dense block's concat buffer (statistics already known)."""
+
+    @staticmethod
+    def forward(ctx, buf, stats, gamma, beta, rmean, rvar, weight, momentum, eps, training):
+        buf = nhwc(buf)
+        n, c, h, w = buf.shape
+        count = n * h * w
+        p = bn_finalize(stats[0] if training else None, stats[1] if training else None, count, gamma, beta, rmean, rvar, momentum, eps, training)
+        z = conv_forward_raw(buf, weight, None, 1, 0, pro=(p.scale, p.shift, True))
+        y = new_act(n, z.shape[1], h // 2, w // 2, z.dtype, z.device)
+        L.call("saunet_pool2x2_forward", L.dtype_code(z), 0, z.data_ptr(), n, h, w, z.shape[1], ld_of(z), y.data_ptr(), ld_of(y), L.stream())
+        ctx.save_for_backward(buf, weight, p.buf)
+        ctx.meta = (count, training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        buf, weight, pbuf = ctx.saved_tensors
+        count, training = ctx.meta
+        p = BNParams.__new__(BNParams); p.buf = pbuf
+        dy = nhwc(dy)
+        n, c, h, w = buf.shape
+        co = weight.shape[0]
+        dz = new_act(n, co, h, w, dy.dtype, dy.device)
+        L.call("saunet_pool2x2_backward", L.dtype_code(dy), 0, None, dy.data_ptr(), n, h, w, co, 0, ld_of(dy), dz.data_ptr(), ld_of(dz), 0, L.stream())
+        dw = conv_wgrad_raw(buf, dz, weight, 1, 0, pro=(p.scale, p.shift, True))
+        da = conv_dgrad_raw(dz, weight, buf.shape, 1, 0)
+        dbuf, _, dg, db = bn_backward(da, buf, p, True, count, training, dx=da)
+        return dbuf, None, dg, db, None, None, dw, None, None, None
+
+
+def transition(buf, stats, m, training):
+    if training:
+        m.norm.num_batches_tracked.add_(1)
+    return _Transition.apply(buf, stats, m.norm.weight, m.norm.bias, m.norm.running_mean, m.norm.running_var, m.conv.weight,
+                             m.norm.momentum, m.norm.eps, training)

@@ -1,0 +1,113 @@
+"""ctypes binding of libsaunet_hip.so (C ABI declared in include/saunet_hip.h).
+
+There is NO fallback: if the HIP library cannot be loaded every op raises.  Each wrapper takes
+torch tensors only for their ``data_ptr()`` / shape; torch is plumbing (memory + streams).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsaunet_hip.so")
+
+F32, BF16 = 0, 1
+PACK_FWD, PACK_DGRAD, PACK_CONVT_FWD, PACK_CONVT_DGRAD = 0, 1, 2, 3
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dtype", "N", "H", "W", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "KH", "KW", "stride", "pad",
+        "transposed", "pro_relu")]
+
+
+class TensorList(C.Structure):
+    _fields_ = [("count", C.c_int32), ("ptrs", (C.c_void_p * 96) * 4), ("numel", C.c_int64 * 96)]
+
+
+vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+_SIGS = {
+    "saunet_init": [i32],
+    "saunet_pack_weight": [i32, i32, vp, i32, i32, i32, i32, vp, vp],
+    "saunet_conv2d_forward": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "saunet_conv2d_wgrad": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp],
+    "saunet_channel_sum": [i32, vp, i64, i32, i32, vp, vp],
+    "saunet_bn_stats": [i32, vp, i64, i32, i32, vp, vp, vp],
+    "saunet_bn_finalize": [i32, vp, vp, f64, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp],
+    "saunet_affine_act": [i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, i64, i32, vp],
+    "saunet_bn_backward_reduce": [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i64, i32, vp],
+    "saunet_bn_backward_apply": [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, f64, i32, i32,
+                                 vp, i32, vp, i32, vp, vp, i64, i32, vp],
+    "saunet_bilinear_forward": [i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp],
+    "saunet_bilinear_backward": [i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp],
+    "saunet_pool2x2_forward": [i32, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp],
+    "saunet_pool2x2_backward": [i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp],
+    "saunet_copy_channels": [i32, i32, vp, i32, vp, i32, i64, i32, i32, vp],
+    "saunet_sigmoid_forward": [i32, vp, i32, vp, i32, i64, i32, vp],
+    "saunet_sigmoid_backward": [i32, vp, i32, vp, i32, vp, i32, i64, i32, i32, vp],
+    "saunet_gate_mul_forward": [i32, vp, i32, vp, vp, i32, i64, i32, vp],
+    "saunet_gate_mul_backward": [i32, vp, i32, vp, vp, i32, vp, i32, vp, i64, i32, vp],
+    "saunet_global_avgpool": [i32, vp, i32, i32, i32, i32, vp, vp],
+    "saunet_se_excite": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+    "saunet_se_excite_backward": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "saunet_att_combine_forward": [i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp],
+    "saunet_att_combine_backward": [i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, vp],
+    "saunet_add_pooled_grad": [i32, vp, i32, vp, i32, i32, i32, vp],
+    "saunet_dual_loss_forward": [i32, vp, i32, vp, vp, vp, i64, vp, vp],
+    "saunet_dual_loss_finalize": [vp, i64, vp, vp, vp],
+    "saunet_dual_loss_backward": [i32, vp, i32, vp, vp, vp, i64, vp, vp, vp, i32, vp, vp],
+    "saunet_canny": [i32, vp, i32, i32, i32, i32, i32, vp, vp, vp],
+    "saunet_sgd_step": [C.POINTER(TensorList), vp, vp],
+    "saunet_radam_step": [C.POINTER(TensorList), vp, vp],
+    "saunet_bucket_copy": [C.POINTER(TensorList), i32, f32, vp],
+}
+EXPORTS = sorted(list(_SIGS) + ["saunet_last_error", "saunet_version"])
+
+_lib = None
+
+
+def load():
+    """Load the shared library (never falls back to anything else)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libsaunet_hip.so is not built (%s). Run __graft_entry__.build() / "
+                           "python -m saunet_amd._build; there is no CPU or PyTorch fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.saunet_last_error.restype = C.c_char_p
+    lib.saunet_version.restype = C.c_int
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = sig
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, _lib.saunet_last_error().decode()))
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        _check(rc, name)
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise RuntimeError("saunet_amd: unsupported activation dtype %s" % t.dtype)

@@ -1,0 +1,450 @@
+"""Drop-in ``torch.nn.Module`` replacements for the reference's SAUNet path, executing on libsaunet_hip.so.
+
+Same class names, constructor arguments, forward signatures, state-dict keys and parameter discovery
+(``isinstance`` of ``nn.modules.conv._ConvNd`` / ``nn.modules.batchnorm._BatchNorm`` as walked by
+/root/reference/train.py:166-185) as the reference modules they replace:
+
+  SAUNet, SegmentationModule, ModelBuilder, DecoderBlock, conv3x3_bn_relu .. models/models.py
+  DualAttBlock, _MRF, SpatialAttentionBlock, SEModule ..................... models/attention_blocks.py
+  GatedSpatialConv2d ...................................................... models/GSConv.py:16-62
+  BasicBlock .............................................................. models/resnet.py:30-59
+  Norm2d .................................................................. models/norm.py:16-22
+  SynchronizedBatchNorm2d ................................................. lib/nn/modules/batchnorm.py:205-265
+  DualLoss (dice_loss fused inside) ....................................... loss.py:124-159, :51-88
+  DenseNet121 (torchvision layout) ........................................ third-party, models/models.py:271
+
+``nn.Conv2d`` / ``nn.BatchNorm2d`` / ``nn.ConvTranspose2d`` objects are used purely as parameter
+containers (so checkpoints and optimiser grouping are interchangeable); their own forward is never called.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import functional as HF
+
+_COMPUTE_DTYPE = torch.float32
+
+
+def set_compute_dtype(dtype):
+    """Storage dtype of activations / packed weights for modules built afterwards (float32 or bfloat16)."""
+    global _COMPUTE_DTYPE
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be float32 or bfloat16")
+    _COMPUTE_DTYPE = dtype
+
+
+def get_compute_dtype():
+    return _COMPUTE_DTYPE
+
+
+def Norm2d(in_channels):
+    return nn.BatchNorm2d(in_channels)
+
+
+class SynchronizedBatchNorm2d(nn.BatchNorm2d):
+    """Cross-replica BatchNorm of the shape-stream ResBlocks: one process per GPU, statistics all-reduced over
+    RCCL inside conv_bn_act.  momentum defaults to 0.001 like the reference's vendored copy."""
+    sync = True
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.001, affine=True):
+        super().__init__(num_features, eps=eps, momentum=momentum, affine=affine)
+        # bookkeeping buffers of the reference implementation (kept for state-dict compatibility)
+        self.register_buffer("_tmp_running_mean", torch.zeros(num_features))
+        self.register_buffer("_tmp_running_var", torch.ones(num_features))
+        self.register_buffer("_running_iter", torch.ones(1))
+
+    def forward(self, x):
+        return HF.batch_norm_act(x, self, relu=False)
+
+
+def _init_conv_bn(module, conv_types=(nn.Conv2d, nn.ConvTranspose2d)):
+    for m in module.modules():
+        if isinstance(m, conv_types):
+            n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+            m.weight.data.normal_(0, math.sqrt(2.0 / n))
+        elif isinstance(m, nn.BatchNorm2d):
+            m.weight.data.fill_(1)
+            m.bias.data.zero_()
+
+
+class ConvBNReLU(nn.Sequential):
+    """conv3x3 -> BatchNorm -> ReLU as one fused unit (children '0', '1', '2' like the reference's nn.Sequential)."""
+
+    def __init__(self, in_planes, out_planes, kernel_size=3, stride=1, padding=1, bias=True):
+        super().__init__(nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride, padding=padding, bias=bias),
+                         nn.BatchNorm2d(out_planes), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        conv, bn = self[0], self[1]
+        return HF.conv_bn_act(x, conv.weight, conv.bias, bn, relu=True, stride=conv.stride[0], padding=conv.padding[0])
+
+
+def conv3x3_bn_relu(in_planes, out_planes, stride=1):
+    return ConvBNReLU(in_planes, out_planes, 3, stride, 1)
+
+
+# ------------------------------------------------------------------------------------------------ shape stream
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        if stride != 1 or downsample is not None:
+            raise NotImplementedError("SAUNet only uses stride-1 BasicBlocks without downsample")
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = SynchronizedBatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = SynchronizedBatchNorm2d(planes)
+        self.downsample = None
+        self.stride = stride
+
+    def forward(self, x):
+        out = HF.conv_bn_act(x, self.conv1.weight, None, self.bn1, relu=True, padding=1)
+        return HF.conv_bn_act(out, self.conv2.weight, None, self.bn2, relu=True, residual=x, padding=1)
+
+
+class GatedSpatialConv2d(nn.Conv2d):
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=0, dilation=1, groups=1, bias=False):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        if self.kernel_size != (1, 1) or groups != 1:
+            raise NotImplementedError("gate convolution is 1x1, groups=1 on this path")
+        self._gate_conv = nn.Sequential(
+            Norm2d(in_channels + 1), nn.Conv2d(in_channels + 1, in_channels + 1, 1), nn.ReLU(),
+            nn.Conv2d(in_channels + 1, 1, 1), Norm2d(1), nn.Sigmoid())
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_normal_(self.weight)
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def forward(self, input_features, gating_features):
+        g = self._gate_conv
+        a = HF.batch_norm_act(HF.cat([input_features, gating_features]), g[0], relu=False)
+        a = HF.relu(HF.conv2d(a, g[1].weight, g[1].bias))
+        # conv (C+1 -> 1) -> BatchNorm(1) -> sigmoid
+        a = HF.sigmoid(HF.conv_bn_act(a, g[3].weight, g[3].bias, g[4], relu=False))
+        y = HF.conv2d(HF.gate_mul(input_features, a), self.weight, self.bias)
+        return y, a
+
+
+# ------------------------------------------------------------------------------------------------ dual attention decoder
+class SEModule(nn.Module):
+    def __init__(self, channels, reduction):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.fc1 = nn.Conv2d(channels, channels // reduction, kernel_size=1, padding=0)
+        self.relu = nn.ReLU(inplace=True)
+        self.fc2 = nn.Conv2d(channels // reduction, channels, kernel_size=1, padding=0)
+        self.sigmoid = nn.Sigmoid()
+        _init_conv_bn(self, (nn.Conv2d,))
+
+    def forward(self, x):
+        zero_s = torch.zeros((x.shape[0], 1, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device)
+        return HF.dual_att_tail(x, zero_s, self.fc1, self.fc2)
+
+
+class SpatialAttentionBlock(nn.Module):
+    def __init__(self, in_features, attn_features, up_factor, normalize_attn=False):
+        super().__init__()
+        if normalize_attn:
+            raise NotImplementedError("normalize_attn=True is never used by SAUNet")
+        self.up_factor = up_factor
+        self.normalize_attn = normalize_attn
+        self.down = nn.Conv2d(in_features, attn_features, kernel_size=1, padding=0, bias=False)
+        self.phi = nn.Conv2d(attn_features, 1, kernel_size=1, padding=0, bias=True)
+        self.relu = nn.ReLU(inplace=True)
+        self.bn = nn.BatchNorm2d(attn_features)
+        _init_conv_bn(self, (nn.Conv2d,))
+
+    def forward(self, x):
+        c = HF.conv_bn_act(x, self.down.weight, None, self.bn, relu=True)
+        return HF.sigmoid(HF.conv2d(c, self.phi.weight, self.phi.bias))
+
+
+class _MRF(nn.Module):
+    def __init__(self, inchannels):
+        super().__init__()
+        self.up = nn.Sequential(nn.ConvTranspose2d(inchannels[0], inchannels[0], kernel_size=4, stride=2, padding=1),
+                                nn.BatchNorm2d(inchannels[0]), nn.ReLU(inplace=True))
+        _init_conv_bn(self)
+
+    def forward(self, channels):
+        if len(channels) == 1:
+            return channels[0]
+        up = HF.conv_bn_act(channels[0], self.up[0].weight, self.up[0].bias, self.up[1], relu=True, transposed=True)
+        return HF.cat([channels[1], up])
+
+
+class DualAttBlock(nn.Module):
+    def __init__(self, inchannels=[128, 256], outchannels=256):
+        super().__init__()
+        self.mrf = _MRF(inchannels)
+        self.spatialAttn = SpatialAttentionBlock(outchannels, int(outchannels / 4), 2)
+        self.channelAttn = SEModule(outchannels, 16)
+        self.c3x3rb = ConvBNReLU(sum(inchannels), outchannels, 3, 1, 1)
+        _init_conv_bn(self)
+
+    def forward(self, x):
+        fused = self.c3x3rb(self.mrf(x))
+        spatial = self.spatialAttn(fused)
+        out = HF.dual_att_tail(fused, spatial, self.channelAttn.fc1, self.channelAttn.fc2)  # (1 + S) * SE(F)
+        return out, spatial
+
+
+class DecoderBlock(nn.Module):
+    def __init__(self, in_channels, middle_channels, out_channels, is_deconv=True):
+        super().__init__()
+        if not is_deconv:
+            raise NotImplementedError("SAUNet builds DecoderBlock with is_deconv=True")
+        self.in_channels = in_channels
+        self.block = nn.Sequential(conv3x3_bn_relu(in_channels, middle_channels),
+                                   nn.ConvTranspose2d(middle_channels, out_channels, kernel_size=4, stride=2, padding=1),
+                                   nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
+        _init_conv_bn(self, (nn.Conv2d,))
+
+    def forward(self, x):
+        b = self.block
+        return HF.conv_bn_act(b[0](x), b[1].weight, b[1].bias, b[2], relu=True, transposed=True)
+
+
+# ------------------------------------------------------------------------------------------------ DenseNet-121 encoder
+class _DenseLayer(nn.Module):
+    def __init__(self, cin, growth, bn_size):
+        super().__init__()
+        self.norm1 = nn.BatchNorm2d(cin); self.relu1 = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(cin, bn_size * growth, 1, bias=False)
+        self.norm2 = nn.BatchNorm2d(bn_size * growth); self.relu2 = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(bn_size * growth, growth, 3, padding=1, bias=False)
+
+
+class _DenseBlock(nn.ModuleDict):
+    def __init__(self, num_layers, cin, growth=32, bn_size=4):
+        super().__init__()
+        for i in range(num_layers):
+            self["denselayer%d" % (i + 1)] = _DenseLayer(cin + i * growth, growth, bn_size)
+
+    def forward(self, x, with_stats=False):
+        buf, stats = HF.dense_block(x, list(self.values()), self.training)
+        return (buf, stats) if with_stats else buf
+
+
+class _Transition(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__(OrderedDict([("norm", nn.BatchNorm2d(cin)), ("relu", nn.ReLU(inplace=True)),
+                                      ("conv", nn.Conv2d(cin, cout, 1, bias=False)), ("pool", nn.AvgPool2d(2, 2))]))
+
+    def forward(self, x, stats=None):
+        if stats is None and self.training:
+            stats = HF.bn_stats(x)
+        return HF.transition(x, stats, self, self.training)
+
+
+class DenseNet121(nn.Module):
+    """torchvision.models.densenet121 layout (features.* / classifier keys); only `features` is on the path."""
+
+    def __init__(self, growth=32, blocks=(6, 12, 24, 16), init_features=64, bn_size=4, num_classes=1000):
+        super().__init__()
+        feats = OrderedDict([("conv0", nn.Conv2d(3, init_features, 7, stride=2, padding=3, bias=False)),
+                             ("norm0", nn.BatchNorm2d(init_features)), ("relu0", nn.ReLU(inplace=True)),
+                             ("pool0", nn.MaxPool2d(3, stride=2, padding=1))])
+        c = init_features
+        for b, n in enumerate(blocks):
+            feats["denseblock%d" % (b + 1)] = _DenseBlock(n, c, growth, bn_size)
+            c += n * growth
+            if b != len(blocks) - 1:
+                feats["transition%d" % (b + 1)] = _Transition(c, c // 2)
+                c //= 2
+        feats["norm5"] = nn.BatchNorm2d(c)
+        self.features = nn.Sequential(feats)
+        self.classifier = nn.Linear(c, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1); nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.constant_(m.bias, 0)
+
+
+def densenet121(pretrained=False, **kw):
+    """ImageNet weights cannot be downloaded here; load them with load_state_dict if you have them."""
+    return DenseNet121(**kw)
+
+
+class _Stem(nn.Sequential):
+    """conv0 (7x7 s2, 3->64) + norm0, no ReLU / pool (models/models.py:304-305).  The 3-channel image is padded
+    to 8 channels so the MFMA implicit-GEMM path (16-byte channel chunks) applies."""
+
+    def forward(self, x):
+        conv, bn = self[0], self[1]
+        w8 = torch.nn.functional.pad(conv.weight, (0, 0, 0, 0, 0, 8 - conv.weight.shape[1]))
+        return HF.conv_bn_act(x, w8, None, bn, relu=False, stride=2, padding=3)
+
+
+class _Tail(nn.Sequential):
+    """denseblock4 + norm5 (no ReLU), models/models.py:312-313."""
+
+    def forward(self, x):
+        buf, stats = self[0](x, with_stats=True)
+        return HF.batch_norm_act(buf, self[1], relu=False, stats=stats if self.training else None)
+
+
+# ------------------------------------------------------------------------------------------------ SAUNet
+class SAUNet(nn.Module):
+    def __init__(self, num_classes=4, num_filters=32, pretrained=True, is_deconv=True, compute_dtype=None):
+        super().__init__()
+        self.num_classes = num_classes
+        self.compute_dtype = compute_dtype or _COMPUTE_DTYPE
+        self.pool = nn.MaxPool2d(2, 2)
+        self.encoder = densenet121(pretrained=pretrained)
+        self.relu = nn.ReLU(inplace=True)
+        self.sigmoid = nn.Sigmoid()
+        # shape stream
+        self.c3 = nn.Conv2d(256, 1, kernel_size=1)
+        self.c4 = nn.Conv2d(512, 1, kernel_size=1)
+        self.c5 = nn.Conv2d(1024, 1, kernel_size=1)
+        self.d0 = nn.Conv2d(128, 64, kernel_size=1)
+        self.res1 = BasicBlock(64, 64)
+        self.d1 = nn.Conv2d(64, 32, kernel_size=1)
+        self.res2 = BasicBlock(32, 32)
+        self.d2 = nn.Conv2d(32, 16, kernel_size=1)
+        self.res3 = BasicBlock(16, 16)
+        self.d3 = nn.Conv2d(16, 8, kernel_size=1)
+        self.fuse = nn.Conv2d(8, 1, kernel_size=1, padding=0, bias=False)
+        self.cw = nn.Conv2d(2, 1, kernel_size=1, padding=0, bias=False)
+        self.gate1 = GatedSpatialConv2d(32, 32)
+        self.gate2 = GatedSpatialConv2d(16, 16)
+        self.gate3 = GatedSpatialConv2d(8, 8)
+        self.expand = ConvBNReLU(1, num_filters, kernel_size=1, padding=0)
+        # encoder aliases (the same module objects, registered twice like the reference -> same state-dict keys)
+        f = self.encoder.features
+        self.conv1 = _Stem(f.conv0, f.norm0)
+        self.conv2 = f.denseblock1
+        self.conv2t = f.transition1
+        self.conv3 = f.denseblock2
+        self.conv3t = f.transition2
+        self.conv4 = f.denseblock3
+        self.conv4t = f.transition3
+        self.conv5 = _Tail(f.denseblock4, f.norm5)
+        # decoder
+        self.center = conv3x3_bn_relu(1024, num_filters * 8 * 2)
+        self.dec5 = DualAttBlock(inchannels=[512, 1024], outchannels=512)
+        self.dec4 = DualAttBlock(inchannels=[512, 512], outchannels=256)
+        self.dec3 = DualAttBlock(inchannels=[256, 256], outchannels=128)
+        self.dec2 = DualAttBlock(inchannels=[128, 128], outchannels=64)
+        self.dec1 = DecoderBlock(64, 48, num_filters, is_deconv)
+        self.dec0 = conv3x3_bn_relu(num_filters * 2, num_filters)
+        self.final = nn.Conv2d(num_filters, self.num_classes, kernel_size=1)
+
+    def _prep_input(self, x):
+        """float image [B,3,H,W] (any layout) -> NHWC, 8 channels (5 zero), compute dtype."""
+        n, c, h, w = x.shape
+        if c != 3:
+            raise RuntimeError("SAUNet expects a 3-channel image")
+        if h % 32 or w % 32:
+            raise RuntimeError("SAUNet input H, W must be multiples of 32")
+        xs = HF.nhwc(x.detach().to(torch.float32))
+        x8 = HF.new_act(n, 8, h, w, self.compute_dtype, x.device, zero=True)
+        HF.copy_channels(xs, x8[:, :3])
+        return x8
+
+    def forward(self, x, return_att=False):
+        size = x.shape[2:]
+        up = HF.interpolate_bilinear
+        conv1 = self.conv1(self._prep_input(x))
+        buf, st = self.conv2(conv1, with_stats=True); conv2 = self.conv2t(buf, st)
+        buf, st = self.conv3(conv2, with_stats=True); conv3 = self.conv3t(buf, st)
+        buf, st = self.conv4(conv3, with_stats=True); conv4 = self.conv4t(buf, st)
+        conv5 = self.conv5(conv4)
+
+        def conv(m, t):
+            return HF.conv2d(t, m.weight, m.bias)
+
+        ss = self.res1(up(conv(self.d0, conv2), size))
+        c3 = up(conv(self.c3, conv3), size)
+        ss, g1 = self.gate1(conv(self.d1, ss), c3)
+        ss = conv(self.d2, self.res2(ss))
+        c4 = up(conv(self.c4, conv4), size)
+        ss, g2 = self.gate2(ss, c4)
+        ss = conv(self.d3, self.res3(ss))
+        c5 = up(conv(self.c5, conv5), size)
+        ss, g3 = self.gate3(ss, c5)
+        ss = up(conv(self.fuse, ss), size)
+        edge_out = HF.sigmoid(ss)
+
+        canny = HF.canny(x, 10, 100, dtype=self.compute_dtype)            # on device, no host round trip
+        acts = HF.sigmoid(conv(self.cw, HF.cat([edge_out, canny])))
+        edge = self.expand(acts)
+
+        conv2u, conv3u, conv4u = up(conv2, scale_factor=2), up(conv3, scale_factor=2), up(conv4, scale_factor=2)
+        center = self.center(HF.max_pool2x2(conv5))
+        dec5, att5 = self.dec5([center, conv5])
+        dec4, att4 = self.dec4([dec5, conv4u])
+        dec3, att3 = self.dec3([dec4, conv3u])
+        dec2, att2 = self.dec2([dec3, conv2u])
+        dec1 = self.dec1(dec2)
+        dec0 = self.dec0(HF.cat([dec1, edge]))
+        x_out = conv(self.final, dec0)
+        if return_att:
+            with torch.no_grad():
+                maps = [up(att2, scale_factor=2), up(att3, scale_factor=4), up(att4, scale_factor=8), up(att5, scale_factor=16)]
+            return x_out, edge_out, maps + [g1, g2, g3]
+        return x_out, edge_out
+
+
+# ------------------------------------------------------------------------------------------------ loss / task wrapper
+class DualLoss(nn.Module):
+    def __init__(self, num_classes=4, lmbda=10, epsilon=10e-6, mode="train"):
+        super().__init__()
+        if num_classes != 4:
+            raise NotImplementedError("the fused loss kernel is specialised for the 4 ACDC classes")
+        self.epsilon, self.lmbda, self.channels = epsilon, lmbda, num_classes
+        self.epoch, self.alpha = 1, 1.0
+        self.last_metrics = None
+
+    def forward(self, pred, target, epoch=0):
+        seg, edge_in = pred
+        seg_t, edge_t = target
+        if seg_t.dim() == 2:
+            seg_t = seg_t.unsqueeze(0)
+        loss, metrics = HF.dual_loss(seg, edge_in, seg_t, edge_t)
+        self.last_metrics = metrics
+        return loss
+
+
+class SegmentationModuleBase(nn.Module):
+    def pixel_acc(self, metrics, num_class):
+        return metrics[0], [metrics[i] for i in range(1, num_class)]
+
+
+class SegmentationModule(SegmentationModuleBase):
+    def __init__(self, crit, unet, num_class):
+        super().__init__()
+        self.crit, self.unet, self.num_class = crit, unet, num_class
+
+    def forward(self, feed_dict, epoch, *, segSize=None, return_att=False):
+        if segSize is None:  # training
+            p = self.unet(feed_dict["image"])
+            loss = self.crit(p, feed_dict["mask"], epoch=epoch)
+            return loss, self.pixel_acc(self.crit.last_metrics, self.num_class)
+        if segSize is True:  # test
+            p, e, maps = self.unet(feed_dict["image"], return_att=True)
+            return torch.softmax(p.float(), dim=1), maps
+        out = self.unet(feed_dict["image"], return_att=return_att)
+        seg_t, edge_t = feed_dict["mask"]
+        loss = self.crit((out[0], out[1]), (seg_t.long().unsqueeze(0), edge_t.unsqueeze(0)))
+        return torch.softmax(out[0].float(), dim=1), loss
+
+
+class ModelBuilder:
+    def build_unet(self, num_class=1, arch="saunet", weights=""):
+        if arch.lower() != "saunet":
+            raise Exception("Architecture undefined!")
+        unet = SAUNet(num_classes=num_class)
+        if len(weights) > 0:
+            unet.load_state_dict(torch.load(weights, map_location=lambda storage, loc: storage), strict=False)
+        return unet
