@@ -32,7 +32,13 @@ def nhwc(t):
 
 
 def ld_of(t):
-    return 1 if t.shape[1] == 1 else t.stride(3)
+    """channel stride (elements between consecutive pixels) of an NHWC view"""
+    n, c, h, w = t.shape
+    if w > 1:
+        return t.stride(3)
+    if h > 1:
+        return t.stride(2)
+    return t.stride(0) if n > 1 else c
 
 
 def new_act(n, c, h, w, dtype, device, zero=False):
@@ -315,6 +321,8 @@ def conv_bn_act(x, weight, bias, bn, relu=True, residual=None, stride=1, padding
     process group when one with more than one rank exists."""
     if bn.training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
+    if transposed:
+        stride, padding = 2, 1  # the only transposed geometry on the path: ConvTranspose2d(k=4, s=2, p=1)
     group = None
     if getattr(bn, "sync", False) and bn.training and torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size() > 1:

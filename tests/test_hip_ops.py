@@ -24,7 +24,7 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 def to_dev(t, dtype):
-    t = t.cuda()
+    t = t.detach().cuda()
     if t.dim() == 4:
         t = t.to(dtype).contiguous(memory_format=torch.channels_last)
     return t
@@ -32,7 +32,7 @@ def to_dev(t, dtype):
 
 def q(t, dtype):
     """what the device sees after storage rounding (so bf16 tests compare like with like)"""
-    return t.to(dtype).float()
+    return t.detach().to(dtype).float().clone()
 
 
 def close(a, b, tol, what=""):
@@ -72,7 +72,7 @@ def test_conv2d_fwd_bwd(case, dtype):
     yr = F.conv2d(xr, wq + (wr - wr.detach()), br, s, p)
     cot = rnd(*yr.shape, seed=5)
     yr.backward(q(cot, dtype))
-    xd = to_dev(x, dtype).requires_grad_(True); wd = wt.cuda().requires_grad_(True); bd = b.cuda().requires_grad_(True)
+    xd = to_dev(x, dtype).requires_grad_(s == 1); wd = wt.cuda().requires_grad_(True); bd = b.cuda().requires_grad_(True)
     yd = hf.conv2d(xd, wd, bd, s, p)
     yd.backward(to_dev(cot, dtype))
     tol = TOL[dtype]
@@ -147,6 +147,7 @@ def test_conv_bn_act(dtype, relu, res, transposed):
     xr = q(x, dtype).requires_grad_(True); wr = wt.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
     wq = q(wt, dtype) + (wr - wr.detach())
     z = F.conv_transpose2d(xr, wq, br, stride=2, padding=1) if transposed else F.conv2d(xr, wq, br, 1, 1)
+    z = z + (q(z, dtype) - z).detach()   # the device stores the conv output in `dtype` (straight-through for the gradient)
     y = bn_r(z)
     if res:
         y = y + xr
