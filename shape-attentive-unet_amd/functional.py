@@ -8,6 +8,7 @@ Backward passes are written by hand so that producer/consumer fusion survives di
   * concatenation is a write into a channel slice.
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -42,8 +43,8 @@ def ld_of(t):
 
 
 def new_act(n, c, h, w, dtype, device, zero=False):
-    f = torch.zeros if zero else torch.empty
-    return f((n, c, h, w), dtype=dtype, device=device, memory_format=_CL)
+    t = torch.empty((n, c, h, w), dtype=dtype, device=device, memory_format=_CL)
+    return t.zero_() if zero else t
 
 
 def _check_dev(t):
@@ -59,12 +60,13 @@ class PackedWeights:
         self.cache = {}
 
     def get(self, w, mode, dtype):
-        # only leaf Parameters are cached (temporaries may reuse an address with the same version counter)
+        # only leaf Parameters are cached, identified by object (weakref) + version counter: an address or an id()
+        # can be recycled by another tensor, a live object cannot
         cacheable = isinstance(w, torch.nn.Parameter)
-        key = (w.data_ptr(), mode, dtype)
+        key = (id(w), mode, dtype)
         ent = self.cache.get(key) if cacheable else None
         ver = w._version
-        if ent is not None and ent[0] == ver and ent[1].device == w.device:
+        if ent is not None and ent[2]() is w and ent[0] == ver and ent[1].device == w.device and ent[3] == w.data_ptr():
             return ent[1]
         out = torch.empty(w.numel(), dtype=dtype, device=w.device)
         wd = w.detach()
@@ -77,7 +79,9 @@ class PackedWeights:
         L.call("saunet_pack_weight", mode, L.BF16 if dtype == torch.bfloat16 else L.F32, wd.data_ptr(), co, ci, kh, kw,
                out.data_ptr(), L.stream())
         if cacheable:
-            self.cache[key] = (ver, out)
+            if len(self.cache) > 4096:
+                self.cache = {k: v for k, v in self.cache.items() if v[2]() is not None}
+            self.cache[key] = (ver, out, weakref.ref(w), w.data_ptr())
         return out
 
     def clear(self):
@@ -476,6 +480,31 @@ def cat(xs):
     return _Cat.apply(*xs)
 
 
+class _Cast(torch.autograd.Function):
+    """storage-dtype conversion (bf16 <-> float32) of an activation; the gradient is cast back."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        ctx.src_dtype = x.dtype
+        y = new_act(n, c, h, w, dtype, x.device)
+        copy_channels(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = nhwc(dy)
+        n, c, h, w = dy.shape
+        dx = new_act(n, c, h, w, ctx.src_dtype, dy.device)
+        copy_channels(dy, dx)
+        return dx, None
+
+
+def cast(x, dtype):
+    return x if x.dtype == dtype else _Cast.apply(x, dtype)
+
+
 class _GateMul(torch.autograd.Function):
     """x * (alpha + 1) with a one-channel alpha (GSConv.py:55)."""
 
@@ -554,12 +583,22 @@ def dual_att_tail(F, S, fc1, fc2):
     return _DualAttTail.apply(F, S, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
 
 
+def _as_f32(t):
+    t = nhwc(t)
+    if t.dtype == torch.float32:
+        return t
+    n, c, h, w = t.shape
+    return copy_channels(t, new_act(n, c, h, w, torch.float32, t.device))
+
+
 class _DualLoss(torch.autograd.Function):
-    """dice + weighted CE + BCE(edge) and the pixel_acc metrics from one pass (loss.py:149-159)."""
+    """dice + weighted CE + BCE(edge) and the pixel_acc metrics from one pass (loss.py:149-159).
+    The loss always runs on float32 copies of the (4+1)-channel heads, whatever the storage dtype."""
 
     @staticmethod
     def forward(ctx, logits, edge, seg_t, edge_t):
-        logits = nhwc(logits); edge = nhwc(edge)
+        ctx.in_dtypes = (logits.dtype, edge.dtype)
+        logits = _as_f32(logits); edge = _as_f32(edge)
         n, c, h, w = logits.shape
         if c != 4:
             raise RuntimeError("DualLoss kernel is specialised for 4 classes, got %d" % c)
@@ -567,9 +606,10 @@ class _DualLoss(torch.autograd.Function):
         dev = logits.device
         seg_t = seg_t.to(device=dev, dtype=torch.int64).contiguous()
         edge_t = edge_t.to(device=dev, dtype=torch.float32).contiguous()
+        if seg_t.numel() != P or edge_t.numel() != P:
+            raise RuntimeError("DualLoss: target sizes %s / %s do not match logits %s" % (tuple(seg_t.shape), tuple(edge_t.shape), tuple(logits.shape)))
         sums = torch.zeros(32, dtype=torch.float64, device=dev)
-        dt = L.dtype_code(logits)
-        L.call("saunet_dual_loss_forward", dt, logits.data_ptr(), ld_of(logits), edge.data_ptr(), seg_t.data_ptr(), edge_t.data_ptr(), P,
+        L.call("saunet_dual_loss_forward", L.F32, logits.data_ptr(), ld_of(logits), edge.data_ptr(), seg_t.data_ptr(), edge_t.data_ptr(), P,
                sums.data_ptr(), L.stream())
         out = torch.empty(5, dtype=torch.float32, device=dev)
         L.call("saunet_dual_loss_finalize", sums.data_ptr(), P, out.data_ptr(), out[1:].data_ptr(), L.stream())
@@ -582,11 +622,15 @@ class _DualLoss(torch.autograd.Function):
     def backward(ctx, dloss, _dmetrics):
         logits, edge, seg_t, edge_t, sums = ctx.saved_tensors
         n, c, h, w = logits.shape
-        dl = new_act(n, c, h, w, logits.dtype, logits.device)
-        de = new_act(n, 1, h, w, logits.dtype, logits.device)
+        dl = new_act(n, c, h, w, torch.float32, logits.device)
+        de = new_act(n, 1, h, w, torch.float32, logits.device)
         dloss = dloss.to(torch.float32).contiguous()
-        L.call("saunet_dual_loss_backward", L.dtype_code(logits), logits.data_ptr(), ld_of(logits), edge.data_ptr(), seg_t.data_ptr(),
+        L.call("saunet_dual_loss_backward", L.F32, logits.data_ptr(), ld_of(logits), edge.data_ptr(), seg_t.data_ptr(),
                edge_t.data_ptr(), n * h * w, sums.data_ptr(), dloss.data_ptr(), dl.data_ptr(), ld_of(dl), de.data_ptr(), L.stream())
+        if ctx.in_dtypes[0] != torch.float32:
+            dl = copy_channels(dl, new_act(n, c, h, w, ctx.in_dtypes[0], dl.device))
+        if ctx.in_dtypes[1] != torch.float32:
+            de = copy_channels(de, new_act(n, 1, h, w, ctx.in_dtypes[1], de.device))
         return dl, de, None, None
 
 

@@ -373,12 +373,14 @@ class SAUNet(nn.Module):
         ss = conv(self.d3, self.res3(ss))
         c5 = up(conv(self.c5, conv5), size)
         ss, g3 = self.gate3(ss, c5)
-        ss = up(conv(self.fuse, ss), size)
+        # the one/two-channel edge head stays in float32 whatever the storage dtype: a bf16 sigmoid saturates to
+        # exactly 1.0 and BCE's log(1 - e) would hit its -100 clamp (the reference is float32 throughout)
+        ss = HF.cast(up(conv(self.fuse, ss), size), torch.float32)
         edge_out = HF.sigmoid(ss)
 
-        canny = HF.canny(x, 10, 100, dtype=self.compute_dtype)            # on device, no host round trip
+        canny = HF.canny(x, 10, 100, dtype=torch.float32)                 # on device, no host round trip
         acts = HF.sigmoid(conv(self.cw, HF.cat([edge_out, canny])))
-        edge = self.expand(acts)
+        edge = HF.cast(self.expand(acts), self.compute_dtype)
 
         conv2u, conv3u, conv4u = up(conv2, scale_factor=2), up(conv3, scale_factor=2), up(conv4, scale_factor=2)
         center = self.center(HF.max_pool2x2(conv5))

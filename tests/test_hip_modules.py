@@ -1,0 +1,70 @@
+"""GPU parity of the drop-in nn.Modules against the fixtures the REAL reference produced
+(tests/golden/modules_*.npz) -- float32 storage, tolerance 1e-4 of each tensor's max (north_star: 1e-3)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import load, rnd, module_state, close
+
+pytestmark = pytest.mark.gpu
+
+
+def build(name):
+    import saunet_amd as S
+    return {
+        "SEModule": lambda: S.SEModule(32, 16),
+        "SpatialAttentionBlock": lambda: S.SpatialAttentionBlock(32, 8, 2),
+        "DualAttBlock": lambda: S.DualAttBlock(inchannels=[32, 48], outchannels=32),
+        "GatedSpatialConv2d": lambda: S.GatedSpatialConv2d(16, 16),
+        "BasicBlock": lambda: S.BasicBlock(16, 16),
+        "DecoderBlock": lambda: S.DecoderBlock(32, 24, 16, True),
+        "conv3x3_bn_relu": lambda: S.conv3x3_bn_relu(24, 16),
+    }[name]()
+
+
+CALL = {"DualAttBlock": lambda m, xs: m([xs[0], xs[1]])}
+NAMES = ["SEModule", "SpatialAttentionBlock", "DualAttBlock", "GatedSpatialConv2d", "BasicBlock", "DecoderBlock", "conv3x3_bn_relu"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_module_matches_reference_fixture(name):
+    gold = load("modules_%s.npz" % name)
+    seed = int(gold["meta.seed"])
+    sd = module_state(gold, name, seed)
+    mod = build(name).cuda()
+    res = mod.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all(("num_batches_tracked" in k) or ("_tmp_running" in k) or ("_running_iter" in k) for k in res.missing_keys), res.missing_keys
+    nin = sum(1 for k in gold if k.startswith("meta.shape"))
+    xs = [rnd(tuple(gold["meta.shape%d" % i]), seed, "%s.in%d" % (name, i)).cuda().requires_grad_(True) for i in range(nin)]
+    call = CALL.get(name, lambda m, xs: m(*xs))
+    mod.train()
+    y = call(mod, xs)
+    ys = list(y) if isinstance(y, (tuple, list)) else [y]
+    cots = [rnd(tuple(t.shape), seed, "%s.cot%d" % (name, i)).cuda() for i, t in enumerate(ys)]
+    torch.autograd.backward(ys, cots)
+    tol = 1e-4
+    for i, t in enumerate(ys):
+        ok, err, sc = close(t.detach().float().cpu().numpy(), gold["train.out%d" % i], tol, 1e-6)
+        assert ok, "%s out%d err %.3g scale %.3g" % (name, i, err, sc)
+    for i, x in enumerate(xs):
+        ok, err, sc = close(x.grad.float().cpu().numpy(), gold["train.dx%d" % i], tol, 1e-6)
+        assert ok, "%s dx%d err %.3g scale %.3g" % (name, i, err, sc)
+    gscale = max(float(np.abs(gold[k]).max()) for k in gold if k.startswith("train.grad."))
+    for k, p in mod.named_parameters():
+        g = p.grad.float().cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+        ok, err, sc = close(g, gold["train.grad." + k], tol, 1e-5 * gscale)
+        assert ok, "%s grad %s err %.3g scale %.3g" % (name, k, err, sc)
+    for k, b in mod.named_buffers():
+        if ("train.buf." + k) in gold:
+            ok, err, sc = close(b.float().cpu().numpy(), gold["train.buf." + k], tol, 1e-6)
+            assert ok, "%s buffer %s err %.3g" % (name, k, err)
+    # eval mode (running statistics) from the ORIGINAL state
+    mod.load_state_dict(sd, strict=False)
+    mod.eval()
+    with torch.no_grad():
+        y = call(mod, [x.detach() for x in xs])
+    ys = list(y) if isinstance(y, (tuple, list)) else [y]
+    for i, t in enumerate(ys):
+        ok, err, sc = close(t.float().cpu().numpy(), gold["eval.out%d" % i], tol, 1e-6)
+        assert ok, "%s eval out%d err %.3g scale %.3g" % (name, i, err, sc)

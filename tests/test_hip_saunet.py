@@ -1,0 +1,146 @@
+"""Whole-network GPU parity: SAUNet forward + DualLoss + backward on the HIP path vs
+ (a) the fixture the REAL reference produced for config #1 (B=2, 128x128) and
+ (b) the CPU oracle on other sizes / seeds; plus size-independent properties at the bench size."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import saunet_ref as R, weights as Wt
+from tests.golden_util import load, close
+
+pytestmark = pytest.mark.gpu
+
+
+def make_net(seed, dtype=torch.float32):
+    import saunet_amd as S
+    S.set_compute_dtype(dtype)
+    spec = R.state_dict_spec()
+    sd = Wt.make_state_dict(spec, seed)
+    net = S.SAUNet(num_classes=4).cuda()
+    res = net.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    sm = S.SegmentationModule(S.DualLoss(mode="train"), net, 4)
+    return S, spec, sd, net, sm
+
+
+def test_config1_against_reference_fixture():
+    g = load("saunet_128.npz")
+    seed, B, H = int(g["meta.seed"]), int(g["meta.B"]), int(g["meta.H"])
+    S, spec, sd, net, sm = make_net(seed)
+    img, seg, edge = Wt.synthetic_batch(B, H, H)
+    feed = {"image": img.cuda(), "mask": (seg.cuda(), edge.cuda())}
+    sm.train()
+    loss, (acc, jac) = sm(feed, 1)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss0"])) < 1e-4, (float(loss), float(g["loss0"]))
+    assert abs(float(acc) - float(g["acc0"])) < 1e-4
+    assert np.abs(np.array([float(j) for j in jac]) - g["jac0"]).max() < 1e-4
+    keys = list(g["grad_keys"])
+    pd = dict(net.named_parameters())
+    norms = np.array([float(pd[k].grad.double().norm()) for k in keys])
+    gmax = g["grad_norms"].max()
+    assert np.abs(norms - g["grad_norms"]).max() <= 1e-3 * gmax, np.abs(norms - g["grad_norms"]).max() / gmax
+    for k in g:
+        if k.startswith("grad."):
+            ok, err, sc = close(pd[k[5:]].grad.float().cpu().numpy(), g[k], 1e-3, 1e-5 * gmax)
+            assert ok, "%s err %.3g scale %.3g" % (k, err, sc)
+    bd = dict(net.named_buffers())
+    for k in g:
+        if k.startswith("buf."):
+            ok, err, sc = close(bd[k[4:]].float().cpu().numpy(), g[k], 1e-4, 1e-6)
+            assert ok, "%s err %.3g" % (k, err)
+    # forward tensors with fresh weights
+    net.load_state_dict(sd, strict=False)
+    with torch.no_grad():
+        lg, eo = net(img.cuda())
+    ok, err, sc = close(lg[:, :, ::8, ::8].float().cpu().numpy(), g["logits_s8"], 1e-3, 1e-5)
+    assert ok, "logits err %.3g scale %.3g" % (err, sc)
+    ok, err, sc = close(eo[:, :, ::8, ::8].float().cpu().numpy(), g["edge_s8"], 1e-3, 1e-5)
+    assert ok, "edge err %.3g" % err
+    # inference branch on the initial weights
+    net.load_state_dict(sd, strict=False)
+    sm.eval()
+    with torch.no_grad():
+        pred, l_eval = sm({"image": img[:1].cuda(), "mask": (seg[0].cuda(), edge[0].cuda())}, epoch=0, segSize=(H, H))
+    assert abs(float(l_eval) - float(g["eval0_loss"])) < 1e-3 * max(1.0, abs(float(g["eval0_loss"])))
+    ok, err, sc = close(pred[:, :, ::8, ::8].float().cpu().numpy(), g["eval0_pred_s8"], 1e-3, 1e-5)
+    assert ok, "eval softmax err %.3g" % err
+
+
+def test_sgd_trajectory_config1():
+    """10 fused-SGD steps (lr 5e-4, m 0.9, wd 1e-4 on conv weights) track the reference's loss curve."""
+    g = load("saunet_128.npz")
+    seed, B, H = int(g["meta.seed"]), int(g["meta.B"]), int(g["meta.H"])
+    S, spec, sd, net, sm = make_net(seed)
+    img, seg, edge = Wt.synthetic_batch(B, H, H)
+    feed = {"image": img.cuda(), "mask": (seg.cuda(), edge.cuda())}
+    opt = S.optim.create_optimizers(net, "sgd", lr=5e-4, momentum=0.9, weight_decay=1e-4)[0]
+    sm.train()
+    traj = []
+    for it in range(10):
+        sm.zero_grad()
+        loss, _ = sm(feed, 1)
+        loss.backward(); opt.step(); traj.append(float(loss))
+    d = np.abs(np.array(traj) - g["sgd_traj"])
+    assert d[:3].max() < 2e-4 and d.max() < 1e-2, (traj, list(g["sgd_traj"]))
+    assert traj[-1] < traj[0] - 0.5
+
+
+@pytest.mark.parametrize("B,H,W,seed", [(1, 64, 96, 7), (3, 64, 64, 9)])
+def test_other_shapes_against_oracle(B, H, W, seed):
+    S, spec, sd, net, sm = make_net(seed)
+    img, seg, edge = Wt.synthetic_batch(B, H, W, seed=100 + seed)
+    sdo = {k: v.clone() for k, v in sd.items()}
+    keys = Wt.trainable_keys(spec)
+    for k in keys:
+        sdo[k].requires_grad_(True)
+    loss_o, acc_o, lg_o, eo_o = R.segmentation_step(sdo, img, seg, edge, True)
+    loss_o.backward()
+    sm.train()
+    loss, (acc, jac) = sm({"image": img.cuda(), "mask": (seg.cuda(), edge.cuda())}, 1)
+    loss.backward()
+    assert abs(float(loss) - float(loss_o)) < 1e-4 * max(1.0, float(loss_o))
+    pd = dict(net.named_parameters())
+    gmax = max(float(sdo[k].grad.abs().max()) for k in keys)
+    for k in keys:
+        err = float((pd[k].grad.cpu() - sdo[k].grad).abs().max())
+        assert err < 1e-3 * gmax, (k, err, gmax)
+
+
+def test_bf16_storage_tracks_fp32_oracle():
+    """bf16 activations/weights, fp32 accumulate/statistics/loss: loss within 2% and Dice-style metrics close."""
+    seed = 3
+    S, spec, sd, net, sm = make_net(seed, torch.bfloat16)
+    try:
+        img, seg, edge = Wt.synthetic_batch(2, 128, 128)
+        sdo = {k: v.clone() for k, v in sd.items()}
+        loss_o, acc_o, _, _ = R.segmentation_step(sdo, img, seg, edge, True)
+        sm.train()
+        loss, (acc, jac) = sm({"image": img.cuda(), "mask": (seg.cuda(), edge.cuda())}, 1)
+        loss.backward()
+        assert abs(float(loss) - float(loss_o)) < 0.02 * float(loss_o), (float(loss), float(loss_o))
+        assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    finally:
+        S.set_compute_dtype(torch.float32)
+
+
+def test_properties_at_bench_size():
+    """256x256 (BASELINE config 2 geometry, small batch): size-independent checks."""
+    S, spec, sd, net, sm = make_net(11)
+    img, seg, edge = Wt.synthetic_batch(2, 256, 256, seed=5)
+    net.train()
+    x = img.cuda()
+    lg, eo = net(x)
+    assert lg.shape == (2, 4, 256, 256) and eo.shape == (2, 1, 256, 256)
+    assert float(eo.min()) >= 0 and float(eo.max()) <= 1 and torch.isfinite(lg).all()
+    # batch-permutation equivariance of a train-mode step (batch statistics are permutation invariant)
+    net.load_state_dict(sd, strict=False)
+    lg1, _ = net(x)
+    net.load_state_dict(sd, strict=False)
+    lg2, _ = net(x.flip(0))
+    assert float((lg1 - lg2.flip(0)).abs().max()) < 1e-3 * float(lg1.abs().max())
+    # loss(logits) is invariant to adding a per-pixel constant to all class logits (softmax shift invariance)
+    crit = S.DualLoss()
+    l1 = crit((lg1.detach(), eo.detach()), (seg.cuda(), edge.cuda()))
+    l2 = crit((lg1.detach() + 3.0, eo.detach()), (seg.cuda(), edge.cuda()))
+    assert abs(float(l1) - float(l2)) < 1e-4
