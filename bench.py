@@ -1,0 +1,246 @@
+#!/usr/bin/env python
+"""SAUNet training-step benchmark on MI355X (BASELINE.json metric: 2-D slices/s, train fwd+bwd, 256x256).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = forward + DualLoss + backward + gradient all-reduce (N>1) + fused SGD update of the full
+SAUNet (DenseNet-121 encoder, shape stream, dual-attention decoder) on a device-resident synthetic batch
+of 32 slices/GPU at 256x256, bf16 storage / fp32 accumulate (BASELINE config 2; configs 3-5 via flags).
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+# algorithmic work per 256x256 slice (SURVEY.md section 8d / BASELINE.md section 2, conv+convT MACs x2, train = 3x fwd - conv0 dgrad)
+TRAIN_GFLOP_PER_SLICE_256 = 216.1
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="slices per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "radam"])
+    return ap.parse_args()
+
+
+def kernel_roofline(S, dtype, batch, size):
+    """Time the dominant kernel family on its own with HIP events on the launch stream.
+
+    Dominant kernel of the step (profiles/): the DenseNet 3x3 implicit-GEMM convolution (128 -> 32 channels,
+    58 instances/forward; here block-1 geometry: B x 128 x 128 pixels).  Algorithmic bytes per launch =
+    input [P,128] + output [P,32] elements x itemsize (+ weights 36,864 elements); algorithmic FLOPs = 2*P*1152*32."""
+    HF = S.functional
+    h = size // 2
+    n, cin, cout = batch, 128, 32
+    x = torch.randn(n, cin, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device="cuda") * 0.03)
+    scale = torch.rand(cin, device="cuda") + 0.5
+    shift = torch.randn(cin, device="cuda") * 0.1
+    out = HF.new_act(n, cout, h, h, dtype, "cuda")
+    stats = torch.zeros(2, cout, dtype=torch.float64, device="cuda")
+    def run():
+        HF.conv_forward_raw(x, w, None, 1, 1, pro=(scale, shift, True), out=out, stats=(stats[0], stats[1]))
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    reps = 30
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    P = n * h * h
+    flops = 2.0 * P * (cin * 9) * cout
+    nbytes = (P * cin + P * cout + cout * cin * 9) * x.element_size()
+    tflops = flops / (ms * 1e-3) / 1e12
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    ai = flops / nbytes
+    peak_tf = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
+    # the bound that applies: min(MFMA peak, AI x HBM peak)
+    hbm_bound_tf = ai * HBM_PEAK_GBS / 1e3
+    if hbm_bound_tf < peak_tf:
+        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "traffic": None, "kernel": "conv_igemm_fwd 3x3 128->32 @%dx%d B%d" % (h, h, n), "ms": round(ms, 4),
+                "tflops": round(tflops, 1), "flop_per_byte": round(ai, 1)}
+    return {"bound": "mfma", "achieved": round(tflops, 1), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(tflops / peak_tf, 4),
+            "traffic": None, "kernel": "conv_igemm_fwd 3x3 128->32 @%dx%d B%d" % (h, h, n), "ms": round(ms, 4),
+            "gbs": round(gbs, 1), "flop_per_byte": round(ai, 1)}
+
+
+def cpu_baseline(size):
+    """The CPU oracle (oracle/saunet_ref.py, the pinned restatement of the reference's PyTorch path) timed on this
+    host: B=2 slices, fwd+bwd+SGD, a bounded number of iterations."""
+    from oracle import saunet_ref as R, weights as Wt
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    spec = R.state_dict_spec()
+    sd = Wt.make_state_dict(spec, 0)
+    keys = Wt.trainable_keys(spec)
+    for k in keys:
+        sd[k].requires_grad_(True)
+    B = 2
+    img, seg, edge = Wt.synthetic_batch(B, size, size)
+    canny = R.canny_branch(img)
+    opt = torch.optim.SGD([sd[k] for k in keys], lr=5e-4, momentum=0.9)
+    times = []
+    t_start = time.time()
+    for it in range(8):
+        t0 = time.time()
+        opt.zero_grad()
+        loss, *_ = R.segmentation_step(sd, img, seg, edge, True, canny=canny)
+        loss.backward(); opt.step()
+        times.append(time.time() - t0)
+        if time.time() - t_start > 25 and it >= 2:
+            break
+    steady = sorted(times[1:])[len(times[1:]) // 2] if len(times) > 1 else times[0]
+    return {"value": round(B / steady, 3), "unit": "slices/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle restatement (PyTorch CPU fp32), B=2 %dx%d, fwd+bwd+SGD, median of %d iters after 1 warm-up" % (size, size, len(times) - 1)}
+
+
+def main():
+    args = parse()
+    import saunet_amd as S
+    from saunet_amd import dp, data, optim
+    rank, local, world = dp.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    S.set_compute_dtype(dtype)
+    torch.manual_seed(304)
+    net = S.SAUNet(num_classes=4).to(dev)
+    sm = S.SegmentationModule(S.DualLoss(mode="train"), net, 4).train()
+    dp.broadcast_parameters(net)
+    opt = optim.create_optimizers(net, args.optimizer, lr=5e-4, momentum=0.9, weight_decay=1e-4)[0]
+    buckets = dp.GradientBuckets(list(net.parameters()), bucket_mb=32.0, overlap=False) if world > 1 else None
+    img, seg, edge = data.synthetic_batch(args.batch, args.size, args.size, seed=304 + 1000 * rank, device=dev)
+    feed = {"image": img, "mask": (seg, edge)}
+
+    def fwd_bwd():
+        sm.zero_grad(set_to_none=True)
+        loss, _ = sm(feed, 1)
+        loss.backward()
+        return loss
+
+    def tail():
+        if buckets is not None:
+            buckets.finish()
+        opt.step(upload=False)
+
+    opt_ready = False
+    def eager_step():
+        nonlocal opt_ready
+        loss = fwd_bwd()
+        opt.upload_hyper()
+        tail()
+        opt_ready = True
+        return loss
+
+    # warm-up (also creates optimiser state and fills allocator pools)
+    for _ in range(max(args.warmup, 2)):
+        loss = eager_step()
+    torch.cuda.synchronize()
+    mode = "eager"
+    graph = None
+    if not args.no_graph:
+        try:
+            opt.upload_hyper()
+            graph = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                fwd_bwd()
+            torch.cuda.current_stream().wait_stream(s)
+            with torch.cuda.graph(graph):
+                static_loss = fwd_bwd()
+                if world == 1:
+                    tail()
+            mode = "hipgraph(fwd+bwd+opt)" if world == 1 else "hipgraph(fwd+bwd)+eager(allreduce+opt)"
+            graph.replay(); torch.cuda.synchronize()
+        except Exception as e:  # capture unsupported -> measured eagerly, and said so in the JSON
+            graph = None
+            mode = "eager (graph capture failed: %s)" % (str(e).splitlines()[0][:80])
+            torch.cuda.synchronize()
+
+    def step():
+        if graph is None:
+            return eager_step()
+        graph.replay()
+        if world > 1:
+            tail()
+        return static_loss
+
+    for _ in range(2):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt)
+    final_loss = float(loss.detach().float())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        slices = args.batch * world * args.steps / dt
+        scale = (args.size / 256.0) ** 2
+        out = {
+            "metric": "2D slices/sec (train fwd+bwd+allreduce+SGD) at %dx%d" % (args.size, args.size),
+            "value": round(slices, 2), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic (ellipse phantom, z-scored; random-init weights)",
+            "config": {"workload": "ACDC %dx%d batch=%d/GPU SAUNet %s, configs[%d]" % (args.size, args.size, args.batch, args.dtype, 1 if world == 1 else 2),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "mode": mode, "optimizer": args.optimizer,
+                       "loss": round(final_loss, 5)},
+            "achieved_tflops_algorithmic": round(slices * TRAIN_GFLOP_PER_SLICE_256 * scale / 1e3, 2),
+        }
+        if not args.no_roofline:
+            try:
+                out["roofline"] = kernel_roofline(S, dtype, args.batch, args.size)
+            except Exception as e:
+                out["roofline"] = {"error": str(e)[:200]}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.size)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": str(e)[:200]}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
