@@ -36,9 +36,13 @@ __device__ __forceinline__ unsigned int f32_to_bf16_bits(float f)
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// gfx950 has a hardware RNE convert (v_cvt_pk_bf16_f32): let the compiler pick it through the native type
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi)
 {
-    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <typename T> struct Elem;
@@ -50,7 +54,7 @@ template <> struct Elem<float> {
 template <> struct Elem<u16> {  // bf16 stored as raw 16-bit words
     static constexpr int dtype = SAUNET_BF16;
     __device__ static __forceinline__ float load(const u16* p) { return __uint_as_float(((unsigned int)*p) << 16); }
-    __device__ static __forceinline__ void store(u16* p, float v) { *p = (u16)f32_to_bf16_bits(v); }
+    __device__ static __forceinline__ void store(u16* p, float v) { *p = __builtin_bit_cast(u16, (__bf16)v); }
 };
 
 // 16-byte vector of T as floats: 4 f32 or 8 bf16

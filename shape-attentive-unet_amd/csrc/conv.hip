@@ -15,6 +15,9 @@ bool igemm_supported(const saunet_conv_desc* d);
 int igemm_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps, const float* psh,
                   void* y, double* ssum, double* ssq, hipStream_t st);
 int igemm_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw, hipStream_t st);
+bool tile_fwd_supported(const saunet_conv_desc* d);
+int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps, const float* psh,
+                 void* y, double* ssum, double* ssq, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------- packing
 template <typename T>
@@ -49,32 +52,45 @@ struct PwArgs {
     long P; int Cin, Cout, ldx, ldy, pro_relu;
 };
 
+// Each block owns ITEMS = 256*PW_IT consecutive (pixel, cout) items; thread t handles items t, t+256, ...
+// When 256 % Cout == 0 a thread always sees the same cout, so BN statistics are accumulated in registers and
+// leave the block as ONE LDS atomic per thread.
+constexpr int PW_IT = 8;
 template <typename T> __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwArgs a)
 {
     __shared__ float s_sum[64], s_sq[64];
     const bool stats = a.ssum != nullptr;
     if (stats && threadIdx.x < 64) { s_sum[threadIdx.x] = 0.f; s_sq[threadIdx.x] = 0.f; }
     if (stats) __syncthreads();
-    const long idx = blockIdx.x * 256L + threadIdx.x;
     const long total = a.P * a.Cout;
-    if (idx < total) {
+    const long base = (long)blockIdx.x * (256 * PW_IT);
+    const bool fixed_co = (256 % a.Cout) == 0;
+    float rs = 0.f, rq = 0.f;
+    int co_last = 0;
+    const float relu_lo = a.pro_relu ? 0.f : -__builtin_inff();
+    for (int it = 0; it < PW_IT; ++it) {
+        const long idx = base + it * 256 + threadIdx.x;
+        if (idx >= total) break;
         const long p = idx / a.Cout; const int co = (int)(idx - p * a.Cout);
         const T* xr = (const T*)a.x + p * a.ldx;
         const T* wr = (const T*)a.w + (long)co * a.Cin;
         float acc = 0.f;
         if (a.ps != nullptr) {
             for (int c = 0; c < a.Cin; ++c) {
-                float v = fmaf(Elem<T>::load(xr + c), a.ps[c], a.psh[c]);
-                if (a.pro_relu) v = fmaxf(v, 0.f);
+                float v = fmaxf(fmaf(Elem<T>::load(xr + c), a.ps[c], a.psh[c]), relu_lo);
                 acc = fmaf(v, Elem<T>::load(wr + c), acc);
             }
         } else {
             for (int c = 0; c < a.Cin; ++c) acc = fmaf(Elem<T>::load(xr + c), Elem<T>::load(wr + c), acc);
         }
-        if (stats) { atomicAdd(&s_sum[co], acc); atomicAdd(&s_sq[co], acc * acc); }
+        if (stats) {
+            if (fixed_co) { rs += acc; rq = fmaf(acc, acc, rq); co_last = co; }
+            else { atomicAdd(&s_sum[co], acc); atomicAdd(&s_sq[co], acc * acc); }
+        }
         Elem<T>::store((T*)a.y + p * a.ldy + co, acc + (a.bias ? a.bias[co] : 0.f));
     }
     if (stats) {
+        if (fixed_co) { atomicAdd(&s_sum[co_last], rs); atomicAdd(&s_sq[co_last], rq); }
         __syncthreads();
         if (threadIdx.x < a.Cout) {
             atomicAdd(&a.ssum[threadIdx.x], (double)s_sum[threadIdx.x]);
@@ -131,27 +147,29 @@ template <typename T, int WPT> __global__ __launch_bounds__(256) void pointwise_
         if (wco[k] >= 0) atomicAdd(a.dw + wco[k] * a.sM + wci[k] * a.sN, acc[k]);
 }
 
-// out[c] += sum_p x[p][c]  (float64 atomics)
+// out[c] += sum_p x[p][c]: per-thread float partials (flushed to double every 128 rows), one LDS double
+// atomic per thread, one global double atomic per channel per block
 template <typename T> __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ x, long P, int C, int ld,
                                                                                 long rows_per_block, double* __restrict__ out)
 {
-    // thread -> channel (tid % Cw) and row lane (tid / Cw); works for any C <= 1024 by looping channel groups
+    extern __shared__ double s_red[];
+    for (int i = threadIdx.x; i < C; i += 256) s_red[i] = 0.0;
+    __syncthreads();
     const long p0 = blockIdx.x * rows_per_block, p1 = min(p0 + rows_per_block, P);
     for (int cb = 0; cb < C; cb += 256) {
         const int cw = min(256, C - cb);
-        const int rl = 256 / cw;          // row lanes
+        const int rl = 256 / cw;
         const int c = threadIdx.x % cw, r0 = threadIdx.x / cw;
-        double s = 0.0;
-        if (r0 < rl) {
-            float fs = 0.f; int cnt = 0;
-            for (long p = p0 + r0; p < p1; p += rl) {
-                fs += Elem<T>::load(x + p * ld + cb + c);
-                if (++cnt == 256) { s += fs; fs = 0.f; cnt = 0; }
-            }
-            s += fs;
-            atomicAdd(&out[cb + c], s);
+        if (r0 >= rl) continue;
+        double s = 0.0; float fs = 0.f; int cnt = 0;
+        for (long p = p0 + r0; p < p1; p += rl) {
+            fs += Elem<T>::load(x + p * ld + cb + c);
+            if (++cnt == 128) { s += fs; fs = 0.f; cnt = 0; }
         }
+        atomicAdd(&s_red[cb + c], s + (double)fs);
     }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(&out[c], s_red[c]);
 }
 
 static bool is_pointwise(const saunet_conv_desc* d)
@@ -200,12 +218,15 @@ int saunet_conv2d_forward(const saunet_conv_desc* d, const void* x, const void* 
         if (ho != d->Ho || wo != d->Wo) return set_error(SAUNET_BAD_SHAPE, "conv: Ho/Wo %dx%d != %dx%d", d->Ho, d->Wo, ho, wo);
     }
     if ((ps == nullptr) != (psh == nullptr)) return set_error(SAUNET_BAD_SHAPE, "conv: prologue needs scale and shift");
-    if (igemm_supported(d)) return igemm_forward(d, x, w, bias, ps, psh, y, ssum, ssq, st);
+    if (igemm_supported(d)) {
+        if (tile_fwd_supported(d)) return tile_forward(d, x, w, bias, ps, psh, y, ssum, ssq, st);
+        return igemm_forward(d, x, w, bias, ps, psh, y, ssum, ssq, st);
+    }
     if (!is_pointwise(d)) return set_error(SAUNET_UNSUPPORTED, "conv: %dx%d s%d Cin=%d Cout=%d has no kernel", d->KH, d->KW, d->stride, d->Cin, d->Cout);
     if (ssum != nullptr && d->Cout > 64) return set_error(SAUNET_UNSUPPORTED, "pointwise stats need Cout <= 64");
     PwArgs a{x, w, y, bias, ps, psh, ssum, ssq, (long)d->N * d->H * d->W, d->Cin, d->Cout, d->ldx, d->ldy, d->pro_relu};
     long total = a.P * a.Cout;
-    dim3 grid((unsigned)((total + 255) / 256));
+    dim3 grid((unsigned)((total + 256 * PW_IT - 1) / (256 * PW_IT)));
     if (d->dtype == SAUNET_F32) hipLaunchKernelGGL(pointwise_fwd_kernel<float>, grid, dim3(256), 0, st, a);
     else if (d->dtype == SAUNET_BF16) hipLaunchKernelGGL(pointwise_fwd_kernel<u16>, grid, dim3(256), 0, st, a);
     else return set_error(SAUNET_BAD_DTYPE, "conv: dtype %d", d->dtype);
@@ -243,11 +264,13 @@ int saunet_conv2d_wgrad(const saunet_conv_desc* d, const void* x, const void* dy
 int saunet_channel_sum(int dtype, const void* x, int64_t pixels, int C, int ld, double* out, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    long blocks = (pixels + 511) / 512; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    long blocks = (pixels * C + 8191) / 8192; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
     long rpb = (pixels + blocks - 1) / blocks;
     blocks = (pixels + rpb - 1) / rpb;
-    if (dtype == SAUNET_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (long)pixels, C, ld, rpb, out);
-    else if (dtype == SAUNET_BF16) hipLaunchKernelGGL(channel_sum_kernel<u16>, dim3((unsigned)blocks), dim3(256), 0, st, (const u16*)x, (long)pixels, C, ld, rpb, out);
+    const size_t lds = sizeof(double) * C;
+    if (C > 4096) return set_error(SAUNET_UNSUPPORTED, "channel_sum: C=%d", C);
+    if (dtype == SAUNET_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, st, (const float*)x, (long)pixels, C, ld, rpb, out);
+    else if (dtype == SAUNET_BF16) hipLaunchKernelGGL(channel_sum_kernel<u16>, dim3((unsigned)blocks), dim3(256), lds, st, (const u16*)x, (long)pixels, C, ld, rpb, out);
     else return set_error(SAUNET_BAD_DTYPE, "channel_sum: dtype %d", dtype);
     SAUNET_CHECK_LAUNCH("channel_sum");
     return SAUNET_OK;

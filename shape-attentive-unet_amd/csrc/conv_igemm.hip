@@ -97,38 +97,53 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_igemm_fwd_ker
     u32x4 areg[A_PER_T], breg[B_ITERS];
     const int nk = taps * a.kpt;
 
+    const float relu_lo = a.pro_relu ? 0.f : -__builtin_inff();
+    // Loads are UNCONDITIONAL (out-of-range pieces read a safe in-bounds address and are zeroed by a select):
+    // a branch around each load would make the compiler wait for every load separately.
     auto load_tile = [&](int tap, int cstep) {
         const int kh = tap / a.KW, kw = tap - kh * a.KW;
         const int c = cstep * KC + chunk * EPC;
         const bool cok = c < a.Cin;
+        const int cs = cok ? c : 0;
+        bool okv[A_PER_T];
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) {
             int ih = rih[i] + sgn * kh, iw = riw[i] + sgn * kw;
-            bool ok = cok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) v = *(const u32x4*)(xg + ((size_t)(rbase[i] + ih * a.W + iw) * a.ldx + c));
-            areg[i] = v;
-            if (has_pro && ok) {
-                float f[EPC];
-                Vec16<T>::unpack(v, f);
-#pragma unroll
-                for (int j = 0; j < EPC; ++j) {
-                    float t = fmaf(f[j], a.pro_scale[c + j], a.pro_shift[c + j]);
-                    f[j] = a.pro_relu ? fmaxf(t, 0.f) : t;
-                }
-                areg[i] = Vec16<T>::pack(f);
-            }
+            okv[i] = cok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            size_t off = okv[i] ? ((size_t)(rbase[i] + ih * a.W + iw) * a.ldx + cs) : (size_t)0;
+            areg[i] = *(const u32x4*)(xg + off);
         }
 #pragma unroll
         for (int i = 0; i < B_ITERS; ++i) {
             int p = tid + i * NT;
             int brow = p / CPR, bch = p % CPR;
             int cb = cstep * KC + bch * EPC;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (p < BN * CPR && n0 + brow < a.Cout && cb < a.Cin)
-                v = *(const u32x4*)(wg + ((size_t)(n0 + brow) * taps + tap) * a.Cin + cb);
-            breg[i] = v;
+            bool ok = (B_ITERS * NT == BN * CPR || p < BN * CPR) && n0 + brow < a.Cout && cb < a.Cin;
+            size_t off = ok ? (((size_t)(n0 + brow) * taps + tap) * a.Cin + cb) : (size_t)0;
+            u32x4 v = *(const u32x4*)(wg + off);
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            breg[i] = ok ? v : z;
         }
+        if (has_pro) {
+            float sc[EPC], sh[EPC];
+#pragma unroll
+            for (int j = 0; j < EPC; j += 4) {
+                f32x4 s4 = *(const f32x4*)(a.pro_scale + cs + j), t4 = *(const f32x4*)(a.pro_shift + cs + j);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { sc[j + q] = s4[q]; sh[j + q] = t4[q]; }
+            }
+#pragma unroll
+            for (int i = 0; i < A_PER_T; ++i) {
+                float f[EPC];
+                Vec16<T>::unpack(areg[i], f);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) f[j] = fmaxf(fmaf(f[j], sc[j], sh[j]), relu_lo);
+                areg[i] = Vec16<T>::pack(f);
+            }
+        }
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < A_PER_T; ++i) areg[i] = okv[i] ? areg[i] : z;
     };
     auto store_tile = [&](int buf) {
         unsigned char* sa = smem + buf * STAGE;
@@ -348,40 +363,47 @@ __global__ __launch_bounds__(256) void conv_igemm_wgrad_kernel(WgradArgs a)
     constexpr int PM = (KP * CM + 255) / 256, PN = (KP * CN + 255) / 256;
     u32x4 mreg[PM], nreg[PN];
 
+    const float relu_lo = a.pro_relu ? 0.f : -__builtin_inff();
     auto load_tile = [&](int p0) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < PM; ++i) {
             int q = tid + i * 256, row = q / CM, ch = q - row * CM;
             int p = p0 + row, c = mch0 + ch * EPC;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (q < KP * CM && p < p_end && c < a.Cout) v = *(const u32x4*)(dyg + (size_t)p * a.lddy + c);
-            mreg[i] = v;
+            bool ok = (PM * 256 == KP * CM || q < KP * CM) && p < p_end && c < a.Cout;
+            u32x4 v = *(const u32x4*)(dyg + (ok ? ((size_t)p * a.lddy + c) : (size_t)0));
+            mreg[i] = ok ? v : z;
         }
+        bool okn[PN]; int cn[PN];
 #pragma unroll
         for (int i = 0; i < PN; ++i) {
             int q = tid + i * 256, row = q / CN, ch = q - row * CN;
             int p = p0 + row, c = nch0 + ch * EPC;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (q < KP * CN && p < p_end && c < a.Cin) {
-                unsigned int n = a.dHoWo.div(p), rem = p - n * (a.Ho * a.Wo);
-                unsigned int oh = a.dWo.div(rem), ow = rem - oh * a.Wo;
-                int ih = (int)oh * a.stride - a.pad + kh, iw = (int)ow * a.stride - a.pad + kw;
-                if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W) {
-                    v = *(const u32x4*)(xg + ((size_t)(n * a.H + ih) * a.W + iw) * a.ldx + c);
-                    if (has_pro) {
-                        float f[EPC];
-                        Vec16<T>::unpack(v, f);
-#pragma unroll
-                        for (int j = 0; j < EPC; ++j) {
-                            float t = fmaf(f[j], a.pro_scale[c + j], a.pro_shift[c + j]);
-                            f[j] = a.pro_relu ? fmaxf(t, 0.f) : t;
-                        }
-                        v = Vec16<T>::pack(f);
-                    }
-                }
-            }
-            nreg[i] = v;
+            bool ok = (PN * 256 == KP * CN || q < KP * CN) && p < p_end && c < a.Cin;
+            unsigned int pp = ok ? (unsigned)p : 0u;
+            unsigned int n = a.dHoWo.div(pp), rem = pp - n * (a.Ho * a.Wo);
+            unsigned int oh = a.dWo.div(rem), ow = rem - oh * a.Wo;
+            int ih = (int)oh * a.stride - a.pad + kh, iw = (int)ow * a.stride - a.pad + kw;
+            ok = ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            okn[i] = ok; cn[i] = ok ? c : 0;
+            nreg[i] = *(const u32x4*)(xg + (ok ? (((size_t)(n * a.H + ih) * a.W + iw) * a.ldx + c) : (size_t)0));
         }
+        if (has_pro) {
+#pragma unroll
+            for (int i = 0; i < PN; ++i) {
+                float f[EPC];
+                Vec16<T>::unpack(nreg[i], f);
+#pragma unroll
+                for (int j = 0; j < EPC; j += 4) {
+                    f32x4 s4 = *(const f32x4*)(a.pro_scale + cn[i] + j), t4 = *(const f32x4*)(a.pro_shift + cn[i] + j);
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) f[j + qq] = fmaxf(fmaf(f[j + qq], s4[qq], t4[qq]), relu_lo);
+                }
+                nreg[i] = Vec16<T>::pack(f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PN; ++i) nreg[i] = okn[i] ? nreg[i] : z;
     };
     auto store_tile = [&](int buf) {
         unsigned char* sm = smem + buf * STAGE;

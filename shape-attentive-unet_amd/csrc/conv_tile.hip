@@ -1,0 +1,283 @@
+// 3x3 (stride 1, pad 1) and 1x1 convolution kernels built around a 16x16-pixel output tile whose input
+// (with its 1-pixel halo) lives in LDS for the whole K loop:
+//
+//  * conv3x3_tile_fwd_kernel   forward / dgrad:  every input element is read from HBM/L2, BatchNorm+ReLU
+//    transformed and written to LDS ONCE per block and then feeds all 9 taps straight out of LDS (the
+//    generic kernel in conv_igemm.hip gathers and transforms it 9 times).
+//  * conv_tile_wgrad_kernel    weight gradient:  dy tile + x halo tile staged [pixel][channel] (their natural
+//    NHWC layout, coalesced loads); the MFMA K dimension is the PIXEL index, so fragments are fetched with the
+//    gfx950 transposing LDS read ds_read_b64_tr_b16 (4 consecutive pixels of 16 channels per 16-lane group);
+//    all 9 taps are accumulated by the same block from one staged halo.
+//
+// MFMA: mfma_f32_32x32x16_bf16 (bf16 storage) / mfma_f32_32x32x2_f32 (float32 storage, exact f32).
+#include "common.h"
+
+namespace saunet {
+
+struct TileArgs {
+    const void* x; const void* w; void* y;
+    const float* bias; const float* pro_scale; const float* pro_shift;
+    double* stat_sum; double* stat_sumsq;
+    int N, H, W, Cin, ldx, Cout, ldy;
+    int pro_relu;
+    int tiles_x, tiles_y;   // H/16, W/16
+};
+
+template <typename T> struct MmaT;
+template <> struct MmaT<u16> {
+    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c)
+    {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct MmaT<float> {
+    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c)
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+    }
+};
+
+template <int CPR> __device__ __forceinline__ int swz_off(int r, int c)
+{
+    constexpr int RPB = 16 / CPR;
+    return (r * CPR + (c ^ ((r / RPB) & (CPR - 1)))) * 16;
+}
+
+constexpr int TILE = 16, HPITCH = 18, NPIX = HPITCH * HPITCH;
+
+template <typename T, int BN, int WM, int WN, int CPR>
+__global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_tile_fwd_kernel(TileArgs a)
+{
+    constexpr int NT = (256 / WM) * (BN / WN) * 64;
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int KC = CPR * EPC;
+    constexpr int HALO_BYTES = NPIX * CPR * 16;
+    constexpr int WB_BYTES = BN * CPR * 16;
+    constexpr int H_ITERS = (NPIX * CPR + NT - 1) / NT;
+    constexpr int B_ITERS = (BN * CPR + NT - 1) / NT;
+    constexpr int TI = WM / 32, TJ = WN / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* s_halo = smem;
+    unsigned char* s_w = smem + HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
+    int bt = blockIdx.x;
+    const int txi = bt % a.tiles_x; bt /= a.tiles_x;
+    const int tyi = bt % a.tiles_y; const int n = bt / a.tiles_y;
+    const int ty0 = tyi * TILE, tx0 = txi * TILE;
+    const int n0 = blockIdx.y * BN;
+    const T* __restrict__ xg = (const T*)a.x + (size_t)n * a.H * a.W * a.ldx;
+    const T* __restrict__ wg = (const T*)a.w;
+    const bool has_pro = a.pro_scale != nullptr;
+    const float relu_lo = a.pro_relu ? 0.f : -__builtin_inff();
+    const int ncb = (a.Cin + KC - 1) / KC;
+
+    // per-thread halo pieces: (pixel, chunk) -> global offset (without channel block) and validity
+    int hoff[H_ITERS]; int hlds[H_ITERS]; int hchunk[H_ITERS]; bool hok[H_ITERS];
+#pragma unroll
+    for (int i = 0; i < H_ITERS; ++i) {
+        int q = tid + i * NT;
+        int pix = q / CPR, ch = q % CPR;
+        int hy = pix / HPITCH, hx = pix - hy * HPITCH;
+        int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+        bool ok = q < NPIX * CPR && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        hok[i] = ok;
+        hoff[i] = ok ? (iy * a.W + ix) * a.ldx : 0;
+        hlds[i] = (q < NPIX * CPR) ? swz_off<CPR>(pix, ch) : -1;
+        hchunk[i] = ch * EPC;
+    }
+    // A-fragment rows of this lane
+    int pbase[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        int row = wm0 + i * 32 + lr;
+        pbase[i] = (row >> 4) * HPITCH + (row & 15);
+    }
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 breg[B_ITERS];
+    auto load_w = [&](int cb, int tap) {
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            int p = tid + i * NT;
+            int brow = p / CPR, bch = p % CPR;
+            int c = cb * KC + bch * EPC;
+            bool ok = (B_ITERS * NT == BN * CPR || p < BN * CPR) && n0 + brow < a.Cout && c < a.Cin;
+            size_t off = ok ? (((size_t)(n0 + brow) * 9 + tap) * a.Cin + c) : (size_t)0;
+            u32x4 v = *(const u32x4*)(wg + off);
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            breg[i] = ok ? v : z;
+        }
+    };
+    auto store_w = [&](int buf) {
+        unsigned char* sb = s_w + buf * WB_BYTES;
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            int p = tid + i * NT;
+            if (B_ITERS * NT == BN * CPR || p < BN * CPR) *(u32x4*)(sb + swz_off<CPR>(p / CPR, p % CPR)) = breg[i];
+        }
+    };
+
+    int wbuf = 0;
+    load_w(0, 0);
+    for (int cb = 0; cb < ncb; ++cb) {
+        // ---- stage the (transformed) halo of this channel block; previous readers are done (barrier at loop end)
+        {
+            u32x4 hreg[H_ITERS];
+            const int c0 = cb * KC;
+#pragma unroll
+            for (int i = 0; i < H_ITERS; ++i) {
+                bool ok = hok[i] && (c0 + hchunk[i]) < a.Cin;
+                hreg[i] = *(const u32x4*)(xg + (ok ? (size_t)hoff[i] + c0 + hchunk[i] : (size_t)0));
+            }
+            if (has_pro) {
+#pragma unroll
+                for (int i = 0; i < H_ITERS; ++i) {
+                    int c = c0 + hchunk[i];
+                    c = c < a.Cin ? c : 0;
+                    float f[EPC];
+                    Vec16<T>::unpack(hreg[i], f);
+#pragma unroll
+                    for (int j = 0; j < EPC; j += 4) {
+                        f32x4 s4 = *(const f32x4*)(a.pro_scale + c + j), t4 = *(const f32x4*)(a.pro_shift + c + j);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) f[j + q] = fmaxf(fmaf(f[j + q], s4[q], t4[q]), relu_lo);
+                    }
+                    hreg[i] = Vec16<T>::pack(f);
+                }
+            }
+            const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < H_ITERS; ++i) {
+                bool ok = hok[i] && (c0 + hchunk[i]) < a.Cin;
+                if (hlds[i] >= 0) *(u32x4*)(s_halo + hlds[i]) = ok ? hreg[i] : z;
+            }
+        }
+        store_w(wbuf);
+        __syncthreads();
+        for (int tap = 0; tap < 9; ++tap) {
+            // prefetch the next weight tile (next tap, or tap 0 of the next channel block)
+            const bool more = (tap + 1 < 9) || (cb + 1 < ncb);
+            if (more) load_w(tap + 1 < 9 ? cb : cb + 1, tap + 1 < 9 ? tap + 1 : 0);
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const unsigned char* sb = s_w + wbuf * WB_BYTES;
+            int apix[TI];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) apix[i] = pbase[i] + kh * HPITCH + kw;
+#pragma unroll
+            for (int s = 0; s < CPR / 2; ++s) {
+                u32x4 af[TI], bfr[TJ];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) af[i] = *(const u32x4*)(s_halo + swz_off<CPR>(apix[i], 2 * s + lh));
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) bfr[j] = *(const u32x4*)(sb + swz_off<CPR>(wn0 + j * 32 + lr, 2 * s + lh));
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) MmaT<T>::run(af[i], bfr[j], acc[i][j]);
+            }
+            if (more && tap + 1 < 9) store_w(wbuf ^ 1);   // the next cb's tap-0 tile is stored after its halo
+            __syncthreads();
+            if (tap + 1 < 9) wbuf ^= 1;
+        }
+        wbuf ^= 1;
+    }
+
+    // ---- epilogue (same scheme as the generic kernel)
+    float* s_sum = (float*)(smem + 256 * BN * sizeof(T));
+    float* s_sq = s_sum + BN;
+    const bool do_stats = a.stat_sum != nullptr;
+    if (do_stats) for (int i = tid; i < 2 * BN; i += NT) s_sum[i] = 0.f;
+    __syncthreads();
+    T* so = (T*)smem;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int col = wn0 + j * 32 + lr;
+        const float bv = (a.bias != nullptr && n0 + col < a.Cout) ? a.bias[n0 + col] : 0.f;
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r];
+                s += v; ss += v * v;
+                int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                Elem<T>::store(so + row * BN + col, v + bv);
+            }
+        if (do_stats) {
+            s += __shfl_xor(s, 32, 64); ss += __shfl_xor(ss, 32, 64);
+            if (lh == 0) { atomicAdd(&s_sum[col], s); atomicAdd(&s_sq[col], ss); }
+        }
+    }
+    __syncthreads();
+    if (do_stats && tid < BN && n0 + tid < a.Cout) {
+        atomicAdd(&a.stat_sum[n0 + tid], (double)s_sum[tid]);
+        atomicAdd(&a.stat_sumsq[n0 + tid], (double)s_sq[tid]);
+    }
+    constexpr int CH = BN / EPC;
+    T* __restrict__ yg = (T*)a.y + (size_t)n * a.H * a.W * a.ldy;
+    for (int p = tid; p < 256 * CH; p += NT) {
+        int row = p / CH, ch = p - row * CH;
+        int col = n0 + ch * EPC;
+        if (col < a.Cout) {
+            size_t opix = (size_t)(ty0 + (row >> 4)) * a.W + tx0 + (row & 15);
+            *(u32x4*)(yg + opix * a.ldy + col) = *(const u32x4*)(so + row * BN + ch * EPC);
+        }
+    }
+}
+
+template <typename T, int BN, int WM, int WN, int CPR> static int launch_tile_fwd(const TileArgs& a, hipStream_t st)
+{
+    constexpr int NT = (256 / WM) * (BN / WN) * 64;
+    constexpr int MAIN = NPIX * CPR * 16 + 2 * BN * CPR * 16;
+    constexpr int EPI = 256 * BN * (int)sizeof(T) + 2 * BN * 4;
+    constexpr int LDS = MAIN > EPI ? MAIN : EPI;
+    auto kern = conv3x3_tile_fwd_kernel<T, BN, WM, WN, CPR>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    dim3 grid(a.tiles_x * a.tiles_y * a.N, cdiv(a.Cout, BN));
+    hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, st, a);
+    SAUNET_CHECK_LAUNCH("conv3x3_tile_fwd");
+    return SAUNET_OK;
+}
+
+template <typename T> static int dispatch_tile_fwd(const TileArgs& a, hipStream_t st)
+{
+    constexpr int EPC = 16 / sizeof(T);
+    const bool narrow = a.Cin <= 4 * EPC;
+    if (a.Cout <= 32) return narrow ? launch_tile_fwd<T, 32, 64, 32, 4>(a, st) : launch_tile_fwd<T, 32, 64, 32, 8>(a, st);
+    if (a.Cout <= 64) return narrow ? launch_tile_fwd<T, 64, 64, 64, 4>(a, st) : launch_tile_fwd<T, 64, 64, 64, 8>(a, st);
+    return narrow ? launch_tile_fwd<T, 128, 128, 64, 4>(a, st) : launch_tile_fwd<T, 128, 128, 64, 8>(a, st);
+}
+
+bool tile_fwd_supported(const saunet_conv_desc* d)
+{
+    return !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->H % TILE == 0 && d->W % TILE == 0 &&
+           d->Ho == d->H && d->Wo == d->W;
+}
+
+int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps, const float* psh,
+                 void* y, double* ssum, double* ssq, hipStream_t st)
+{
+    TileArgs a;
+    a.x = x; a.w = w; a.y = y; a.bias = bias; a.pro_scale = ps; a.pro_shift = psh; a.stat_sum = ssum; a.stat_sumsq = ssq;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Cout = d->Cout; a.ldy = d->ldy;
+    a.pro_relu = d->pro_relu; a.tiles_y = d->H / TILE; a.tiles_x = d->W / TILE;
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return set_error(SAUNET_BAD_ALIGN, "conv: pointers must be 16-byte aligned");
+    if (d->dtype == SAUNET_BF16) return dispatch_tile_fwd<u16>(a, st);
+    if (d->dtype == SAUNET_F32) return dispatch_tile_fwd<float>(a, st);
+    return set_error(SAUNET_BAD_DTYPE, "conv: dtype %d", d->dtype);
+}
+
+}  // namespace saunet

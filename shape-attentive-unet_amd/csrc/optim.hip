@@ -66,7 +66,7 @@ extern "C" {
 int saunet_sgd_step(const saunet_tensor_list* tl, const float* hyper, void* stream)
 {
     if (tl->count <= 0 || tl->count > 96) return set_error(SAUNET_BAD_SHAPE, "sgd: %d tensors", tl->count);
-    hipLaunchKernelGGL(sgd_kernel, dim3(32, tl->count), dim3(256), 0, (hipStream_t)stream, *tl, hyper);
+    hipLaunchKernelGGL(sgd_kernel, dim3(128, tl->count), dim3(256), 0, (hipStream_t)stream, *tl, hyper);
     SAUNET_CHECK_LAUNCH("sgd_step");
     return SAUNET_OK;
 }
@@ -74,7 +74,7 @@ int saunet_sgd_step(const saunet_tensor_list* tl, const float* hyper, void* stre
 int saunet_radam_step(const saunet_tensor_list* tl, const float* hyper, void* stream)
 {
     if (tl->count <= 0 || tl->count > 96) return set_error(SAUNET_BAD_SHAPE, "radam: %d tensors", tl->count);
-    hipLaunchKernelGGL(radam_kernel, dim3(32, tl->count), dim3(256), 0, (hipStream_t)stream, *tl, hyper);
+    hipLaunchKernelGGL(radam_kernel, dim3(128, tl->count), dim3(256), 0, (hipStream_t)stream, *tl, hyper);
     SAUNET_CHECK_LAUNCH("radam_step");
     return SAUNET_OK;
 }
@@ -82,7 +82,7 @@ int saunet_radam_step(const saunet_tensor_list* tl, const float* hyper, void* st
 int saunet_bucket_copy(const saunet_tensor_list* tl, int pack, float scale, void* stream)
 {
     if (tl->count <= 0 || tl->count > 96) return set_error(SAUNET_BAD_SHAPE, "bucket_copy: %d tensors", tl->count);
-    hipLaunchKernelGGL(bucket_copy_kernel, dim3(32, tl->count), dim3(256), 0, (hipStream_t)stream, *tl, pack, scale);
+    hipLaunchKernelGGL(bucket_copy_kernel, dim3(128, tl->count), dim3(256), 0, (hipStream_t)stream, *tl, pack, scale);
     SAUNET_CHECK_LAUNCH("bucket_copy");
     return SAUNET_OK;
 }

@@ -315,7 +315,11 @@ class _ConvBNAct(torch.autograd.Function):
                                               sync_group=group)
         dx = conv_dgrad_raw(dz, weight, x.shape, stride, pad, transposed) if ctx.needs_input_grad[0] else None
         dw = conv_wgrad_raw(x, dz, weight, stride, pad, transposed)
-        db = channel_sum(dz) if has_bias else None
+        db = None
+        if has_bias:
+            # a bias in front of a training-mode BatchNorm has an exactly zero gradient (sum of dz over the batch is 0)
+            cout = dz.shape[1]
+            db = torch.zeros(cout, dtype=torch.float32, device=dz.device) if training else channel_sum(dz)
         return dx, dw, db, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
 
 
