@@ -66,7 +66,12 @@ int saunet_conv2d_forward(const saunet_conv_desc* d, const void* x, const void* 
  * caller (split-K partial sums are added atomically).  replaces autograd's convolution_backward
  * (weight part) behind loss.backward() at train.py:104. */
 int saunet_conv2d_wgrad(const saunet_conv_desc* d, const void* x, const void* dy,
-                        const float* pro_scale, const float* pro_shift, float* dw, void* stream);
+                        const float* pro_scale, const float* pro_shift, float* dw,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+/* bytes of caller-owned scratch saunet_conv2d_wgrad needs for this shape (0 = none; <0 = saunet_status).
+ * The tiled kernels write per-block partial gradients there with plain stores and reduce them afterwards
+ * (cross-XCD float atomics on the same addresses are ~10x more expensive than the stores + one reduce pass). */
+int64_t saunet_conv2d_wgrad_workspace(const saunet_conv_desc* d);
 /* db[c] = sum_pixels dy[:,c]  (float64 atomics into a zeroed buffer, then cast by the caller) */
 int saunet_channel_sum(int dtype, const void* dy, int64_t pixels, int C, int ld, double* out, void* stream);
 

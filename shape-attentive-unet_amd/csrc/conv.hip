@@ -16,6 +16,9 @@ int igemm_forward(const saunet_conv_desc* d, const void* x, const void* w, const
                   void* y, double* ssum, double* ssq, hipStream_t st);
 int igemm_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw, hipStream_t st);
 bool tile_fwd_supported(const saunet_conv_desc* d);
+bool tile_wgrad_supported(const saunet_conv_desc* d);
+int tile_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw,
+               void* ws, size_t ws_bytes, size_t* need, hipStream_t st);
 int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps, const float* psh,
                  void* y, double* ssum, double* ssq, hipStream_t st);
 
@@ -234,10 +237,24 @@ int saunet_conv2d_forward(const saunet_conv_desc* d, const void* x, const void* 
     return SAUNET_OK;
 }
 
-int saunet_conv2d_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw, void* stream)
+int64_t saunet_conv2d_wgrad_workspace(const saunet_conv_desc* d)
+{
+    if (igemm_supported(d) && tile_wgrad_supported(d)) {
+        size_t need = 0;
+        int rc = tile_wgrad(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &need, nullptr);
+        return rc == SAUNET_OK ? (int64_t)need : (int64_t)rc;
+    }
+    return 0;
+}
+
+int saunet_conv2d_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw,
+                        void* workspace, int64_t workspace_bytes, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (igemm_supported(d)) return igemm_wgrad(d, x, dy, ps, psh, dw, st);
+    if (igemm_supported(d)) {
+        if (tile_wgrad_supported(d)) return tile_wgrad(d, x, dy, ps, psh, dw, workspace, (size_t)workspace_bytes, nullptr, st);
+        return igemm_wgrad(d, x, dy, ps, psh, dw, st);
+    }
     if (!is_pointwise(d)) return set_error(SAUNET_UNSUPPORTED, "wgrad: %dx%d Cin=%d Cout=%d has no kernel", d->KH, d->KW, d->Cin, d->Cout);
     const int nW = d->Cin * d->Cout;
     PwWgradArgs a{x, dy, dw, ps, psh, (long)d->N * d->H * d->W, d->Cin, d->Cout, d->ldx, d->ldy, d->pro_relu, 0, (long)d->Cin, 1, 32};

@@ -280,4 +280,300 @@ int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const 
     return set_error(SAUNET_BAD_DTYPE, "conv: dtype %d", d->dtype);
 }
 
+// =====================================================================================================
+// wgrad on pixel tiles: dW[co][ci][tap] += sum_{pixels of the tile} dy[p][co] * a[p (+) tap][ci]
+struct TileWgradArgs {
+    const void* x; const void* dy; float* dw;
+    const float* pro_scale; const float* pro_shift;
+    int N, H, W, Cin, ldx, Cout, lddy, pro_relu;
+    int tiles_x, tiles_y, ntiles, ncit;   // tiles per row / column, total, number of ci tiles
+    long sM, sN;
+    float* ws; long wsize;                 // per-group partial gradients [groups][wsize] (plain stores, reduced afterwards)
+};
+
+// one ds_read_b64_tr_b16: every 16-lane group reads a [4 rows][16 cols] block of 16-bit elements (each lane
+// supplies the address of 4 consecutive elements of one row) and receives one COLUMN (4 consecutive rows).
+// Two of them (rows r..r+3 and r+4..r+7) make one 8-deep MFMA operand fragment.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+__device__ __forceinline__ void tr_read2(const unsigned char* p0, int pitch4, u32x4& out)
+{
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + pitch4));
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+    out[0] = a[0]; out[1] = a[1]; out[2] = b[0]; out[3] = b[1];
+}
+
+template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KSPLIT>
+__global__ __launch_bounds__(256, 2) void conv_tile_wgrad_kernel(TileWgradArgs a)
+{
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int PAD = KS / 2;
+    constexpr int HR = TR + 2 * PAD, HC = TILE + 2 * PAD;          // halo rows / cols
+    constexpr int NPX = HR * HC, NPY = TR * TILE;
+    // row pitch: a multiple of 16 bytes that is == 64 (mod 128) so the 4 rows of a transposing read (and the two
+    // 16-lane groups that issue together) fall on disjoint banks
+    constexpr int PY_RAW = CO_T * (int)sizeof(T), PX_RAW = CI_T * (int)sizeof(T);
+    constexpr int PY = sizeof(T) == 2 ? ((PY_RAW % 128 == 64) ? PY_RAW : PY_RAW + 64) : PY_RAW;
+    constexpr int PX = sizeof(T) == 2 ? ((PX_RAW % 128 == 64) ? PX_RAW : PX_RAW + 64) : PX_RAW;
+    constexpr int MI = WM / 32, NI = WN / 32, TAPS = KS * KS;
+    constexpr int CHY = CO_T / EPC, CHX = CI_T / EPC;
+    constexpr int YI = (NPY * CHY + 255) / 256, XI = (NPX * CHX + 255) / 256;
+    constexpr int XB = XI > 6 ? (XI + 1) / 2 : XI;   // stage the halo in two batches when it is large (VGPR budget)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* s_y = smem;
+    unsigned char* s_x = smem + NPY * PY;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    static_assert((CO_T / WM) * (CI_T / WN) * KSPLIT == 4, "4 waves per block");
+    constexpr int CWAVES = (CO_T / WM) * (CI_T / WN);
+    const int cwave = wave % CWAVES, kwave = wave / CWAVES;       // channel sub-tile / K (tile row) slice of this wave
+    const int wm0 = (cwave / (CI_T / WN)) * WM, wn0 = (cwave % (CI_T / WN)) * WN;
+    const int cot = blockIdx.y / a.ncit, cit = blockIdx.y - cot * a.ncit;
+    const int co0 = cot * CO_T, ci0 = cit * CI_T;
+    const T* __restrict__ xg = (const T*)a.x;
+    const T* __restrict__ dyg = (const T*)a.dy;
+    const bool has_pro = a.pro_scale != nullptr;
+    const float relu_lo = a.pro_relu ? 0.f : -__builtin_inff();
+
+    f32x16 acc[MI][NI][TAPS];
+#pragma unroll
+    for (int m = 0; m < MI; ++m)
+#pragma unroll
+        for (int n = 0; n < NI; ++n)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][t][r] = 0.f;
+
+    const int li = lane & 15, lg = lane >> 4, nhalf = lg & 1, khalf = lg >> 1;
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int bt = tile;
+        const int txi = bt % a.tiles_x; bt /= a.tiles_x;
+        const int tyi = bt % a.tiles_y; const int n = bt / a.tiles_y;
+        const int ty0 = tyi * TR, tx0 = txi * TILE;
+        __syncthreads();   // previous tile fully consumed
+        {
+            u32x4 yreg[YI];
+            const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < YI; ++i) {
+                int q = tid + i * 256, pix = q / CHY, ch = q - pix * CHY;
+                int c = co0 + ch * EPC;
+                bool ok = (YI * 256 == NPY * CHY || q < NPY * CHY) && c < a.Cout;
+                size_t off = ok ? (((size_t)n * a.H + ty0 + pix / TILE) * a.W + tx0 + (pix % TILE)) * a.lddy + c : (size_t)0;
+                u32x4 v = *(const u32x4*)(dyg + off);
+                yreg[i] = ok ? v : z;
+            }
+#pragma unroll
+            for (int i = 0; i < YI; ++i) {
+                int q = tid + i * 256, pix = q / CHY, ch = q - pix * CHY;
+                if (YI * 256 == NPY * CHY || q < NPY * CHY) *(u32x4*)(s_y + pix * PY + ch * 16) = yreg[i];
+            }
+        }
+#pragma unroll
+        for (int b0 = 0; b0 < XI; b0 += XB) {
+            u32x4 xreg[XB]; bool okx[XB]; int cx[XB];
+            const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < XB; ++i) {
+                int q = tid + (b0 + i) * 256, pix = q / CHX, ch = q - pix * CHX;
+                int hy = pix / HC, hx = pix - hy * HC;
+                int iy = ty0 + hy - PAD, ix = tx0 + hx - PAD;
+                int c = ci0 + ch * EPC;
+                bool ok = (b0 + i < XI) && q < NPX * CHX && c < a.Cin && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                okx[i] = ok; cx[i] = ok ? c : 0;
+                xreg[i] = *(const u32x4*)(xg + (ok ? (((size_t)n * a.H + iy) * a.W + ix) * a.ldx + c : (size_t)0));
+            }
+            if (has_pro) {
+#pragma unroll
+                for (int i = 0; i < XB; ++i) {
+                    float f[EPC];
+                    Vec16<T>::unpack(xreg[i], f);
+#pragma unroll
+                    for (int j = 0; j < EPC; j += 4) {
+                        f32x4 s4 = *(const f32x4*)(a.pro_scale + cx[i] + j), t4 = *(const f32x4*)(a.pro_shift + cx[i] + j);
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) f[j + qq] = fmaxf(fmaf(f[j + qq], s4[qq], t4[qq]), relu_lo);
+                    }
+                    xreg[i] = Vec16<T>::pack(f);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < XB; ++i) {
+                int q = tid + (b0 + i) * 256, pix = q / CHX, ch = q - pix * CHX;
+                if ((b0 + i < XI) && q < NPX * CHX) *(u32x4*)(s_x + pix * PX + ch * 16) = okx[i] ? xreg[i] : z;
+            }
+        }
+        __syncthreads();
+        // ---- one MFMA K-step = one tile row (16 pixels)
+        for (int ty = kwave; ty < TR; ty += KSPLIT) {
+            if constexpr (sizeof(T) == 2) {
+                u32x4 af[MI];
+#pragma unroll
+                for (int m = 0; m < MI; ++m) {
+                    const unsigned char* base = s_y + (ty * TILE + 8 * khalf + (li >> 2)) * PY + (wm0 + m * 32 + 16 * nhalf + 4 * (li & 3)) * 2;
+                    tr_read2(base, 4 * PY, af[m]);
+                }
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int kh = t / KS, kw = t - kh * KS;
+#pragma unroll
+                    for (int nn = 0; nn < NI; ++nn) {
+                        u32x4 bf;
+                        const unsigned char* base = s_x + ((ty + kh) * HC + kw + 8 * khalf + (li >> 2)) * PX + (wn0 + nn * 32 + 16 * nhalf + 4 * (li & 3)) * 2;
+                        tr_read2(base, 4 * PX, bf);
+#pragma unroll
+                        for (int m = 0; m < MI; ++m)
+                            acc[m][nn][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[m]), __builtin_bit_cast(bf16x8_t, bf), acc[m][nn][t], 0, 0, 0);
+                    }
+                }
+            } else {
+                const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+                for (int k = 0; k < TILE; k += 2) {
+                    float af[MI];
+#pragma unroll
+                    for (int m = 0; m < MI; ++m) af[m] = *(const float*)(s_y + (ty * TILE + k + lh) * PY + (wm0 + m * 32 + lr) * 4);
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t) {
+                        const int kh = t / KS, kw = t - kh * KS;
+#pragma unroll
+                        for (int nn = 0; nn < NI; ++nn) {
+                            float bv = *(const float*)(s_x + ((ty + kh) * HC + kw + k + lh) * PX + (wn0 + nn * 32 + lr) * 4);
+#pragma unroll
+                            for (int m = 0; m < MI; ++m) acc[m][nn][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bv, acc[m][nn][t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const int lr = lane & 31, lh = lane >> 5;
+    float* s_red = (float*)smem;   // [KSPLIT-1][64 lanes][16] floats per (m, n, tap) round
+#pragma unroll
+    for (int m = 0; m < MI; ++m)
+#pragma unroll
+        for (int nn = 0; nn < NI; ++nn) {
+            const int ci = ci0 + wn0 + nn * 32 + lr;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                if constexpr (KSPLIT > 1) {
+                    __syncthreads();
+                    if (kwave > 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s_red[((kwave - 1) * 16 + r) * 64 + lane] = acc[m][nn][t][r];
+                    }
+                    __syncthreads();
+                    if (kwave == 0) {
+#pragma unroll
+                        for (int k = 0; k < KSPLIT - 1; ++k)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[m][nn][t][r] += s_red[(k * 16 + r) * 64 + lane];
+                    }
+                }
+                if (kwave == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int co = co0 + wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (co < a.Cout && ci < a.Cin) a.ws[(size_t)blockIdx.x * a.wsize + (size_t)co * a.sM + (size_t)ci * a.sN + t] = acc[m][nn][t][r];
+                    }
+                }
+            }
+        }
+}
+
+// dw[i] += sum_g ws[g][i]; blockIdx.y takes a slice of the groups (atomics only between slices)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, long wsize, int groups, int gper, float* __restrict__ dw)
+{
+    const int g0 = blockIdx.y * gper, g1 = min(g0 + gper, groups);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < wsize; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+#pragma unroll 4
+        for (int g = g0; g < g1; ++g) s += ws[(size_t)g * wsize + i];
+        if (gridDim.y == 1) dw[i] += s; else atomicAdd(dw + i, s);
+    }
+}
+
+static int tile_wgrad_groups(int ntiles, int nchan_tiles)
+{
+    int groups = 512 / nchan_tiles; if (groups < 1) groups = 1; if (groups > ntiles) groups = ntiles;
+    return groups;
+}
+
+template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KSPLIT> static int launch_tile_wgrad(TileWgradArgs& a, size_t ws_bytes, size_t* need, hipStream_t st)
+{
+    constexpr int PAD = KS / 2;
+    constexpr int NPX = (TR + 2 * PAD) * (TILE + 2 * PAD), NPY = TR * TILE;
+    constexpr int PY_RAW = CO_T * (int)sizeof(T), PX_RAW = CI_T * (int)sizeof(T);
+    constexpr int PY = sizeof(T) == 2 ? ((PY_RAW % 128 == 64) ? PY_RAW : PY_RAW + 64) : PY_RAW;
+    constexpr int PX = sizeof(T) == 2 ? ((PX_RAW % 128 == 64) ? PX_RAW : PX_RAW + 64) : PX_RAW;
+    constexpr int LDS_MAIN = NPY * PY + NPX * PX;
+    constexpr int LDS_RED = KSPLIT > 1 ? (KSPLIT - 1) * 16 * 64 * 4 : 0;
+    constexpr int LDS = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
+    static_assert(LDS <= 160 * 1024, "tile does not fit LDS");
+    auto kern = conv_tile_wgrad_kernel<T, KS, TR, CO_T, CI_T, WM, WN, KSPLIT>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    a.tiles_y = a.H / TR; a.tiles_x = a.W / TILE; a.ntiles = a.N * a.tiles_y * a.tiles_x;
+    const int ncot = cdiv(a.Cout, CO_T); a.ncit = cdiv(a.Cin, CI_T);
+    const int groups = tile_wgrad_groups(a.ntiles, ncot * a.ncit);
+    a.wsize = (long)a.Cout * a.Cin * KS * KS;
+    const size_t bytes = (size_t)groups * a.wsize * sizeof(float);
+    if (need) { *need = bytes; return SAUNET_OK; }
+    if (a.ws == nullptr || ws_bytes < bytes) return set_error(SAUNET_BAD_SHAPE, "wgrad: workspace %zu < %zu bytes", ws_bytes, bytes);
+    dim3 grid(groups, ncot * a.ncit);
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, a);
+    long rb = (a.wsize + 255) / 256; if (rb > 2048) rb = 2048;
+    int gsl = 1;                       // group slices: enough blocks to fill the chip even for small weight tensors
+    while (rb * gsl < 512 && gsl * 8 < groups) gsl *= 2;
+    const int gper = (groups + gsl - 1) / gsl; gsl = (groups + gper - 1) / gper;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb, gsl), dim3(256), 0, st, a.ws, a.wsize, groups, gper, a.dw);
+    SAUNET_CHECK_LAUNCH("conv_tile_wgrad");
+    return SAUNET_OK;
+}
+
+template <typename T> static int dispatch_tile_wgrad(TileWgradArgs& a, int ks, size_t wsb, size_t* need, hipStream_t st)
+{
+    // few channel tiles -> 32x32 channel tile with the 4 waves splitting the K (pixel-row) dimension: the per-block
+    // partial gradient (what has to be reduced across blocks afterwards) is 4x smaller
+    const bool small = (long)a.Cout * a.Cin <= 64 * 128;
+    if constexpr (sizeof(T) == 2) {
+        if (ks == 3) {
+            if (small) return launch_tile_wgrad<T, 3, 16, 32, 32, 32, 32, 4>(a, wsb, need, st);
+            return launch_tile_wgrad<T, 3, 8, 64, 64, 32, 32, 1>(a, wsb, need, st);
+        }
+        if (small) return launch_tile_wgrad<T, 1, 16, 64, 64, 64, 64, 4>(a, wsb, need, st);
+        return launch_tile_wgrad<T, 1, 8, 128, 128, 64, 64, 1>(a, wsb, need, st);
+    } else {
+        if (ks == 3) {
+            if (small) return launch_tile_wgrad<T, 3, 16, 32, 32, 32, 32, 4>(a, wsb, need, st);
+            return launch_tile_wgrad<T, 3, 8, 64, 64, 32, 32, 1>(a, wsb, need, st);
+        }
+        return launch_tile_wgrad<T, 1, 8, 64, 64, 32, 32, 1>(a, wsb, need, st);
+    }
+}
+
+bool tile_wgrad_supported(const saunet_conv_desc* d)
+{
+    const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1, k1 = d->KH == 1 && d->KW == 1 && d->pad == 0;
+    return !d->transposed && (k3 || k1) && d->stride == 1 && d->H % TILE == 0 && d->W % TILE == 0 && d->Ho == d->H && d->Wo == d->W;
+}
+
+int tile_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw,
+               void* ws, size_t ws_bytes, size_t* need, hipStream_t st)
+{
+    TileWgradArgs a;
+    a.ws = (float*)ws;
+    a.x = x; a.dy = dy; a.dw = dw; a.pro_scale = ps; a.pro_shift = psh; a.pro_relu = d->pro_relu;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Cout = d->Cout; a.lddy = d->ldy;
+    a.sM = (long)d->Cin * d->KH * d->KW; a.sN = (long)d->KH * d->KW;
+    if (!need && (((uintptr_t)x | (uintptr_t)dy) & 15)) return set_error(SAUNET_BAD_ALIGN, "wgrad: pointers must be 16-byte aligned");
+    if (d->dtype == SAUNET_BF16) return dispatch_tile_wgrad<u16>(a, d->KH, ws_bytes, need, st);
+    if (d->dtype == SAUNET_F32) return dispatch_tile_wgrad<float>(a, d->KH, ws_bytes, need, st);
+    return set_error(SAUNET_BAD_DTYPE, "wgrad: dtype %d", d->dtype);
+}
+
 }  // namespace saunet

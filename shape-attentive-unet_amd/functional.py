@@ -161,8 +161,12 @@ def conv_wgrad_raw(x, dy, weight, stride, pad, transposed=False, pro=None):
     else:
         cout, _, kh, kw = weight.shape
     d = _desc(x, cout, ld_of(dy), dy.shape[2], dy.shape[3], kh, kw, stride, pad, transposed, bool(pro and pro[2]))
+    need = L.load().saunet_conv2d_wgrad_workspace(C.byref(d))
+    if need < 0:
+        raise RuntimeError("saunet_conv2d_wgrad_workspace failed (%d)" % need)
+    ws = torch.empty(need // 4, dtype=torch.float32, device=x.device) if need > 0 else None
     L.call("saunet_conv2d_wgrad", C.byref(d), x.data_ptr(), dy.data_ptr(), L.ptr(pro[0]) if pro else None,
-           L.ptr(pro[1]) if pro else None, dw.data_ptr(), L.stream())
+           L.ptr(pro[1]) if pro else None, dw.data_ptr(), L.ptr(ws), need, L.stream())
     return dw
 
 

@@ -30,7 +30,8 @@ _SIGS = {
     "saunet_init": [i32],
     "saunet_pack_weight": [i32, i32, vp, i32, i32, i32, i32, vp, vp],
     "saunet_conv2d_forward": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "saunet_conv2d_wgrad": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp],
+    "saunet_conv2d_wgrad": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i64, vp],
+    "saunet_conv2d_wgrad_workspace": [C.POINTER(ConvDesc)],
     "saunet_channel_sum": [i32, vp, i64, i32, i32, vp, vp],
     "saunet_bn_stats": [i32, vp, i64, i32, i32, vp, vp, vp],
     "saunet_bn_finalize": [i32, vp, vp, f64, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp],
@@ -80,7 +81,7 @@ def load():
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = sig
-        fn.restype = C.c_int
+        fn.restype = C.c_int64 if name.endswith("_workspace") else C.c_int
     _lib = lib
     return lib
 
