@@ -55,6 +55,10 @@ int saunet_init(int device);
  * attention_blocks.py:150-151,179-186,215-220, GSConv.py:40-42,56-57, resnet.py:24-27 and the
  * DenseNet-121 convs of torchvision (models/models.py:271). */
 int saunet_pack_weight(int mode, int dtype, const float* w, int Co, int Ci, int KH, int KW, void* out, void* stream);
+/* the same for up to 64 weights in ONE launch (all packings of a training step are refreshed right after the
+ * optimiser update instead of 300+ tiny launches) */
+typedef struct saunet_pack_list { int32_t count; int32_t mode[64]; int32_t dims[64][4]; const void* src[64]; void* dst[64]; } saunet_pack_list;
+int saunet_pack_weight_multi(const saunet_pack_list* pl, int dtype, void* stream);
 /* y = conv(prologue(x), w) (+bias).  If stat_sum/stat_sumsq are non-NULL, per-output-channel
  * sums of the un-biased accumulator and its square are ATOMICALLY added (float64) -- the batch
  * statistics BatchNorm needs, taken in the producer's epilogue. */

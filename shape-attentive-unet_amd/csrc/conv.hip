@@ -48,6 +48,35 @@ __global__ void pack_weight_kernel(int mode, const float* __restrict__ w, int Co
     }
 }
 
+// all packings of one training step in a few launches: blockIdx.y = entry
+template <typename T> __global__ void pack_weight_multi_kernel(saunet_pack_list pl)
+{
+    const int e = blockIdx.y;
+    const int mode = pl.mode[e], Co = pl.dims[e][0], Ci = pl.dims[e][1], KH = pl.dims[e][2], KW = pl.dims[e][3];
+    const float* __restrict__ w = (const float*)pl.src[e];
+    T* __restrict__ out = (T*)pl.dst[e];
+    const long total = (long)Co * Ci * KH * KW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float v;
+        if (mode == SAUNET_PACK_FWD) {
+            int ci = i % Ci; long t = i / Ci; int kw = t % KW; t /= KW; int kh = t % KH; int co = t / KH;
+            v = w[(((long)co * Ci + ci) * KH + kh) * KW + kw];
+        } else if (mode == SAUNET_PACK_DGRAD) {
+            int co = i % Co; long t = i / Co; int kw = t % KW; t /= KW; int kh = t % KH; int ci = t / KH;
+            v = w[(((long)co * Ci + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
+        } else if (mode == SAUNET_PACK_CONVT_FWD) {
+            int ci = i % Ci; long t = i / Ci; int tw = t % 2; t /= 2; int th = t % 2; t /= 2; int co = t % Co; t /= Co;
+            int pw = t % 2, ph = t / 2;
+            int kh = (1 - ph) + 2 * th, kw = (1 - pw) + 2 * tw;
+            v = w[(((long)ci * Co + co) * 4 + kh) * 4 + kw];
+        } else {
+            int co = i % Co; long t = i / Co; int kw = t % 4; t /= 4; int kh = t % 4; int ci = t / 4;
+            v = w[(((long)ci * Co + co) * 4 + kh) * 4 + kw];
+        }
+        Elem<T>::store(out + i, v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------- pointwise (1x1) small-channel path
 struct PwArgs {
     const void* x; const void* w; void* y; const float* bias; const float* ps; const float* psh;
@@ -98,6 +127,68 @@ template <typename T> __global__ __launch_bounds__(256) void pointwise_fwd_kerne
         if (threadIdx.x < a.Cout) {
             atomicAdd(&a.ssum[threadIdx.x], (double)s_sum[threadIdx.x]);
             atomicAdd(&a.ssq[threadIdx.x], (double)s_sq[threadIdx.x]);
+        }
+    }
+}
+
+// Small-channel pointwise conv, one PIXEL per thread: the pixel's Cin values are read once into registers,
+// weights / bias / prologue live in LDS (broadcast reads).  Used when Cin <= CIN_PAD <= 64 and Cout <= 64.
+// BN statistics: per-output-channel wave reduction -> LDS -> one float64 atomic per channel per block.
+template <typename T, int CIN_PAD> __global__ __launch_bounds__(256) void pointwise_small_fwd_kernel(PwArgs a)
+{
+    extern __shared__ float sm[];
+    float* sw = sm;                          // [Cout][CIN_PAD]
+    float* sb = sw + a.Cout * CIN_PAD;       // [Cout]
+    float* sps = sb + a.Cout;                // [CIN_PAD] x2
+    float* ssum = sps + 2 * CIN_PAD;         // [Cout] x2
+    const bool stats = a.ssum != nullptr, has_pro = a.ps != nullptr;
+    for (int i = threadIdx.x; i < a.Cout * CIN_PAD; i += 256) {
+        int co = i / CIN_PAD, ci = i - co * CIN_PAD;
+        sw[i] = ci < a.Cin ? Elem<T>::load((const T*)a.w + (long)co * a.Cin + ci) : 0.f;
+    }
+    for (int i = threadIdx.x; i < a.Cout; i += 256) { sb[i] = a.bias ? a.bias[i] : 0.f; ssum[i] = 0.f; ssum[a.Cout + i] = 0.f; }
+    for (int i = threadIdx.x; i < CIN_PAD; i += 256) {
+        sps[i] = (has_pro && i < a.Cin) ? a.ps[i] : 1.f;
+        sps[CIN_PAD + i] = (has_pro && i < a.Cin) ? a.psh[i] : 0.f;
+    }
+    __syncthreads();
+    const float relu_lo = a.pro_relu ? 0.f : -__builtin_inff();
+    const int lane = threadIdx.x & 63;
+    const long pstride = (long)gridDim.x * 256;
+    const long pend = ((a.P + 255) / 256) * 256;   // whole waves iterate together (wave reductions below)
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < pend; p += pstride) {
+        const bool live = p < a.P;
+        float xv[CIN_PAD];
+        const T* xr = (const T*)a.x + (live ? p : 0) * a.ldx;
+#pragma unroll
+        for (int c = 0; c < CIN_PAD; ++c) {
+            float v = (c < a.Cin) ? Elem<T>::load(xr + c) : 0.f;
+            if (has_pro) v = fmaxf(fmaf(v, sps[c], sps[CIN_PAD + c]), relu_lo);
+            xv[c] = (c < a.Cin) ? v : 0.f;
+        }
+        T* yr = (T*)a.y + (live ? p : 0) * a.ldy;
+        for (int co = 0; co < a.Cout; ++co) {
+            const float* wr = sw + co * CIN_PAD;
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CIN_PAD; c += 4) {
+                f32x4 w4 = *(const f32x4*)(wr + c);
+                acc = fmaf(w4[0], xv[c], acc); acc = fmaf(w4[1], xv[c + 1], acc);
+                acc = fmaf(w4[2], xv[c + 2], acc); acc = fmaf(w4[3], xv[c + 3], acc);
+            }
+            if (stats) {
+                float v = live ? acc : 0.f;
+                float s = wave_sum(v), q = wave_sum(v * v);
+                if (lane == 0) { atomicAdd(&ssum[co], s); atomicAdd(&ssum[a.Cout + co], q); }
+            }
+            if (live) Elem<T>::store(yr + co, acc + sb[co]);
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.Cout; i += 256) {
+            atomicAdd(&a.ssum[i], (double)ssum[i]);
+            atomicAdd(&a.ssq[i], (double)ssum[a.Cout + i]);
         }
     }
 }
@@ -210,6 +301,17 @@ int saunet_pack_weight(int mode, int dtype, const float* w, int Co, int Ci, int 
     return SAUNET_OK;
 }
 
+int saunet_pack_weight_multi(const saunet_pack_list* pl, int dtype, void* stream)
+{
+    if (pl->count <= 0 || pl->count > 64) return set_error(SAUNET_BAD_SHAPE, "pack_multi: %d entries", pl->count);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SAUNET_F32) hipLaunchKernelGGL(pack_weight_multi_kernel<float>, dim3(64, pl->count), dim3(256), 0, st, *pl);
+    else if (dtype == SAUNET_BF16) hipLaunchKernelGGL(pack_weight_multi_kernel<u16>, dim3(64, pl->count), dim3(256), 0, st, *pl);
+    else return set_error(SAUNET_BAD_DTYPE, "pack_multi: dtype %d", dtype);
+    SAUNET_CHECK_LAUNCH("pack_weight_multi");
+    return SAUNET_OK;
+}
+
 int saunet_conv2d_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias,
                           const float* ps, const float* psh, void* y, double* ssum, double* ssq, void* stream)
 {
@@ -228,6 +330,20 @@ int saunet_conv2d_forward(const saunet_conv_desc* d, const void* x, const void* 
     if (!is_pointwise(d)) return set_error(SAUNET_UNSUPPORTED, "conv: %dx%d s%d Cin=%d Cout=%d has no kernel", d->KH, d->KW, d->stride, d->Cin, d->Cout);
     if (ssum != nullptr && d->Cout > 64) return set_error(SAUNET_UNSUPPORTED, "pointwise stats need Cout <= 64");
     PwArgs a{x, w, y, bias, ps, psh, ssum, ssq, (long)d->N * d->H * d->W, d->Cin, d->Cout, d->ldx, d->ldy, d->pro_relu};
+    if (d->Cin <= 64 && d->Cout <= 64) {
+        const int cpad = d->Cin <= 4 ? 4 : d->Cin <= 8 ? 8 : d->Cin <= 16 ? 16 : d->Cin <= 36 ? 36 : 64;
+        long blocks = (a.P + 255) / 256; if (blocks > 2048) blocks = 2048;
+        const size_t lds = sizeof(float) * ((size_t)d->Cout * cpad + 3 * d->Cout + 2 * cpad);
+#define PWS(TT, CP) hipLaunchKernelGGL((pointwise_small_fwd_kernel<TT, CP>), dim3((unsigned)blocks), dim3(256), lds, st, a)
+#define PWS_T(TT) do { if (cpad == 4) PWS(TT, 4); else if (cpad == 8) PWS(TT, 8); else if (cpad == 16) PWS(TT, 16); else if (cpad == 36) PWS(TT, 36); else PWS(TT, 64); } while (0)
+        if (d->dtype == SAUNET_F32) PWS_T(float);
+        else if (d->dtype == SAUNET_BF16) PWS_T(u16);
+        else return set_error(SAUNET_BAD_DTYPE, "conv: dtype %d", d->dtype);
+#undef PWS_T
+#undef PWS
+        SAUNET_CHECK_LAUNCH("pointwise_small_fwd");
+        return SAUNET_OK;
+    }
     long total = a.P * a.Cout;
     dim3 grid((unsigned)((total + 256 * PW_IT - 1) / (256 * PW_IT)));
     if (d->dtype == SAUNET_F32) hipLaunchKernelGGL(pointwise_fwd_kernel<float>, grid, dim3(256), 0, st, a);

@@ -53,11 +53,92 @@ def _check_dev(t):
 
 
 # ------------------------------------------------------------------------------------------------ raw op wrappers
+class ZeroArena:
+    """Zero-initialised scratch handed out as slices of a few big buffers (one memset each) instead of hundreds of
+    tiny torch.zeros() fills per step: BN statistic accumulators (float64) and weight-gradient buffers (float32)."""
+
+    def __init__(self, dtype, chunk):
+        self.dtype, self.chunk = dtype, chunk
+        self.buf, self.off = None, 0
+
+    def reset(self):
+        self.buf, self.off = None, 0
+
+    def take(self, n, device):
+        n_al = (n + 31) // 32 * 32  # keep every slice 128/256-byte aligned
+        if n_al > self.chunk:
+            return torch.zeros(n, dtype=self.dtype, device=device)
+        if self.buf is None or self.buf.device != torch.device(device) or self.off + n_al > self.chunk:
+            self.buf = torch.zeros(self.chunk, dtype=self.dtype, device=device)
+            self.off = 0
+        out = self.buf[self.off:self.off + n]
+        self.off += n_al
+        return out
+
+
+STATS = ZeroArena(torch.float64, 1 << 18)      # 2 MB chunks
+GRADS = ZeroArena(torch.float32, 1 << 24)      # 64 MB chunks
+
+
+def zeros_f64(*shape, device):
+    n = 1
+    for s_ in shape:
+        n *= s_
+    return STATS.take(n, device).view(*shape)
+
+
+def begin_step():
+    """Called at the start of every SAUNet forward: new scratch arenas, all weight packings refreshed in bulk."""
+    STATS.reset(); GRADS.reset()
+    PACKS.prepack()
+
+
 class PackedWeights:
-    """Per-parameter cache of MFMA-friendly weight packings, invalidated by the tensor version counter."""
+    """Per-parameter cache of MFMA-friendly weight packings.  Entries are keyed by the Parameter object (weakref)
+    and its version counter; `prepack` re-packs every packing seen so far in a handful of multi-tensor launches."""
 
     def __init__(self):
         self.cache = {}
+        self.dirty = True
+
+    def invalidate(self):
+        """the fused optimisers update parameters through raw pointers (no version bump): they call this"""
+        self.dirty = True
+
+    def _dims(self, w, mode):
+        if mode in (L.PACK_CONVT_FWD, L.PACK_CONVT_DGRAD):
+            ci, co, kh, kw = w.shape
+        else:
+            co, ci, kh, kw = w.shape
+        return co, ci, kh, kw
+
+    def prepack(self):
+        if not self.dirty:
+            return
+        live = []
+        for key, ent in list(self.cache.items()):
+            w = ent[2]()
+            if w is None or w.data_ptr() != ent[3]:
+                del self.cache[key]
+                continue
+            live.append((key, ent, w))
+        by_dtype = {}
+        for key, ent, w in live:
+            by_dtype.setdefault((key[2], w.device), []).append((key, ent, w))
+        for (dtype, dev), items in by_dtype.items():
+            with torch.cuda.device(dev):
+                for s0 in range(0, len(items), 64):
+                    pl = L.PackList()
+                    chunk = items[s0:s0 + 64]
+                    pl.count = len(chunk)
+                    for i, (key, ent, w) in enumerate(chunk):
+                        co, ci, kh, kw = self._dims(w, key[1])
+                        pl.mode[i] = key[1]
+                        pl.dims[i][0], pl.dims[i][1], pl.dims[i][2], pl.dims[i][3] = co, ci, kh, kw
+                        pl.src[i] = w.data_ptr(); pl.dst[i] = ent[1].data_ptr()
+                        self.cache[key] = (w._version, ent[1], ent[2], ent[3])
+                    L.call("saunet_pack_weight_multi", C.byref(pl), L.BF16 if dtype == torch.bfloat16 else L.F32, L.stream())
+        self.dirty = False
 
     def get(self, w, mode, dtype):
         # only leaf Parameters are cached, identified by object (weakref) + version counter: an address or an id()
@@ -66,16 +147,17 @@ class PackedWeights:
         key = (id(w), mode, dtype)
         ent = self.cache.get(key) if cacheable else None
         ver = w._version
-        if ent is not None and ent[2]() is w and ent[0] == ver and ent[1].device == w.device and ent[3] == w.data_ptr():
+        if ent is not None and ent[2]() is w and ent[0] == ver and ent[1].device == w.device and ent[3] == w.data_ptr() \
+                and not self.dirty:
             return ent[1]
-        out = torch.empty(w.numel(), dtype=dtype, device=w.device)
-        wd = w.detach()
-        if not wd.is_contiguous():
-            wd = wd.contiguous()
-        if mode in (L.PACK_CONVT_FWD, L.PACK_CONVT_DGRAD):
-            ci, co, kh, kw = w.shape
+        if ent is not None and ent[2]() is w and ent[1].device == w.device and ent[1].numel() == w.numel():
+            out = ent[1]      # re-pack in place (keeps addresses stable for graph replay)
         else:
-            co, ci, kh, kw = w.shape
+            out = torch.empty(w.numel(), dtype=dtype, device=w.device)
+        wd = w.detach()
+        if not wd.is_contiguous() or wd.dtype != torch.float32:
+            wd = wd.contiguous().float()
+        co, ci, kh, kw = self._dims(w, mode)
         L.call("saunet_pack_weight", mode, L.BF16 if dtype == torch.bfloat16 else L.F32, wd.data_ptr(), co, ci, kh, kw,
                out.data_ptr(), L.stream())
         if cacheable:
@@ -86,6 +168,7 @@ class PackedWeights:
 
     def clear(self):
         self.cache.clear()
+        self.dirty = True
 
 
 PACKS = PackedWeights()
@@ -155,7 +238,7 @@ def conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed=False, out=None)
 
 def conv_wgrad_raw(x, dy, weight, stride, pad, transposed=False, pro=None):
     x = nhwc(x); dy = nhwc(dy)
-    dw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+    dw = GRADS.take(weight.numel(), x.device).view(weight.shape)
     if transposed:
         _, cout, kh, kw = weight.shape
     else:
@@ -173,7 +256,7 @@ def conv_wgrad_raw(x, dy, weight, stride, pad, transposed=False, pro=None):
 def channel_sum(t):
     t = nhwc(t)
     n, c, h, w = t.shape
-    acc = torch.zeros(c, dtype=torch.float64, device=t.device)
+    acc = zeros_f64(c, device=t.device)
     L.call("saunet_channel_sum", L.dtype_code(t), t.data_ptr(), n * h * w, c, ld_of(t), acc.data_ptr(), L.stream())
     return acc.float()
 
@@ -182,7 +265,7 @@ def bn_stats(x, stats=None):
     x = nhwc(x)
     n, c, h, w = x.shape
     if stats is None:
-        stats = torch.zeros(2, c, dtype=torch.float64, device=x.device)
+        stats = zeros_f64(2, c, device=x.device)
     L.call("saunet_bn_stats", L.dtype_code(x), x.data_ptr(), n * h * w, c, ld_of(x), stats[0].data_ptr(), stats[1].data_ptr(), L.stream())
     return stats
 
@@ -230,7 +313,7 @@ def bn_backward(dy, x, p, relu, count, training, residual=None, dx=None, accumul
     n, c, h, w = x.shape
     P = n * h * w
     dev = x.device
-    sums = torch.zeros(2 * c, dtype=torch.float64, device=dev)
+    sums = zeros_f64(2 * c, device=dev)
     if residual is not None:
         residual = nhwc(residual)
     rp, rl = L.ptr(residual), (ld_of(residual) if residual is not None else 0)
@@ -288,6 +371,12 @@ def conv_transpose2d(x, weight, bias=None):
     return _Conv.apply(x, weight, bias, 2, 1, True)
 
 
+def _bump(bn):
+    """num_batches_tracked += 1 (skipped when the owning SAUNet increments all counters with one fused add)"""
+    if bn.training and bn.num_batches_tracked is not None and not getattr(bn, "_nbt_fused", False):
+        bn.num_batches_tracked.add_(1)
+
+
 class _ConvBNAct(torch.autograd.Function):
     """y = act(BN(conv(x)) [+ residual]) with the batch statistics taken in the conv epilogue."""
 
@@ -295,7 +384,7 @@ class _ConvBNAct(torch.autograd.Function):
     def forward(ctx, x, weight, bias, gamma, beta, rmean, rvar, residual, stride, pad, transposed, relu, momentum, eps, training, group):
         x = nhwc(x)
         cout = weight.shape[1] if transposed else weight.shape[0]
-        stats = torch.zeros(2, cout, dtype=torch.float64, device=x.device) if training else None
+        stats = zeros_f64(2, cout, device=x.device) if training else None
         z = conv_forward_raw(x, weight, bias, stride, pad, transposed, stats=(stats[0], stats[1]) if training else None)
         count = z.shape[0] * z.shape[2] * z.shape[3]
         if group is not None and training:
@@ -331,8 +420,7 @@ def conv_bn_act(x, weight, bias, bn, relu=True, residual=None, stride=1, padding
     """bn: an nn.BatchNorm2d-like module (weight, bias, running_mean, running_var, momentum, eps, training).
     A bn with a truthy ``sync`` attribute (SynchronizedBatchNorm2d) reduces its statistics over the default
     process group when one with more than one rank exists."""
-    if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    _bump(bn)
     if transposed:
         stride, padding = 2, 1  # the only transposed geometry on the path: ConvTranspose2d(k=4, s=2, p=1)
     group = None
@@ -370,8 +458,7 @@ class _BNAct(torch.autograd.Function):
 
 
 def batch_norm_act(x, bn, relu=False, stats=None):
-    if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    _bump(bn)
     return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, stats, relu, bn.momentum, bn.eps, bn.training)
 
 
@@ -724,7 +811,7 @@ class _DenseBlock(torch.autograd.Function):
         ctot = c0 + growth * nl
         dev = x0.device
         buf = new_act(n, ctot, h, w, x0.dtype, dev)
-        stats = torch.zeros(2, ctot, dtype=torch.float64, device=dev)
+        stats = zeros_f64(2, ctot, device=dev)
         copy_channels(x0, buf[:, :c0])
         count = n * h * w
         if training:
@@ -736,7 +823,7 @@ class _DenseBlock(torch.autograd.Function):
             mom, eps = cfgs[l]
             cin = c0 + growth * l
             p1 = bn_finalize(stats[0, :cin], stats[1, :cin], count, n1w, n1b, n1rm, n1rv, mom, eps, training)
-            st2 = torch.zeros(2, c1w.shape[0], dtype=torch.float64, device=dev) if training else None
+            st2 = zeros_f64(2, c1w.shape[0], device=dev) if training else None
             z1 = conv_forward_raw(buf[:, :cin], c1w, None, 1, 0, pro=(p1.scale, p1.shift, True),
                                   stats=(st2[0], st2[1]) if training else None)
             p2 = bn_finalize(st2[0] if training else None, st2[1] if training else None, count, n2w, n2b, n2rm, n2rv, mom, eps, training)
@@ -784,8 +871,7 @@ def dense_block(x0, layers, training):
         params += [m.norm1.weight, m.norm1.bias, m.conv1.weight, m.norm2.weight, m.norm2.bias, m.conv2.weight]
         bufs += [m.norm1.running_mean, m.norm1.running_var, m.norm2.running_mean, m.norm2.running_var]
         cfgs.append((m.norm1.momentum, m.norm1.eps))
-        if training:
-            m.norm1.num_batches_tracked.add_(1); m.norm2.num_batches_tracked.add_(1)
+        _bump(m.norm1); _bump(m.norm2)
     return _DenseBlock.apply(x0, training, tuple(cfgs), *params, *bufs)
 
 
@@ -822,7 +908,6 @@ class _Transition(torch.autograd.Function):
 
 
 def transition(buf, stats, m, training):
-    if training:
-        m.norm.num_batches_tracked.add_(1)
+    _bump(m.norm)
     return _Transition.apply(buf, stats, m.norm.weight, m.norm.bias, m.norm.running_mean, m.norm.running_var, m.conv.weight,
                              m.norm.momentum, m.norm.eps, training)

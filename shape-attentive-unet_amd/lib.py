@@ -21,6 +21,11 @@ class ConvDesc(C.Structure):
         "transposed", "pro_relu")]
 
 
+class PackList(C.Structure):
+    _fields_ = [("count", C.c_int32), ("mode", C.c_int32 * 64), ("dims", (C.c_int32 * 4) * 64), ("src", C.c_void_p * 64),
+                ("dst", C.c_void_p * 64)]
+
+
 class TensorList(C.Structure):
     _fields_ = [("count", C.c_int32), ("ptrs", (C.c_void_p * 96) * 4), ("numel", C.c_int64 * 96)]
 
@@ -29,6 +34,7 @@ vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 _SIGS = {
     "saunet_init": [i32],
     "saunet_pack_weight": [i32, i32, vp, i32, i32, i32, i32, vp, vp],
+    "saunet_pack_weight_multi": [C.POINTER(PackList), i32, vp],
     "saunet_conv2d_forward": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "saunet_conv2d_wgrad": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i64, vp],
     "saunet_conv2d_wgrad_workspace": [C.POINTER(ConvDesc)],

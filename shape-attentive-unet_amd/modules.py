@@ -352,7 +352,24 @@ class SAUNet(nn.Module):
         HF.copy_channels(xs, x8[:, :3])
         return x8
 
+    def _bump_counters(self):
+        """all 150 BatchNorm `num_batches_tracked` counters live in one int64 tensor: one add per step"""
+        bns = [m for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.num_batches_tracked is not None]
+        flat = getattr(self, "_nbt_flat", None)
+        ok = flat is not None and flat.device == bns[0].num_batches_tracked.device and all(
+            b.num_batches_tracked.data_ptr() == flat.data_ptr() + 8 * i for i, b in enumerate(bns))
+        if not ok:
+            flat = torch.stack([b.num_batches_tracked.detach().reshape(()) for b in bns]).contiguous()
+            for i, b in enumerate(bns):
+                b.num_batches_tracked = flat[i]
+                b._nbt_fused = True
+            object.__setattr__(self, "_nbt_flat", flat)
+        flat.add_(1)
+
     def forward(self, x, return_att=False):
+        HF.begin_step()
+        if self.training:
+            self._bump_counters()
         size = x.shape[2:]
         up = HF.interpolate_bilinear
         conv1 = self.conv1(self._prep_input(x))

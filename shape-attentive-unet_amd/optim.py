@@ -109,7 +109,7 @@ class FusedSGD(_FusedBase):
             for tl in _tensor_lists([ps, [p.grad for p in ps], bufs]):
                 L.call("saunet_sgd_step", C.byref(tl), self._hyper(g).data_ptr(), L.stream())
             g["_stepped"] = True
-        HF.PACKS.clear()
+        HF.PACKS.invalidate()
 
 
 class FusedRAdam(_FusedBase):
@@ -157,7 +157,7 @@ class FusedRAdam(_FusedBase):
             for tl in _tensor_lists([ps, [p.grad for p in ps], ea, es]):
                 L.call("saunet_radam_step", C.byref(tl), self._hyper(g).data_ptr(), L.stream())
             g["_step"] = g.get("_step", 0) + 1
-        HF.PACKS.clear()
+        HF.PACKS.invalidate()
 
 
 def create_optimizers(unet, optimizer="sgd", lr=5e-4, momentum=0.9, weight_decay=1e-4):
