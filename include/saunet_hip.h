@@ -65,6 +65,18 @@ int saunet_pack_weight_multi(const saunet_pack_list* pl, int dtype, void* stream
 int saunet_conv2d_forward(const saunet_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                           const float* pro_scale, const float* pro_shift, void* y,
                           double* stat_sum, double* stat_sumsq, void* stream);
+/* Same, with an optional fused BatchNorm-backward epilogue for the case "this convolution IS the dgrad that produces
+ * the gradient of a BN(+ReLU) output": instead of y = conv(...), store g = y * [bn_x*scale+shift > 0] and add
+ * sum g, sum g*xhat (xhat = (bn_x-mean)*invstd) to sums[0:C], sums[C:2C] -- the reduction pass of BN backward, done
+ * while the tile is still on chip.  bn_x is the tensor that BN normalised, same pixels/channels as y. */
+typedef struct saunet_bn_epilogue {
+    const void* bn_x; int32_t ld_bn_x; int32_t relu;
+    const float* scale; const float* shift; const float* mean; const float* invstd;
+    double* sums;
+} saunet_bn_epilogue;
+int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                             const float* pro_scale, const float* pro_shift, void* y,
+                             double* stat_sum, double* stat_sumsq, const saunet_bn_epilogue* epi, void* stream);
 /* dw[...] += sum_pixels dy (x) prologue(x).  dw is the float32 gradient in the PARAMETER's own
  * layout ([Co,Ci,kh,kw], or [Ci,Co,4,4] when d->transposed); it must be zero-initialised by the
  * caller (split-K partial sums are added atomically).  replaces autograd's convolution_backward

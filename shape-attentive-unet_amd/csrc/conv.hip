@@ -13,14 +13,14 @@ int set_error(int code, const char* fmt, ...)
 
 bool igemm_supported(const saunet_conv_desc* d);
 int igemm_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps, const float* psh,
-                  void* y, double* ssum, double* ssq, hipStream_t st);
+                  void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st);
 int igemm_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw, hipStream_t st);
 bool tile_fwd_supported(const saunet_conv_desc* d);
 bool tile_wgrad_supported(const saunet_conv_desc* d);
 int tile_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw,
                void* ws, size_t ws_bytes, size_t* need, hipStream_t st);
 int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps, const float* psh,
-                 void* y, double* ssum, double* ssq, hipStream_t st);
+                 void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------- packing
 template <typename T>
@@ -315,6 +315,13 @@ int saunet_pack_weight_multi(const saunet_pack_list* pl, int dtype, void* stream
 int saunet_conv2d_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias,
                           const float* ps, const float* psh, void* y, double* ssum, double* ssq, void* stream)
 {
+    return saunet_conv2d_forward_ex(d, x, w, bias, ps, psh, y, ssum, ssq, nullptr, stream);
+}
+
+int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const void* w, const float* bias,
+                             const float* ps, const float* psh, void* y, double* ssum, double* ssq,
+                             const saunet_bn_epilogue* epi, void* stream)
+{
     hipStream_t st = (hipStream_t)stream;
     if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->ldx < d->Cin || d->ldy < d->Cout)
         return set_error(SAUNET_BAD_SHAPE, "conv: bad shape N=%d Cin=%d ldx=%d Cout=%d ldy=%d", d->N, d->Cin, d->ldx, d->Cout, d->ldy);
@@ -324,9 +331,12 @@ int saunet_conv2d_forward(const saunet_conv_desc* d, const void* x, const void* 
     }
     if ((ps == nullptr) != (psh == nullptr)) return set_error(SAUNET_BAD_SHAPE, "conv: prologue needs scale and shift");
     if (igemm_supported(d)) {
-        if (tile_fwd_supported(d)) return tile_forward(d, x, w, bias, ps, psh, y, ssum, ssq, st);
-        return igemm_forward(d, x, w, bias, ps, psh, y, ssum, ssq, st);
+        if (epi && (((uintptr_t)epi->bn_x & 15) || epi->ld_bn_x % (d->dtype == SAUNET_BF16 ? 8 : 4)))
+            return set_error(SAUNET_BAD_ALIGN, "conv: bn epilogue tensor must be 16-byte aligned");
+        if (tile_fwd_supported(d)) return tile_forward(d, x, w, bias, ps, psh, y, ssum, ssq, epi, st);
+        return igemm_forward(d, x, w, bias, ps, psh, y, ssum, ssq, epi, st);
     }
+    if (epi) return set_error(SAUNET_UNSUPPORTED, "conv: the BN-backward epilogue needs the MFMA path");
     if (!is_pointwise(d)) return set_error(SAUNET_UNSUPPORTED, "conv: %dx%d s%d Cin=%d Cout=%d has no kernel", d->KH, d->KW, d->stride, d->Cin, d->Cout);
     if (ssum != nullptr && d->Cout > 64) return set_error(SAUNET_UNSUPPORTED, "pointwise stats need Cout <= 64");
     PwArgs a{x, w, y, bias, ps, psh, ssum, ssq, (long)d->N * d->H * d->W, d->Cin, d->Cout, d->ldx, d->ldy, d->pro_relu};

@@ -27,6 +27,7 @@ struct IgemmArgs {
     int M;            // GEMM rows per launch (per phase when transposed)
     int Mh, Mw;       // row decode: m -> (n, q, r) with q < Mh, r < Mw
     int kpt;          // K-steps per tap = ceil(Cin / KC)
+    saunet_bn_epilogue epi;   // epi.bn_x == nullptr: plain store
 };
 
 template <typename T> struct Mma;
@@ -53,7 +54,7 @@ template <int CPR> __device__ __forceinline__ int lds_off(int r, int c)
     return (r * CPR + (c ^ ((r / RPB) & (CPR - 1)))) * 16;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int CPR>
+template <typename T, int BM, int BN, int WM, int WN, int CPR, bool BNEPI>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_igemm_fwd_kernel(IgemmArgs a)
 {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
@@ -231,29 +232,83 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_igemm_fwd_ker
     }
     constexpr int CH = BN / EPC;  // 16-byte chunks per output row
     T* __restrict__ yg = (T*)a.y;
-    for (int p = tid; p < BM * CH; p += NT) {
+    constexpr bool bnb = BNEPI;
+    float e1[EPC], e2[EPC], esc[EPC], esh[EPC], emu[EPC], eis[EPC];
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) e1[j] = e2[j] = 0.f;
+    if (bnb) {   // NT % CH == 0: the channel chunk of a thread is loop-invariant -> per-channel constants in registers
+        const int colf = n0 + (tid % CH) * EPC;
+        const int cs = colf < a.Cout ? colf : 0;
+#pragma unroll
+        for (int j = 0; j < EPC; j += 4) {
+            f32x4 v0 = *(const f32x4*)(a.epi.scale + cs + j), v1 = *(const f32x4*)(a.epi.shift + cs + j);
+            f32x4 v2 = *(const f32x4*)(a.epi.mean + cs + j), v3 = *(const f32x4*)(a.epi.invstd + cs + j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { esc[j + q] = v0[q]; esh[j + q] = v1[q]; emu[j + q] = v2[q]; eis[j + q] = v3[q]; }
+        }
+    }
+    constexpr int S_ITERS = (BM * CH) / NT;
+    static_assert((BM * CH) % NT == 0, "store loop must divide evenly");
+    size_t opixv[S_ITERS]; bool okv[S_ITERS]; u32x4 xr[S_ITERS];
+    const int colv = n0 + (tid % CH) * EPC;
+#pragma unroll
+    for (int i = 0; i < S_ITERS; ++i) {
+        int p = tid + i * NT;
+        int row = p / CH;
+        int m = m0 + row;
+        okv[i] = m < a.M && colv < a.Cout;
+        size_t opix = m;
+        if (a.transposed) {
+            int n = m / (a.Mh * a.Mw), rem = m - n * (a.Mh * a.Mw);
+            int q = rem / a.Mw, r = rem - q * a.Mw;
+            opix = ((size_t)n * a.Ho + 2 * q + ph) * a.Wo + 2 * r + pw;
+        }
+        opixv[i] = okv[i] ? opix : 0;
+        if (bnb) xr[i] = *(const u32x4*)((const T*)a.epi.bn_x + (okv[i] ? opixv[i] * a.epi.ld_bn_x + colv : (size_t)0));   // all loads in flight together
+    }
+#pragma unroll
+    for (int i = 0; i < S_ITERS; ++i) {
+        int p = tid + i * NT;
         int row = p / CH, ch = p - row * CH;
-        int m = m0 + row, col = n0 + ch * EPC;
-        if (m < a.M && col < a.Cout) {
-            size_t opix = m;
-            if (a.transposed) {
-                int n = m / (a.Mh * a.Mw), rem = m - n * (a.Mh * a.Mw);
-                int q = rem / a.Mw, r = rem - q * a.Mw;
-                opix = ((size_t)n * a.Ho + 2 * q + ph) * a.Wo + 2 * r + pw;
+        u32x4 v = *(const u32x4*)(so + row * BN + ch * EPC);
+        if (bnb) {   // fused BatchNorm-backward reduction: g = v*[relu mask], sums += g, g*xhat
+            float g[EPC], xv[EPC];
+            Vec16<T>::unpack(v, g);
+            Vec16<T>::unpack(xr[i], xv);
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) {
+                if (a.epi.relu && !(fmaf(xv[j], esc[j], esh[j]) > 0.f)) g[j] = 0.f;
+                if (!okv[i]) g[j] = 0.f;
+                e1[j] += g[j];
+                e2[j] = fmaf(g[j], (xv[j] - emu[j]) * eis[j], e2[j]);
             }
-            *(u32x4*)(yg + opix * a.ldy + col) = *(const u32x4*)(so + row * BN + ch * EPC);
+            v = Vec16<T>::pack(g);
+        }
+        if (okv[i]) *(u32x4*)(yg + opixv[i] * a.ldy + colv) = v;
+    }
+    if (bnb) {   // NT % CH == 0: a thread always owns the same EPC channels -> one LDS atomic per channel per thread
+        __syncthreads();
+        for (int i = tid; i < 2 * BN; i += NT) s_sum[i] = 0.f;
+        __syncthreads();
+        const int ch = tid % CH;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) { atomicAdd(&s_sum[ch * EPC + j], e1[j]); atomicAdd(&s_sq[ch * EPC + j], e2[j]); }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.Cout) {
+            atomicAdd(&a.epi.sums[n0 + tid], (double)s_sum[tid]);
+            atomicAdd(&a.epi.sums[a.Cout + n0 + tid], (double)s_sq[tid]);
         }
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int CPR>
-static int launch_fwd(const IgemmArgs& a, int phases, hipStream_t st)
+template <typename T, int BM, int BN, int WM, int WN, int CPR, bool BNEPI>
+static int launch_fwd_i(const IgemmArgs& a, int phases, hipStream_t st)
 {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     constexpr int STAGE = (BM + BN) * CPR * 16;
     constexpr int EPI = BM * BN * (int)sizeof(T) + 2 * BN * 4;
     constexpr int LDS = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
-    auto kern = conv_igemm_fwd_kernel<T, BM, BN, WM, WN, CPR>;
+    auto kern = conv_igemm_fwd_kernel<T, BM, BN, WM, WN, CPR, BNEPI>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -263,6 +318,12 @@ static int launch_fwd(const IgemmArgs& a, int phases, hipStream_t st)
     hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, st, a);
     SAUNET_CHECK_LAUNCH("conv_igemm_fwd");
     return SAUNET_OK;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int CPR>
+static int launch_fwd(const IgemmArgs& a, int phases, hipStream_t st)
+{
+    return a.epi.bn_x ? launch_fwd_i<T, BM, BN, WM, WN, CPR, true>(a, phases, st) : launch_fwd_i<T, BM, BN, WM, WN, CPR, false>(a, phases, st);
 }
 
 template <typename T> static int dispatch_fwd(const IgemmArgs& a, int phases, hipStream_t st)
@@ -288,9 +349,10 @@ bool igemm_supported(const saunet_conv_desc* d)
 }
 
 int igemm_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps,
-                  const float* psh, void* y, double* ssum, double* ssq, hipStream_t st)
+                  const float* psh, void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st)
 {
     IgemmArgs a;
+    if (epi) a.epi = *epi; else a.epi.bn_x = nullptr;
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.pro_scale = ps; a.pro_shift = psh; a.stat_sum = ssum; a.stat_sumsq = ssq;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
     a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.ldy = d->ldy;

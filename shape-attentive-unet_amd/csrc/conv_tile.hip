@@ -21,6 +21,7 @@ struct TileArgs {
     int N, H, W, Cin, ldx, Cout, ldy;
     int pro_relu;
     int tiles_x, tiles_y;   // H/16, W/16
+    saunet_bn_epilogue epi;
 };
 
 template <typename T> struct MmaT;
@@ -47,8 +48,8 @@ template <int CPR> __device__ __forceinline__ int swz_off(int r, int c)
 
 constexpr int TILE = 16, HPITCH = 18, NPIX = HPITCH * HPITCH;
 
-template <typename T, int BN, int WM, int WN, int CPR>
-__global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_tile_fwd_kernel(TileArgs a)
+template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI>
+__global__ __launch_bounds__((256 / WM) * (BN / WN) * 64, BNEPI ? 1 : 2) void conv3x3_tile_fwd_kernel(TileArgs a)
 {
     constexpr int NT = (256 / WM) * (BN / WN) * 64;
     constexpr int EPC = 16 / sizeof(T);
@@ -76,20 +77,6 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_tile_fwd_
     const float relu_lo = a.pro_relu ? 0.f : -__builtin_inff();
     const int ncb = (a.Cin + KC - 1) / KC;
 
-    // per-thread halo pieces: (pixel, chunk) -> global offset (without channel block) and validity
-    int hoff[H_ITERS]; int hlds[H_ITERS]; int hchunk[H_ITERS]; bool hok[H_ITERS];
-#pragma unroll
-    for (int i = 0; i < H_ITERS; ++i) {
-        int q = tid + i * NT;
-        int pix = q / CPR, ch = q % CPR;
-        int hy = pix / HPITCH, hx = pix - hy * HPITCH;
-        int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-        bool ok = q < NPIX * CPR && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        hok[i] = ok;
-        hoff[i] = ok ? (iy * a.W + ix) * a.ldx : 0;
-        hlds[i] = (q < NPIX * CPR) ? swz_off<CPR>(pix, ch) : -1;
-        hchunk[i] = ch * EPC;
-    }
     // A-fragment rows of this lane
     int pbase[TI];
 #pragma unroll
@@ -132,40 +119,50 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_tile_fwd_
     int wbuf = 0;
     load_w(0, 0);
     for (int cb = 0; cb < ncb; ++cb) {
-        // ---- stage the (transformed) halo of this channel block; previous readers are done (barrier at loop end)
+        // ---- stage the (transformed) halo of this channel block; previous readers are done (barrier at loop end).
+        // Batches of HB pieces per thread in a NON-unrolled loop: keeps the index math out of long-lived registers.
         {
-            u32x4 hreg[H_ITERS];
+            constexpr int HB = 4, NB = (H_ITERS + HB - 1) / HB;
             const int c0 = cb * KC;
+#pragma unroll 1
+            for (int b = 0; b < NB; ++b) {
+                u32x4 hreg[HB]; int hl[HB]; bool hk[HB]; int hc[HB];
 #pragma unroll
-            for (int i = 0; i < H_ITERS; ++i) {
-                bool ok = hok[i] && (c0 + hchunk[i]) < a.Cin;
-                hreg[i] = *(const u32x4*)(xg + (ok ? (size_t)hoff[i] + c0 + hchunk[i] : (size_t)0));
-            }
-            if (has_pro) {
-#pragma unroll
-                for (int i = 0; i < H_ITERS; ++i) {
-                    int c = c0 + hchunk[i];
-                    c = c < a.Cin ? c : 0;
-                    float f[EPC];
-                    Vec16<T>::unpack(hreg[i], f);
-#pragma unroll
-                    for (int j = 0; j < EPC; j += 4) {
-                        f32x4 s4 = *(const f32x4*)(a.pro_scale + c + j), t4 = *(const f32x4*)(a.pro_shift + c + j);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) f[j + q] = fmaxf(fmaf(f[j + q], s4[q], t4[q]), relu_lo);
-                    }
-                    hreg[i] = Vec16<T>::pack(f);
+                for (int i = 0; i < HB; ++i) {
+                    const int q = tid + (b * HB + i) * NT;
+                    const int pix = q / CPR, ch = q % CPR;
+                    const int hy = pix / HPITCH, hx = pix - hy * HPITCH;
+                    const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+                    const int c = c0 + ch * EPC;
+                    const bool inr = q < NPIX * CPR;
+                    const bool ok = inr && c < a.Cin && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    hk[i] = ok; hc[i] = ok ? c : 0;
+                    hl[i] = inr ? swz_off<CPR>(pix, ch) : -1;
+                    hreg[i] = *(const u32x4*)(xg + (ok ? (size_t)(iy * a.W + ix) * a.ldx + c : (size_t)0));
                 }
-            }
-            const u32x4 z = {0u, 0u, 0u, 0u};
+                if (has_pro) {
 #pragma unroll
-            for (int i = 0; i < H_ITERS; ++i) {
-                bool ok = hok[i] && (c0 + hchunk[i]) < a.Cin;
-                if (hlds[i] >= 0) *(u32x4*)(s_halo + hlds[i]) = ok ? hreg[i] : z;
+                    for (int i = 0; i < HB; ++i) {
+                        float f[EPC];
+                        Vec16<T>::unpack(hreg[i], f);
+#pragma unroll
+                        for (int j = 0; j < EPC; j += 4) {
+                            f32x4 s4 = *(const f32x4*)(a.pro_scale + hc[i] + j), t4 = *(const f32x4*)(a.pro_shift + hc[i] + j);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) f[j + q] = fmaxf(fmaf(f[j + q], s4[q], t4[q]), relu_lo);
+                        }
+                        hreg[i] = Vec16<T>::pack(f);
+                    }
+                }
+                const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int i = 0; i < HB; ++i)
+                    if (hl[i] >= 0) *(u32x4*)(s_halo + hl[i]) = hk[i] ? hreg[i] : z;
             }
         }
         store_w(wbuf);
         __syncthreads();
+#pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             // prefetch the next weight tile (next tap, or tap 0 of the next channel block)
             const bool more = (tap + 1 < 9) || (cb + 1 < ncb);
@@ -227,29 +224,89 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_tile_fwd_
     }
     constexpr int CH = BN / EPC;
     T* __restrict__ yg = (T*)a.y + (size_t)n * a.H * a.W * a.ldy;
-    for (int p = tid; p < 256 * CH; p += NT) {
-        int row = p / CH, ch = p - row * CH;
-        int col = n0 + ch * EPC;
-        if (col < a.Cout) {
+    constexpr bool bnb = BNEPI;
+    const T* __restrict__ bx = (const T*)a.epi.bn_x + (size_t)n * a.H * a.W * a.epi.ld_bn_x;
+    float e1[EPC], e2[EPC], esc[EPC], esh[EPC], emu[EPC], eis[EPC];
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) e1[j] = e2[j] = 0.f;
+    if (bnb) {   // NT % CH == 0: the channel chunk of a thread is loop-invariant -> per-channel constants in registers
+        const int colf = n0 + (tid % CH) * EPC;
+        const int cs = colf < a.Cout ? colf : 0;
+#pragma unroll
+        for (int j = 0; j < EPC; j += 4) {
+            f32x4 v0 = *(const f32x4*)(a.epi.scale + cs + j), v1 = *(const f32x4*)(a.epi.shift + cs + j);
+            f32x4 v2 = *(const f32x4*)(a.epi.mean + cs + j), v3 = *(const f32x4*)(a.epi.invstd + cs + j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { esc[j + q] = v0[q]; esh[j + q] = v1[q]; emu[j + q] = v2[q]; eis[j + q] = v3[q]; }
+        }
+    }
+    constexpr int S_ITERS = (256 * CH) / NT;
+    static_assert((256 * CH) % NT == 0, "store loop must divide evenly");
+    const int colv = n0 + (tid % CH) * EPC;
+    const bool cok = colv < a.Cout;
+    u32x4 xr[S_ITERS];
+    if (bnb) {
+#pragma unroll
+        for (int i = 0; i < S_ITERS; ++i) {
+            int row = (tid + i * NT) / CH;
             size_t opix = (size_t)(ty0 + (row >> 4)) * a.W + tx0 + (row & 15);
-            *(u32x4*)(yg + opix * a.ldy + col) = *(const u32x4*)(so + row * BN + ch * EPC);
+            xr[i] = *(const u32x4*)(bx + (cok ? opix * a.epi.ld_bn_x + colv : (size_t)0));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < S_ITERS; ++i) {
+        int p = tid + i * NT;
+        int row = p / CH, ch = p - row * CH;
+        size_t opix = (size_t)(ty0 + (row >> 4)) * a.W + tx0 + (row & 15);
+        u32x4 v = *(const u32x4*)(so + row * BN + ch * EPC);
+        if (bnb) {
+            float g[EPC], xv[EPC];
+            Vec16<T>::unpack(v, g);
+            Vec16<T>::unpack(xr[i], xv);
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) {
+                if (a.epi.relu && !(fmaf(xv[j], esc[j], esh[j]) > 0.f)) g[j] = 0.f;
+                if (!cok) g[j] = 0.f;
+                e1[j] += g[j];
+                e2[j] = fmaf(g[j], (xv[j] - emu[j]) * eis[j], e2[j]);
+            }
+            v = Vec16<T>::pack(g);
+        }
+        if (cok) *(u32x4*)(yg + opix * a.ldy + colv) = v;
+    }
+    if (bnb) {
+        __syncthreads();
+        for (int i = tid; i < 2 * BN; i += NT) s_sum[i] = 0.f;
+        __syncthreads();
+        const int ch = tid % CH;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) { atomicAdd(&s_sum[ch * EPC + j], e1[j]); atomicAdd(&s_sq[ch * EPC + j], e2[j]); }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.Cout) {
+            atomicAdd(&a.epi.sums[n0 + tid], (double)s_sum[tid]);
+            atomicAdd(&a.epi.sums[a.Cout + n0 + tid], (double)s_sq[tid]);
         }
     }
 }
 
-template <typename T, int BN, int WM, int WN, int CPR> static int launch_tile_fwd(const TileArgs& a, hipStream_t st)
+template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI> static int launch_tile_fwd_i(const TileArgs& a, hipStream_t st)
 {
     constexpr int NT = (256 / WM) * (BN / WN) * 64;
     constexpr int MAIN = NPIX * CPR * 16 + 2 * BN * CPR * 16;
     constexpr int EPI = 256 * BN * (int)sizeof(T) + 2 * BN * 4;
     constexpr int LDS = MAIN > EPI ? MAIN : EPI;
-    auto kern = conv3x3_tile_fwd_kernel<T, BN, WM, WN, CPR>;
+    auto kern = conv3x3_tile_fwd_kernel<T, BN, WM, WN, CPR, BNEPI>;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
     dim3 grid(a.tiles_x * a.tiles_y * a.N, cdiv(a.Cout, BN));
     hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, st, a);
     SAUNET_CHECK_LAUNCH("conv3x3_tile_fwd");
     return SAUNET_OK;
+}
+
+template <typename T, int BN, int WM, int WN, int CPR> static int launch_tile_fwd(const TileArgs& a, hipStream_t st)
+{
+    return a.epi.bn_x ? launch_tile_fwd_i<T, BN, WM, WN, CPR, true>(a, st) : launch_tile_fwd_i<T, BN, WM, WN, CPR, false>(a, st);
 }
 
 template <typename T> static int dispatch_tile_fwd(const TileArgs& a, hipStream_t st)
@@ -268,9 +325,10 @@ bool tile_fwd_supported(const saunet_conv_desc* d)
 }
 
 int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps, const float* psh,
-                 void* y, double* ssum, double* ssq, hipStream_t st)
+                 void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st)
 {
     TileArgs a;
+    if (epi) a.epi = *epi; else a.epi.bn_x = nullptr;
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.pro_scale = ps; a.pro_shift = psh; a.stat_sum = ssum; a.stat_sumsq = ssq;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Cout = d->Cout; a.ldy = d->ldy;
     a.pro_relu = d->pro_relu; a.tiles_y = d->H / TILE; a.tiles_x = d->W / TILE;

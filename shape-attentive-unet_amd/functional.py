@@ -215,8 +215,15 @@ def conv_forward_raw(x, weight, bias, stride, pad, transposed=False, pro=None, o
     return out
 
 
-def conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed=False, out=None):
-    """dx of y = conv(x, weight): a forward convolution over dy with re-packed weights."""
+def igemm_ok(t, cin, cout):
+    """mirror of igemm_supported() in csrc/conv_igemm.hip: is this (view, Cin, Cout) on the MFMA path?"""
+    epc = 8 if t.dtype == torch.bfloat16 else 4
+    return cin % epc == 0 and cout % epc == 0 and cin >= epc and cout >= 8 and ld_of(t) % epc == 0
+
+
+def conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed=False, out=None, bn_epi=None):
+    """dx of y = conv(x, weight): a forward convolution over dy with re-packed weights.
+    bn_epi = (bn_x, BNParams, relu, sums): fuse the reduction pass of the BatchNorm backward that consumes dx."""
     dy = nhwc(dy)
     n, cin, h, w = x_shape
     if out is None:
@@ -231,6 +238,15 @@ def conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed=False, out=None)
             raise RuntimeError("dgrad: only stride-1 convolutions need an input gradient on this path")
         wp = PACKS.get(weight, L.PACK_DGRAD, dy.dtype)
         d = _desc(dy, cin, ld_of(out), h, w, kh, kw, 1, kh - 1 - pad)
+    if bn_epi is not None:
+        bx, p, relu, sums = bn_epi
+        e = L.BnEpilogue()
+        e.bn_x, e.ld_bn_x, e.relu = bx.data_ptr(), ld_of(bx), 1 if relu else 0
+        e.scale, e.shift, e.mean, e.invstd = p.scale.data_ptr(), p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr()
+        e.sums = sums.data_ptr()
+        L.call("saunet_conv2d_forward_ex", C.byref(d), dy.data_ptr(), wp.data_ptr(), None, None, None, out.data_ptr(), None, None,
+               C.byref(e), L.stream())
+        return out
     L.call("saunet_conv2d_forward", C.byref(d), dy.data_ptr(), wp.data_ptr(), None, None, None, out.data_ptr(), None, None,
            L.stream())
     return out
@@ -304,7 +320,8 @@ def affine_act(x, scale, shift, relu, residual=None, out=None):
     return out
 
 
-def bn_backward(dy, x, p, relu, count, training, residual=None, dx=None, accumulate=False, want_dres=False, sync_group=None):
+def bn_backward(dy, x, p, relu, count, training, residual=None, dx=None, accumulate=False, want_dres=False, sync_group=None,
+                presums=None):
     """Returns (dx, dres, dgamma, dbeta).  x is the tensor BN normalised (pre-affine).
     sync_group: all-reduce the two per-channel sums over that process group between the reduce and the
     apply kernel (SynchronizedBatchNorm semantics, lib/nn/modules/batchnorm.py:98-139); `count` must then
@@ -313,13 +330,17 @@ def bn_backward(dy, x, p, relu, count, training, residual=None, dx=None, accumul
     n, c, h, w = x.shape
     P = n * h * w
     dev = x.device
-    sums = zeros_f64(2 * c, device=dev)
     if residual is not None:
         residual = nhwc(residual)
     rp, rl = L.ptr(residual), (ld_of(residual) if residual is not None else 0)
     dt = L.dtype_code(x)
-    L.call("saunet_bn_backward_reduce", dt, dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), rp, rl, p.scale.data_ptr(),
-           p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), 1 if relu else 0, sums.data_ptr(), P, c, L.stream())
+    if presums is not None:
+        # dy is already g = dy*[relu mask] and the two sums were taken in the producing dgrad kernel's epilogue
+        sums, relu = presums, False
+    else:
+        sums = zeros_f64(2 * c, device=dev)
+        L.call("saunet_bn_backward_reduce", dt, dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), rp, rl, p.scale.data_ptr(),
+               p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), 1 if relu else 0, sums.data_ptr(), P, c, L.stream())
     if sync_group is not None and training:
         torch.distributed.all_reduce(sums, group=sync_group)
     if dx is None:
@@ -854,11 +875,13 @@ class _DenseBlock(torch.autograd.Function):
             xin = buf[:, :cin]
             dz2 = dbuf[:, cin:cin + growth]
             dw2 = conv_wgrad_raw(z1, dz2, c2w, 1, 1, pro=(p2.scale, p2.shift, True))
-            da2 = conv_dgrad_raw(dz2, c2w, z1.shape, 1, 1)
-            dz1, _, dg2, db2 = bn_backward(da2, z1, p2, True, count, training, dx=da2)
+            s2 = zeros_f64(2 * z1.shape[1], device=buf.device)
+            da2 = conv_dgrad_raw(dz2, c2w, z1.shape, 1, 1, bn_epi=(z1, p2, True, s2))
+            dz1, _, dg2, db2 = bn_backward(da2, z1, p2, True, count, training, dx=da2, presums=s2)
             dw1 = conv_wgrad_raw(xin, dz1, c1w, 1, 0, pro=(p1.scale, p1.shift, True))
-            da1 = conv_dgrad_raw(dz1, c1w, (n, cin, h, w), 1, 0)
-            _, _, dg1, db1 = bn_backward(da1, xin, p1, True, count, training, dx=dbuf[:, :cin], accumulate=True)
+            s1 = zeros_f64(2 * cin, device=buf.device)
+            da1 = conv_dgrad_raw(dz1, c1w, (n, cin, h, w), 1, 0, bn_epi=(xin, p1, True, s1))
+            _, _, dg1, db1 = bn_backward(da1, xin, p1, True, count, training, dx=dbuf[:, :cin], accumulate=True, presums=s1)
             grads[6 * l:6 * l + 6] = [dg1, db1, dw1, dg2, db2, dw2]
         dx0 = dbuf[:, :c0] if ctx.needs_input_grad[0] else None
         return (dx0, None, None) + tuple(grads) + (None,) * (4 * nl)
@@ -902,8 +925,9 @@ class _Transition(torch.autograd.Function):
         dz = new_act(n, co, h, w, dy.dtype, dy.device)
         L.call("saunet_pool2x2_backward", L.dtype_code(dy), 0, None, dy.data_ptr(), n, h, w, co, 0, ld_of(dy), dz.data_ptr(), ld_of(dz), 0, L.stream())
         dw = conv_wgrad_raw(buf, dz, weight, 1, 0, pro=(p.scale, p.shift, True))
-        da = conv_dgrad_raw(dz, weight, buf.shape, 1, 0)
-        dbuf, _, dg, db = bn_backward(da, buf, p, True, count, training, dx=da)
+        sb = zeros_f64(2 * c, device=buf.device)
+        da = conv_dgrad_raw(dz, weight, buf.shape, 1, 0, bn_epi=(buf, p, True, sb))
+        dbuf, _, dg, db = bn_backward(da, buf, p, True, count, training, dx=da, presums=sb)
         return dbuf, None, dg, db, None, None, dw, None, None, None
 
 

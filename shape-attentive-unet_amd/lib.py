@@ -21,6 +21,11 @@ class ConvDesc(C.Structure):
         "transposed", "pro_relu")]
 
 
+class BnEpilogue(C.Structure):
+    _fields_ = [("bn_x", C.c_void_p), ("ld_bn_x", C.c_int32), ("relu", C.c_int32), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("mean", C.c_void_p), ("invstd", C.c_void_p), ("sums", C.c_void_p)]
+
+
 class PackList(C.Structure):
     _fields_ = [("count", C.c_int32), ("mode", C.c_int32 * 64), ("dims", (C.c_int32 * 4) * 64), ("src", C.c_void_p * 64),
                 ("dst", C.c_void_p * 64)]
@@ -36,6 +41,7 @@ _SIGS = {
     "saunet_pack_weight": [i32, i32, vp, i32, i32, i32, i32, vp, vp],
     "saunet_pack_weight_multi": [C.POINTER(PackList), i32, vp],
     "saunet_conv2d_forward": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "saunet_conv2d_forward_ex": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(BnEpilogue), vp],
     "saunet_conv2d_wgrad": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i64, vp],
     "saunet_conv2d_wgrad_workspace": [C.POINTER(ConvDesc)],
     "saunet_channel_sum": [i32, vp, i64, i32, i32, vp, vp],
