@@ -193,6 +193,40 @@ template <typename T, int CIN_PAD> __global__ __launch_bounds__(256) void pointw
     }
 }
 
+// Cout small, Cin large (the C -> 1 projections c3/c4/c5): one WAVE per (pixel, cout), lanes stride the channels
+template <typename T> __global__ __launch_bounds__(256) void pointwise_dot_kernel(PwArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const long total = a.P * a.Cout;
+    const float relu_lo = a.pro_relu ? 0.f : -__builtin_inff();
+    for (long i = blockIdx.x * 4L + (threadIdx.x >> 6); i < total; i += (long)gridDim.x * 4) {
+        const long p = i / a.Cout; const int co = (int)(i - p * a.Cout);
+        const T* xr = (const T*)a.x + p * a.ldx;
+        const T* wr = (const T*)a.w + (long)co * a.Cin;
+        float acc = 0.f;
+        for (int c = lane; c < a.Cin; c += 64) {
+            float v = Elem<T>::load(xr + c);
+            if (a.ps) v = fmaxf(fmaf(v, a.ps[c], a.psh[c]), relu_lo);
+            acc = fmaf(v, Elem<T>::load(wr + c), acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) Elem<T>::store((T*)a.y + p * a.ldy + co, acc + (a.bias ? a.bias[co] : 0.f));
+    }
+}
+
+// Cin == 1: y[p][co] = x[p]*w[co] + b[co]  (the dgrad of the C -> 1 projections c3/c4/c5/phi/fuse): pure streaming
+template <typename T> __global__ __launch_bounds__(256) void pointwise_cin1_kernel(PwArgs a)
+{
+    const unsigned total = (unsigned)(a.P * a.Cout);
+    const float relu_lo = a.pro_relu ? 0.f : -__builtin_inff();
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned p = i / (unsigned)a.Cout, co = i - p * (unsigned)a.Cout;
+        float v = Elem<T>::load((const T*)a.x + (size_t)p * a.ldx);
+        if (a.ps) v = fmaxf(fmaf(v, a.ps[0], a.psh[0]), relu_lo);
+        Elem<T>::store((T*)a.y + (size_t)p * a.ldy + co, fmaf(v, Elem<T>::load((const T*)a.w + co), a.bias ? a.bias[co] : 0.f));
+    }
+}
+
 // dw[co][ci] += sum_p dy[p][co] * a[p][ci]: rows staged in LDS, each thread owns <= WPT weights
 struct PwWgradArgs {
     const void* x; const void* dy; float* dw; const float* ps; const float* psh;
@@ -355,6 +389,22 @@ int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const voi
         return SAUNET_OK;
     }
     long total = a.P * a.Cout;
+    if (d->Cin == 1 && ssum == nullptr && total < (1L << 31)) {
+        long blocks = (total + 1023) / 1024; if (blocks > 8192) blocks = 8192;
+        if (d->dtype == SAUNET_F32) hipLaunchKernelGGL(pointwise_cin1_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else if (d->dtype == SAUNET_BF16) hipLaunchKernelGGL(pointwise_cin1_kernel<u16>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else return set_error(SAUNET_BAD_DTYPE, "conv: dtype %d", d->dtype);
+        SAUNET_CHECK_LAUNCH("pointwise_cin1");
+        return SAUNET_OK;
+    }
+    if (d->Cin >= 128 && d->Cout <= 4 && ssum == nullptr) {
+        long blocks = (total + 3) / 4; if (blocks > 16384) blocks = 16384;
+        if (d->dtype == SAUNET_F32) hipLaunchKernelGGL(pointwise_dot_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else if (d->dtype == SAUNET_BF16) hipLaunchKernelGGL(pointwise_dot_kernel<u16>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else return set_error(SAUNET_BAD_DTYPE, "conv: dtype %d", d->dtype);
+        SAUNET_CHECK_LAUNCH("pointwise_dot");
+        return SAUNET_OK;
+    }
     dim3 grid((unsigned)((total + 256 * PW_IT - 1) / (256 * PW_IT)));
     if (d->dtype == SAUNET_F32) hipLaunchKernelGGL(pointwise_fwd_kernel<float>, grid, dim3(256), 0, st, a);
     else if (d->dtype == SAUNET_BF16) hipLaunchKernelGGL(pointwise_fwd_kernel<u16>, grid, dim3(256), 0, st, a);

@@ -336,6 +336,10 @@ template <typename T> static int dispatch_fwd(const IgemmArgs& a, int phases, hi
     } else if (a.Cout <= 64) {
         return narrow ? launch_fwd<T, 128, 64, 64, 32, 4>(a, phases, st) : launch_fwd<T, 128, 64, 64, 32, 8>(a, phases, st);
     } else {
+        // small problems (low-resolution maps): 64x64 tiles so that the grid still covers the 256 CUs
+        const long blocks128 = (long)cdiv(a.M, 128) * cdiv(a.Cout, 128) * phases;
+        if (blocks128 < 384)
+            return narrow ? launch_fwd<T, 64, 64, 32, 32, 4>(a, phases, st) : launch_fwd<T, 64, 64, 32, 32, 8>(a, phases, st);
         return narrow ? launch_fwd<T, 128, 128, 64, 64, 4>(a, phases, st) : launch_fwd<T, 128, 128, 64, 64, 8>(a, phases, st);
     }
 }

@@ -40,20 +40,23 @@ template <typename T> __global__ __launch_bounds__(256) void bilinear_fwd_kernel
     }
 }
 
-// gather form of the adjoint (deterministic, no atomics, dtype-agnostic): for every INPUT pixel visit
-// the output pixels whose two source rows/cols can include it and re-derive their weights exactly.
-template <typename T> __global__ __launch_bounds__(256) void bilinear_bwd_kernel(BilArgs a)
+// gather form of the adjoint (deterministic, no atomics, dtype-agnostic): for every INPUT pixel visit the output
+// pixels whose two source rows/cols can include it and re-derive their weights exactly.  V channels per thread.
+template <typename T, int V> __global__ __launch_bounds__(256) void bilinear_bwd_kernel(BilArgs a)
 {
     // here src = dy [N,Ho,Wo,C] (lds), dst = dx [N,H,W,C] (ldd)
-    const long total = (long)a.N * a.H * a.W * a.C;
+    const int CV = a.C / V;
+    const long total = (long)a.N * a.H * a.W * CV;
     const T* dy = (const T*)a.src; T* dx = (T*)a.dst;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        int c = (int)(i % a.C); long t = i / a.C;
+        int c = (int)(i % CV) * V; long t = i / CV;
         int ix = (int)(t % a.W); t /= a.W; int iy = (int)(t % a.H); int n = (int)(t / a.H);
         int oy_lo = 0, oy_hi = a.Ho - 1, ox_lo = 0, ox_hi = a.Wo - 1;
-        if (a.sy > 0.f) { oy_lo = max(0, (int)floorf((iy - 1) / a.sy) - 1); oy_hi = min(a.Ho - 1, (int)ceilf((iy + 1) / a.sy) + 1); }
-        if (a.sx > 0.f) { ox_lo = max(0, (int)floorf((ix - 1) / a.sx) - 1); ox_hi = min(a.Wo - 1, (int)ceilf((ix + 1) / a.sx) + 1); }
-        float acc = 0.f;
+        if (a.sy > 0.f) { oy_lo = max(0, (int)floorf((iy - 1) / a.sy)); oy_hi = min(a.Ho - 1, (int)ceilf((iy + 1) / a.sy)); }
+        if (a.sx > 0.f) { ox_lo = max(0, (int)floorf((ix - 1) / a.sx)); ox_hi = min(a.Wo - 1, (int)ceilf((ix + 1) / a.sx)); }
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
         const T* b = dy + (long)n * a.Ho * a.Wo * a.lds + c;
         for (int oy = oy_lo; oy <= oy_hi; ++oy) {
             int y0, y1; float ly; bil_coord(oy, a.sy, a.H, y0, y1, ly);
@@ -63,12 +66,30 @@ template <typename T> __global__ __launch_bounds__(256) void bilinear_bwd_kernel
                 int x0, x1; float lx; bil_coord(ox, a.sx, a.W, x0, x1, lx);
                 float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
                 if (wx == 0.f) continue;
-                acc = fmaf(wy * wx, Elem<T>::load(b + ((long)oy * a.Wo + ox) * a.lds), acc);
+                const float wgt = wy * wx;
+                const T* q = b + ((long)oy * a.Wo + ox) * a.lds;
+                if constexpr (V == 1) acc[0] = fmaf(wgt, Elem<T>::load(q), acc[0]);
+                else {
+                    float f[V];
+                    Vec16<T>::unpack(*(const u32x4*)q, f);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) acc[j] = fmaf(wgt, f[j], acc[j]);
+                }
             }
         }
         T* o = dx + (((long)n * a.H + iy) * a.W + ix) * a.ldd + c;
-        if (a.accumulate) acc += Elem<T>::load(o);
-        Elem<T>::store(o, acc);
+        if constexpr (V == 1) {
+            if (a.accumulate) acc[0] += Elem<T>::load(o);
+            Elem<T>::store(o, acc[0]);
+        } else {
+            if (a.accumulate) {
+                float f[V];
+                Vec16<T>::unpack(*(const u32x4*)o, f);
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] += f[j];
+            }
+            *(u32x4*)o = Vec16<T>::pack(acc);
+        }
     }
 }
 
@@ -350,10 +371,13 @@ int saunet_bilinear_forward(int dtype, const void* x, int N, int H, int W, int C
 int saunet_bilinear_backward(int dtype, const void* dy, int N, int Ho, int Wo, int C, int lddy, void* dx, int H, int W, int lddx, int accumulate, void* stream)
 {
     BilArgs a{dy, dx, N, H, W, C, lddy, Ho, Wo, lddx, Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f, accumulate};
-    const long total = (long)N * H * W * C;
-#define CALL(TT) hipLaunchKernelGGL(bilinear_bwd_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a)
-    DISPATCH_T(dtype, CALL);
-#undef CALL
+    const int epc = dtype == SAUNET_BF16 ? 8 : 4;
+    const bool vec = C % epc == 0 && lddy % epc == 0 && lddx % epc == 0 && !(((uintptr_t)dy | (uintptr_t)dx) & 15);
+    const long total = (long)N * H * W * (vec ? C / epc : C);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SAUNET_F32) { if (vec) hipLaunchKernelGGL((bilinear_bwd_kernel<float, 4>), dim3(grid_for(total)), dim3(256), 0, st, a); else hipLaunchKernelGGL((bilinear_bwd_kernel<float, 1>), dim3(grid_for(total)), dim3(256), 0, st, a); }
+    else if (dtype == SAUNET_BF16) { if (vec) hipLaunchKernelGGL((bilinear_bwd_kernel<u16, 8>), dim3(grid_for(total)), dim3(256), 0, st, a); else hipLaunchKernelGGL((bilinear_bwd_kernel<u16, 1>), dim3(grid_for(total)), dim3(256), 0, st, a); }
+    else return set_error(SAUNET_BAD_DTYPE, "dtype %d", dtype);
     SAUNET_CHECK_LAUNCH("bilinear_backward");
     return SAUNET_OK;
 }

@@ -1,0 +1,85 @@
+"""Host-side logic of the training loop (CPU): schedules, grouping, metrics, checkpoint policy -- mirrors
+/root/reference/train.py:150-216,294-329 and utils.py:119-140."""
+import math
+
+import numpy as np
+import torch
+
+
+def test_cosine_and_resume_lr():
+    import saunet_amd
+    from saunet_amd import optim, train
+    assert optim.cosine_lr(5e-4, 0, 120) == 5e-4
+    assert abs(optim.cosine_lr(1e-3, 60, 120) - 1e-3 * 0.5 * (1 + math.cos(3.14159 * 0.5))) < 1e-12
+    assert optim.cosine_lr(1e-3, 120, 120) < 1e-9
+    assert abs(train.poly_resume_lr(1e-3, 31, 120) - 1e-3 * (1 - 30 / 120) ** 0.9) < 1e-12
+
+
+def test_radam_schedule_matches_reference_formula():
+    import saunet_amd
+    from saunet_amd.optim import FusedRAdam
+    # radam.py:52-66 evaluated by hand for a few steps
+    for step in (1, 2, 5, 6, 100, 1000):
+        beta1, beta2, lr = 0.9, 0.999, 1e-4
+        b2t = beta2 ** step
+        nmax = 2 / (1 - beta2) - 1
+        nsma = nmax - 2 * step * b2t / (1 - b2t)
+        if nsma >= 5:
+            want = lr * math.sqrt((1 - b2t) * (nsma - 4) / (nmax - 4) * (nsma - 2) / nsma * nmax / (nmax - 2)) / (1 - beta1 ** step)
+        else:
+            want = lr / (1 - beta1 ** step)
+        got_n, got = FusedRAdam.schedule(step, lr, beta1, beta2)
+        assert abs(got - want) < 1e-15 and abs(got_n - nsma) < 1e-9
+    assert FusedRAdam.schedule(5, 1e-4, 0.9, 0.999)[0] < 5 <= FusedRAdam.schedule(6, 1e-4, 0.9, 0.999)[0]
+
+
+def test_intersection_and_union_and_dice():
+    import saunet_amd
+    from saunet_amd import train
+    from oracle import saunet_ref as R
+    r = np.random.default_rng(0)
+    pred, lab = r.integers(0, 4, (32, 32)), r.integers(0, 4, (32, 32))
+    a, u = train.intersection_and_union(pred, lab, 4)
+    a2, u2 = R.intersection_and_union(pred, lab, 4)
+    assert (a == a2).all() and (u == u2).all()
+    d = train.dice_from_iu(a, u)
+    for c in range(4):
+        inter = ((pred == c) & (lab == c)).sum()
+        want = 2 * inter / ((pred == c).sum() + (lab == c).sum())
+        assert abs(d[c] - want) < 1e-9
+
+
+def test_checkpoint_policy():
+    import saunet_amd
+    from saunet_amd import train
+    best = {"class": [0.0, 0.0, 0.0], "mean": 0.0}
+    assert not train.should_checkpoint(10, [0.9, 0.9, 0.9], best, 120)      # nothing before epoch 16 ...
+    assert train.should_checkpoint(50, [0.1, 0.1, 0.1], best, 120)           # ... except every 50 epochs
+    assert train.should_checkpoint(16, [0.5, 0.4, 0.3], best, 120)           # new best
+    assert not train.should_checkpoint(17, [0.4, 0.3, 0.2], best, 120)
+    assert train.should_checkpoint(18, [0.4, 0.45, 0.2], best, 120)          # one class improved
+    assert train.should_checkpoint(120, [0.0, 0.0, 0.0], best, 120)          # last epoch
+
+
+def test_synthetic_dataset_format():
+    import saunet_amd
+    from saunet_amd import train
+    ds = train.SyntheticSlices(4, 64)
+    b = train.collate([ds[0], ds[1]])
+    assert b["image"].shape == (2, 3, 64, 64) and b["image"].dtype == torch.float32
+    assert b["mask"][0].shape == (2, 64, 64) and b["mask"][0].dtype == torch.float64    # the loader hands float64 labels
+    assert b["mask"][1].shape == (2, 1, 64, 64) and set(b["mask"][1].unique().tolist()) <= {0.0, 1.0}
+    assert torch.equal(b["image"][:, 0], b["image"][:, 1])                                # one plane replicated x3
+    assert abs(float(b["image"][0, 0].mean())) < 1e-4 and abs(float(b["image"][0, 0].std()) - 1) < 1e-2
+
+
+def test_mask_to_edges_matches_loader_formulation():
+    import saunet_amd
+    from saunet_amd import data
+    from oracle import saunet_ref as R
+    from tests.golden_util import load
+    g = load("loss.npz")
+    assert (data.mask_to_edges(g["m2e_mask"]) == g["m2e_edge"]).all()          # fixture made by the REAL reference
+    r = np.random.default_rng(1)
+    m = r.integers(0, 4, (24, 40))
+    assert (data.mask_to_edges(m) == R.mask_to_edges(m)).all()
