@@ -38,9 +38,12 @@ def parse():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--graph-dp", action="store_true", help="N>1: capture fwd+bwd (incl. the SyncBN all-reduces) in a hipGraph too; "
+                    "default for N>1 is eager launches with the bucket all-reduces overlapped with backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "radam"])
+    ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel probe (the command profiles/ was made with)")
     return ap.parse_args()
 
 
@@ -89,6 +92,17 @@ def kernel_roofline(S, dtype, batch, size):
             "gbs": round(gbs, 1), "flop_per_byte": round(ai, 1)}
 
 
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of the probe kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json), or None."""
+    path = os.path.join(ROOT, "profiles", "roofline_pmc.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        return rec.get("traffic_bytes_per_launch") if rec.get("kernel") == kernel_label else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(size):
     """The CPU oracle (oracle/saunet_ref.py, the pinned restatement of the reference's PyTorch path) timed on this
     host: B=2 slices, fwd+bwd+SGD, a bounded number of iterations."""
@@ -123,6 +137,12 @@ def main():
     args = parse()
     import saunet_amd as S
     from saunet_amd import dp, data, optim
+    if args.roofline_only:
+        torch.cuda.set_device(0)
+        r = kernel_roofline(S, torch.bfloat16 if args.dtype == "bf16" else torch.float32, args.batch, args.size)
+        r["traffic"] = pmc_traffic(r["kernel"])
+        print(json.dumps({"roofline": r}), flush=True)
+        return
     rank, local, world = dp.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -135,7 +155,8 @@ def main():
     sm = S.SegmentationModule(S.DualLoss(mode="train"), net, 4).train()
     dp.broadcast_parameters(net)
     opt = optim.create_optimizers(net, args.optimizer, lr=5e-4, momentum=0.9, weight_decay=1e-4)[0]
-    buckets = dp.GradientBuckets(list(net.parameters()), bucket_mb=32.0, overlap=False) if world > 1 else None
+    use_graph = (not args.no_graph) and (world == 1 or args.graph_dp)
+    buckets = dp.GradientBuckets(list(net.parameters()), bucket_mb=32.0, overlap=not use_graph) if world > 1 else None
     img, seg, edge = data.synthetic_batch(args.batch, args.size, args.size, seed=304 + 1000 * rank, device=dev)
     feed = {"image": img, "mask": (seg, edge)}
 
@@ -143,7 +164,7 @@ def main():
         sm.zero_grad(set_to_none=True)
         loss, _ = sm(feed, 1)
         loss.backward()
-        return loss
+        return loss.detach()     # never keep the autograd graph (and its AccumulateGrad nodes) alive across steps
 
     def tail():
         if buckets is not None:
@@ -162,10 +183,11 @@ def main():
     # warm-up (also creates optimiser state and fills allocator pools)
     for _ in range(max(args.warmup, 2)):
         loss = eager_step()
+    del loss
     torch.cuda.synchronize()
-    mode = "eager"
+    mode = "eager" if world == 1 else "eager, bucketed all-reduce overlapped with backward"
     graph = None
-    if not args.no_graph:
+    if use_graph:
         try:
             opt.upload_hyper()
             graph = torch.cuda.CUDAGraph()
@@ -229,6 +251,7 @@ def main():
         if not args.no_roofline:
             try:
                 out["roofline"] = kernel_roofline(S, dtype, args.batch, args.size)
+                out["roofline"]["traffic"] = pmc_traffic(out["roofline"]["kernel"])
             except Exception as e:
                 out["roofline"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
