@@ -17,8 +17,12 @@ int igemm_forward(const saunet_conv_desc* d, const void* x, const void* w, const
 int igemm_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw, hipStream_t st);
 bool tile_fwd_supported(const saunet_conv_desc* d);
 bool tile_wgrad_supported(const saunet_conv_desc* d);
+bool tile_wgrad_unaligned_supported(const saunet_conv_desc* d);
+// MFMA tile wgrad with scalar staging for odd channel counts: correct, but measured SLOWER than pointwise_wgrad_kernel
+// on the shape-stream layers (scalar 2-byte global loads dominate) -> kept off until the staging is made cooperative
+constexpr bool kUnalignedTileWgrad = false;
 int tile_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw,
-               void* ws, size_t ws_bytes, size_t* need, hipStream_t st);
+               void* ws, size_t ws_bytes, size_t* need, bool aligned, hipStream_t st);
 int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps, const float* psh,
                  void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st);
 
@@ -417,7 +421,12 @@ int64_t saunet_conv2d_wgrad_workspace(const saunet_conv_desc* d)
 {
     if (igemm_supported(d) && tile_wgrad_supported(d)) {
         size_t need = 0;
-        int rc = tile_wgrad(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &need, nullptr);
+        int rc = tile_wgrad(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &need, true, nullptr);
+        return rc == SAUNET_OK ? (int64_t)need : (int64_t)rc;
+    }
+    if (kUnalignedTileWgrad && !igemm_supported(d) && tile_wgrad_unaligned_supported(d)) {
+        size_t need = 0;
+        int rc = tile_wgrad(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &need, false, nullptr);
         return rc == SAUNET_OK ? (int64_t)need : (int64_t)rc;
     }
     return 0;
@@ -428,9 +437,11 @@ int saunet_conv2d_wgrad(const saunet_conv_desc* d, const void* x, const void* dy
 {
     hipStream_t st = (hipStream_t)stream;
     if (igemm_supported(d)) {
-        if (tile_wgrad_supported(d)) return tile_wgrad(d, x, dy, ps, psh, dw, workspace, (size_t)workspace_bytes, nullptr, st);
+        if (tile_wgrad_supported(d)) return tile_wgrad(d, x, dy, ps, psh, dw, workspace, (size_t)workspace_bytes, nullptr, true, st);
         return igemm_wgrad(d, x, dy, ps, psh, dw, st);
     }
+    if (kUnalignedTileWgrad && tile_wgrad_unaligned_supported(d))
+        return tile_wgrad(d, x, dy, ps, psh, dw, workspace, (size_t)workspace_bytes, nullptr, false, st);
     if (!is_pointwise(d)) return set_error(SAUNET_UNSUPPORTED, "wgrad: %dx%d Cin=%d Cout=%d has no kernel", d->KH, d->KW, d->Cin, d->Cout);
     const int nW = d->Cin * d->Cout;
     PwWgradArgs a{x, dy, dw, ps, psh, (long)d->N * d->H * d->W, d->Cin, d->Cout, d->ldx, d->ldy, d->pro_relu, 0, (long)d->Cin, 1, 32};

@@ -363,7 +363,21 @@ __device__ __forceinline__ void tr_read2(const unsigned char* p0, int pitch4, u3
     out[0] = a[0]; out[1] = a[1]; out[2] = b[0]; out[3] = b[1];
 }
 
-template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KSPLIT>
+// 16-byte chunk of EPC channels starting at channel c of a pixel row; the scalar form serves channel counts /
+// strides that are not multiples of the chunk (the shape stream's C = 33, 17, 9, 1 ...)
+template <typename T, bool ALIGNED> __device__ __forceinline__ u32x4 load_chunk(const T* row, int c, int C)
+{
+    if constexpr (ALIGNED) return *(const u32x4*)(row + c);
+    else {
+        constexpr int EPC = 16 / sizeof(T);
+        float f[EPC];
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) f[j] = (c + j < C) ? Elem<T>::load(row + c + j) : 0.f;
+        return Vec16<T>::pack(f);
+    }
+}
+
+template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KSPLIT, bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void conv_tile_wgrad_kernel(TileWgradArgs a)
 {
     constexpr int EPC = 16 / sizeof(T);
@@ -421,8 +435,8 @@ __global__ __launch_bounds__(256, 2) void conv_tile_wgrad_kernel(TileWgradArgs a
                 int q = tid + i * 256, pix = q / CHY, ch = q - pix * CHY;
                 int c = co0 + ch * EPC;
                 bool ok = (YI * 256 == NPY * CHY || q < NPY * CHY) && c < a.Cout;
-                size_t off = ok ? (((size_t)n * a.H + ty0 + pix / TILE) * a.W + tx0 + (pix % TILE)) * a.lddy + c : (size_t)0;
-                u32x4 v = *(const u32x4*)(dyg + off);
+                size_t off = ok ? (((size_t)n * a.H + ty0 + pix / TILE) * a.W + tx0 + (pix % TILE)) * a.lddy : (size_t)0;
+                u32x4 v = load_chunk<T, ALIGNED>(dyg + off, ok ? c : 0, a.Cout);
                 yreg[i] = ok ? v : z;
             }
 #pragma unroll
@@ -443,18 +457,26 @@ __global__ __launch_bounds__(256, 2) void conv_tile_wgrad_kernel(TileWgradArgs a
                 int c = ci0 + ch * EPC;
                 bool ok = (b0 + i < XI) && q < NPX * CHX && c < a.Cin && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 okx[i] = ok; cx[i] = ok ? c : 0;
-                xreg[i] = *(const u32x4*)(xg + (ok ? (((size_t)n * a.H + iy) * a.W + ix) * a.ldx + c : (size_t)0));
+                xreg[i] = load_chunk<T, ALIGNED>(xg + (ok ? (((size_t)n * a.H + iy) * a.W + ix) * a.ldx : (size_t)0), cx[i], a.Cin);
             }
             if (has_pro) {
 #pragma unroll
                 for (int i = 0; i < XB; ++i) {
                     float f[EPC];
                     Vec16<T>::unpack(xreg[i], f);
+                    if constexpr (ALIGNED) {
 #pragma unroll
-                    for (int j = 0; j < EPC; j += 4) {
-                        f32x4 s4 = *(const f32x4*)(a.pro_scale + cx[i] + j), t4 = *(const f32x4*)(a.pro_shift + cx[i] + j);
+                        for (int j = 0; j < EPC; j += 4) {
+                            f32x4 s4 = *(const f32x4*)(a.pro_scale + cx[i] + j), t4 = *(const f32x4*)(a.pro_shift + cx[i] + j);
 #pragma unroll
-                        for (int qq = 0; qq < 4; ++qq) f[j + qq] = fmaxf(fmaf(f[j + qq], s4[qq], t4[qq]), relu_lo);
+                            for (int qq = 0; qq < 4; ++qq) f[j + qq] = fmaxf(fmaf(f[j + qq], s4[qq], t4[qq]), relu_lo);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < EPC; ++j) {
+                            const int cc = cx[i] + j < a.Cin ? cx[i] + j : 0;
+                            f[j] = (cx[i] + j < a.Cin) ? fmaxf(fmaf(f[j], a.pro_scale[cc], a.pro_shift[cc]), relu_lo) : 0.f;
+                        }
                     }
                     xreg[i] = Vec16<T>::pack(f);
                 }
@@ -561,7 +583,7 @@ static int tile_wgrad_groups(int ntiles, int nchan_tiles)
     return groups;
 }
 
-template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KSPLIT> static int launch_tile_wgrad(TileWgradArgs& a, size_t ws_bytes, size_t* need, hipStream_t st)
+template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KSPLIT, bool ALIGNED = true> static int launch_tile_wgrad(TileWgradArgs& a, size_t ws_bytes, size_t* need, hipStream_t st)
 {
     constexpr int PAD = KS / 2;
     constexpr int NPX = (TR + 2 * PAD) * (TILE + 2 * PAD), NPY = TR * TILE;
@@ -572,7 +594,7 @@ template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KS
     constexpr int LDS_RED = KSPLIT > 1 ? (KSPLIT - 1) * 16 * 64 * 4 : 0;
     constexpr int LDS = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
     static_assert(LDS <= 160 * 1024, "tile does not fit LDS");
-    auto kern = conv_tile_wgrad_kernel<T, KS, TR, CO_T, CI_T, WM, WN, KSPLIT>;
+    auto kern = conv_tile_wgrad_kernel<T, KS, TR, CO_T, CI_T, WM, WN, KSPLIT, ALIGNED>;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
     a.tiles_y = a.H / TR; a.tiles_x = a.W / TILE; a.ntiles = a.N * a.tiles_y * a.tiles_x;
@@ -593,8 +615,12 @@ template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KS
     return SAUNET_OK;
 }
 
-template <typename T> static int dispatch_tile_wgrad(TileWgradArgs& a, int ks, size_t wsb, size_t* need, hipStream_t st)
+template <typename T> static int dispatch_tile_wgrad(TileWgradArgs& a, int ks, bool aligned, size_t wsb, size_t* need, hipStream_t st)
 {
+    if (!aligned) {   // pointwise layers with odd channel counts: scalar staging, 64x64 channel tile, K split over the waves
+        if (ks != 1) return set_error(SAUNET_UNSUPPORTED, "unaligned tile wgrad is 1x1 only");
+        return launch_tile_wgrad<T, 1, 16, 64, 64, 64, 64, 4, false>(a, wsb, need, st);
+    }
     // few channel tiles -> 32x32 channel tile with the 4 waves splitting the K (pixel-row) dimension: the per-block
     // partial gradient (what has to be reduced across blocks afterwards) is 4x smaller
     const bool small = (long)a.Cout * a.Cin <= 64 * 128;
@@ -614,6 +640,12 @@ template <typename T> static int dispatch_tile_wgrad(TileWgradArgs& a, int ks, s
     }
 }
 
+bool tile_wgrad_unaligned_supported(const saunet_conv_desc* d)
+{
+    return !d->transposed && d->KH == 1 && d->KW == 1 && d->pad == 0 && d->stride == 1 && d->H % TILE == 0 && d->W % TILE == 0 &&
+           d->Ho == d->H && d->Wo == d->W;
+}
+
 bool tile_wgrad_supported(const saunet_conv_desc* d)
 {
     const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1, k1 = d->KH == 1 && d->KW == 1 && d->pad == 0;
@@ -621,16 +653,16 @@ bool tile_wgrad_supported(const saunet_conv_desc* d)
 }
 
 int tile_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw,
-               void* ws, size_t ws_bytes, size_t* need, hipStream_t st)
+               void* ws, size_t ws_bytes, size_t* need, bool aligned, hipStream_t st)
 {
     TileWgradArgs a;
     a.ws = (float*)ws;
     a.x = x; a.dy = dy; a.dw = dw; a.pro_scale = ps; a.pro_shift = psh; a.pro_relu = d->pro_relu;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Cout = d->Cout; a.lddy = d->ldy;
     a.sM = (long)d->Cin * d->KH * d->KW; a.sN = (long)d->KH * d->KW;
-    if (!need && (((uintptr_t)x | (uintptr_t)dy) & 15)) return set_error(SAUNET_BAD_ALIGN, "wgrad: pointers must be 16-byte aligned");
-    if (d->dtype == SAUNET_BF16) return dispatch_tile_wgrad<u16>(a, d->KH, ws_bytes, need, st);
-    if (d->dtype == SAUNET_F32) return dispatch_tile_wgrad<float>(a, d->KH, ws_bytes, need, st);
+    if (aligned && !need && (((uintptr_t)x | (uintptr_t)dy) & 15)) return set_error(SAUNET_BAD_ALIGN, "wgrad: pointers must be 16-byte aligned");
+    if (d->dtype == SAUNET_BF16) return dispatch_tile_wgrad<u16>(a, d->KH, aligned, ws_bytes, need, st);
+    if (d->dtype == SAUNET_F32) return dispatch_tile_wgrad<float>(a, d->KH, aligned, ws_bytes, need, st);
     return set_error(SAUNET_BAD_DTYPE, "wgrad: dtype %d", d->dtype);
 }
 
