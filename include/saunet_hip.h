@@ -71,6 +71,8 @@ int saunet_conv2d_forward(const saunet_conv_desc* d, const void* x, const void* 
  * while the tile is still on chip.  bn_x is the tensor that BN normalised, same pixels/channels as y. */
 typedef struct saunet_bn_epilogue {
     const void* bn_x; int32_t ld_bn_x; int32_t relu;
+    int32_t accumulate;   /* 1: y += scale[c]*g instead of y = g ("linear" BN backward, see saunet_bn_backward_coeff); 1x1 path only */
+    int32_t reserved;
     const float* scale; const float* shift; const float* mean; const float* invstd;
     double* sums;
 } saunet_bn_epilogue;
@@ -118,6 +120,15 @@ int saunet_bn_backward_apply(int dtype, const void* dy, int lddy, const void* x,
                              void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta,
                              int64_t pixels, int C, void* stream);
 
+/* "Linear" form of the BatchNorm backward used inside DenseNet, where one concat channel feeds many BatchNorms:
+ *   dx_c = sum_k s_kc*g_k  -  (A_c + B_c*xhat_c),   A_c = sum_k s_kc*mean(g_k),  B_c = sum_k s_kc*mean(g_k*xhat)
+ * The first term is accumulated by the dgrad epilogue (accumulate=1); `coeff` folds one consumer's reduction into A/B
+ * (and emits that BatchNorm's dgamma/dbeta); `correct` applies -(A + B*xhat) once per channel chunk, in place. */
+int saunet_bn_backward_coeff(int C, const double* sums, double count, const float* scale, float* A, float* B,
+                             float* dgamma, float* dbeta, int training, void* stream);
+int saunet_bn_backward_correct(int dtype, void* dx, int lddx, const void* x, int ldx, const float* A, const float* B,
+                               const float* xhat_scale, const float* xhat_shift, int64_t pixels, int C, void* stream);
+
 /* ---- resampling / pooling ------------------------------------------------------------------
  * F.interpolate(mode='bilinear', align_corners=True) models/models.py:337-356,372-374,386-389;
  * nn.MaxPool2d(2,2) :270,376; AvgPool2d(2,2) in the DenseNet transitions. */
@@ -125,6 +136,11 @@ int saunet_bilinear_forward(int dtype, const void* x, int N, int H, int W, int C
 int saunet_bilinear_backward(int dtype, const void* dy, int N, int Ho, int Wo, int C, int lddy, void* dx, int H, int W, int lddx, int accumulate, void* stream);
 int saunet_pool2x2_forward(int dtype, int is_max, const void* x, int N, int H, int W, int C, int ldx, void* y, int ldy, void* stream);
 int saunet_pool2x2_backward(int dtype, int is_max, const void* x, const void* dy, int N, int H, int W, int C, int ldx, int lddy, void* dx, int lddx, int accumulate, void* stream);
+
+/* out[(n,oh,ow)][(kh,kw,c)] = x[n,oh*s-p+kh,ow*s-p+kw,c] (zero outside); C a multiple of the 16-byte chunk.  Lowers the
+ * DenseNet stem conv0 (7x7 stride 2 on the 8-channel padded image, models/models.py:304) to a K=392 pointwise GEMM. */
+int saunet_im2col(int dtype, const void* x, int N, int H, int W, int C, int ldx, int KH, int KW, int stride, int pad,
+                  void* out, int ldo, void* stream);
 
 /* ---- element-wise glue ----------------------------------------------------------------------*/
 /* dst[:, :C] (ld ldd) = src[:, :C] (ld lds) -- the only "cat" there is: writing a channel slice */

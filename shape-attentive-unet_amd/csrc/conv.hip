@@ -371,7 +371,10 @@ int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const voi
     if (igemm_supported(d)) {
         if (epi && (((uintptr_t)epi->bn_x & 15) || epi->ld_bn_x % (d->dtype == SAUNET_BF16 ? 8 : 4)))
             return set_error(SAUNET_BAD_ALIGN, "conv: bn epilogue tensor must be 16-byte aligned");
-        if (tile_fwd_supported(d)) return tile_forward(d, x, w, bias, ps, psh, y, ssum, ssq, epi, st);
+        if (tile_fwd_supported(d)) {
+            if (epi && epi->accumulate) return set_error(SAUNET_UNSUPPORTED, "conv: accumulating BN epilogue is implemented for 1x1 dgrads");
+            return tile_forward(d, x, w, bias, ps, psh, y, ssum, ssq, epi, st);
+        }
         return igemm_forward(d, x, w, bias, ps, psh, y, ssum, ssq, epi, st);
     }
     if (epi) return set_error(SAUNET_UNSUPPORTED, "conv: the BN-backward epilogue needs the MFMA path");

@@ -231,6 +231,42 @@ template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_apply
     }
 }
 
+__global__ void bn_bwd_coeff_kernel(int C, const double* __restrict__ sums, double count, const float* __restrict__ scale,
+                                    float* __restrict__ A, float* __restrict__ B, float* __restrict__ dgamma, float* __restrict__ dbeta, int training)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double s1 = sums[c], s2 = sums[C + c];
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    if (training) { A[c] += scale[c] * (float)(s1 / count); B[c] += scale[c] * (float)(s2 / count); }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_bwd_correct_kernel(T* __restrict__ dx, int lddx, const T* __restrict__ x, int ldx, const float* __restrict__ A,
+                                                             const float* __restrict__ B, const float* __restrict__ xs, const float* __restrict__ xt,
+                                                             long P, int C, long rpb)
+{
+    const long p0 = blockIdx.x * rpb, p1 = min(p0 + rpb, P);
+    const int CH = C / V;
+    for (int cb = 0; cb < CH; cb += 256) {
+        const int cw = min(256, CH - cb), rl = 256 / cw;
+        const int ch = cb + threadIdx.x % cw, r0 = threadIdx.x / cw;
+        if (r0 >= rl) continue;
+        float a[V], b[V], s[V], t[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { a[j] = A[ch * V + j]; b[j] = B[ch * V + j]; s[j] = xs[ch * V + j]; t[j] = xt[ch * V + j]; }
+        for (long p = p0 + r0; p < p1; p += rl) {
+            float d[V], xv[V];
+            ChunkIO<T, V>::load(dx + p * lddx + ch * V, d);
+            ChunkIO<T, V>::load(x + p * ldx + ch * V, xv);
+#pragma unroll
+            for (int j = 0; j < V; ++j) d[j] -= a[j] + b[j] * fmaf(xv[j], s[j], t[j]);
+            ChunkIO<T, V>::store(dx + p * lddx + ch * V, d);
+        }
+    }
+}
+
 static inline long rows_per_block(long P, int C, int V, int* blocks)
 {
     // enough blocks to fill the chip, each with a few thousand elements per thread at most
@@ -319,6 +355,28 @@ int saunet_bn_backward_reduce(int dtype, const void* dy, int lddy, const void* x
     DISPATCH_TV(dtype, vec, CALL);
 #undef CALL
     SAUNET_CHECK_LAUNCH("bn_backward_reduce");
+    return SAUNET_OK;
+}
+
+int saunet_bn_backward_coeff(int C, const double* sums, double count, const float* scale, float* A, float* B,
+                             float* dgamma, float* dbeta, int training, void* stream)
+{
+    hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, sums, count, scale, A, B, dgamma, dbeta, training);
+    SAUNET_CHECK_LAUNCH("bn_backward_coeff");
+    return SAUNET_OK;
+}
+
+int saunet_bn_backward_correct(int dtype, void* dx, int lddx, const void* x, int ldx, const float* A, const float* B,
+                               const float* xhat_scale, const float* xhat_shift, int64_t pixels, int C, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = vec_ok(dtype, C, {lddx, ldx}, {dx, x});
+    int blocks; const int V = vec ? (dtype == SAUNET_BF16 ? 8 : 4) : 1;
+    long rpb = rows_per_block(pixels, C, V, &blocks);
+#define CALL(TT, VV) hipLaunchKernelGGL((bn_bwd_correct_kernel<TT, VV>), dim3(blocks), dim3(256), 0, st, (TT*)dx, lddx, (const TT*)x, ldx, A, B, xhat_scale, xhat_shift, (long)pixels, C, rpb)
+    DISPATCH_TV(dtype, vec, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("bn_backward_correct");
     return SAUNET_OK;
 }
 

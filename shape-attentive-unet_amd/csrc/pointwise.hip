@@ -145,6 +145,28 @@ template <typename T> __global__ __launch_bounds__(256) void pool_bwd_kernel(Poo
     }
 }
 
+// ------------------------------------------------------------------------------------------ im2col (stem conv)
+// out[(n,oh,ow)][(kh,kw,c)] = x[n, oh*stride-pad+kh, ow*stride-pad+kw, c]  (0 outside): turns the 7x7 stride-2 stem conv
+// on the 8-channel padded image into a K = 392 pointwise GEMM that runs on the tuned 1x1 forward / wgrad kernels
+struct Im2colArgs { const void* x; void* out; int N, H, W, C, ldx, Ho, Wo, KH, KW, stride, pad, ldo; };
+template <typename T> __global__ __launch_bounds__(256) void im2col_kernel(Im2colArgs a)
+{
+    constexpr int EPC = 16 / sizeof(T);
+    const int cpp = a.C / EPC;                          // 16-byte chunks per pixel
+    const long total = (long)a.N * a.Ho * a.Wo * a.KH * a.KW * cpp;
+    const T* x = (const T*)a.x; T* o = (T*)a.out;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int ch = (int)(i % cpp); long t = i / cpp;
+        int kw = (int)(t % a.KW); t /= a.KW; int kh = (int)(t % a.KH); t /= a.KH;
+        int ow = (int)(t % a.Wo); long t2 = t / a.Wo; int oh = (int)(t2 % a.Ho); int n = (int)(t2 / a.Ho);
+        int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+            v = *(const u32x4*)(x + (((long)n * a.H + ih) * a.W + iw) * a.ldx + ch * EPC);
+        *(u32x4*)(o + t * a.ldo + ((kh * a.KW + kw) * cpp + ch) * EPC) = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ element-wise
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void copy_channels_kernel(const TS* __restrict__ s, int lds, TD* __restrict__ d, int ldd, long P, int C, int acc)
@@ -379,6 +401,19 @@ int saunet_bilinear_backward(int dtype, const void* dy, int N, int Ho, int Wo, i
     else if (dtype == SAUNET_BF16) { if (vec) hipLaunchKernelGGL((bilinear_bwd_kernel<u16, 8>), dim3(grid_for(total)), dim3(256), 0, st, a); else hipLaunchKernelGGL((bilinear_bwd_kernel<u16, 1>), dim3(grid_for(total)), dim3(256), 0, st, a); }
     else return set_error(SAUNET_BAD_DTYPE, "dtype %d", dtype);
     SAUNET_CHECK_LAUNCH("bilinear_backward");
+    return SAUNET_OK;
+}
+
+int saunet_im2col(int dtype, const void* x, int N, int H, int W, int C, int ldx, int KH, int KW, int stride, int pad, void* out, int ldo, void* stream)
+{
+    const int epc = dtype == SAUNET_BF16 ? 8 : 4;
+    if (C % epc || ldx % epc || ldo % epc || (((uintptr_t)x | (uintptr_t)out) & 15)) return set_error(SAUNET_BAD_ALIGN, "im2col: 16-byte channel chunks required");
+    Im2colArgs a{x, out, N, H, W, C, ldx, (H + 2 * pad - KH) / stride + 1, (W + 2 * pad - KW) / stride + 1, KH, KW, stride, pad, ldo};
+    const long total = (long)N * a.Ho * a.Wo * KH * KW * (C / epc);
+#define CALL(TT) hipLaunchKernelGGL(im2col_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a)
+    DISPATCH_T(dtype, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("im2col");
     return SAUNET_OK;
 }
 

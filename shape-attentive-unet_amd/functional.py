@@ -239,9 +239,10 @@ def conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed=False, out=None,
         wp = PACKS.get(weight, L.PACK_DGRAD, dy.dtype)
         d = _desc(dy, cin, ld_of(out), h, w, kh, kw, 1, kh - 1 - pad)
     if bn_epi is not None:
-        bx, p, relu, sums = bn_epi
+        bx, p, relu, sums = bn_epi[:4]
         e = L.BnEpilogue()
         e.bn_x, e.ld_bn_x, e.relu = bx.data_ptr(), ld_of(bx), 1 if relu else 0
+        e.accumulate = 1 if (len(bn_epi) > 4 and bn_epi[4]) else 0
         e.scale, e.shift, e.mean, e.invstd = p.scale.data_ptr(), p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr()
         e.sums = sums.data_ptr()
         L.call("saunet_conv2d_forward_ex", C.byref(d), dy.data_ptr(), wp.data_ptr(), None, None, None, out.data_ptr(), None, None,
@@ -267,6 +268,16 @@ def conv_wgrad_raw(x, dy, weight, stride, pad, transposed=False, pro=None):
     L.call("saunet_conv2d_wgrad", C.byref(d), x.data_ptr(), dy.data_ptr(), L.ptr(pro[0]) if pro else None,
            L.ptr(pro[1]) if pro else None, dw.data_ptr(), L.ptr(ws), need, L.stream())
     return dw
+
+
+def im2col(x, kh, kw, stride, pad):
+    """[N,C,H,W] (NHWC memory) -> [N, kh*kw*C, Ho, Wo] with K order (kh, kw, c); no gradient (used on the input image)."""
+    x = nhwc(x)
+    n, c, h, w = x.shape
+    ho, wo = conv_out_hw(h, w, kh, kw, stride, pad, False)
+    out = new_act(n, kh * kw * c, ho, wo, x.dtype, x.device)
+    L.call("saunet_im2col", L.dtype_code(x), x.data_ptr(), n, h, w, c, ld_of(x), kh, kw, stride, pad, out.data_ptr(), ld_of(out), L.stream())
+    return out
 
 
 def channel_sum(t):
@@ -851,7 +862,13 @@ class _DenseBlock(torch.autograd.Function):
             conv_forward_raw(z1, c2w, None, 1, 1, pro=(p2.scale, p2.shift, True), out=buf[:, cin:cin + growth],
                              stats=(stats[0, cin:cin + growth], stats[1, cin:cin + growth]) if training else None)
             saved += [z1, p1.buf, p2.buf]
-        ctx.save_for_backward(buf, *params, *saved)
+        # xhat = x*xs + xt for every concat channel (gamma=1, beta=0): what the deferred backward correction needs
+        xh = torch.zeros(2, ctot, dtype=torch.float32, device=dev)
+        if training:
+            one, zero = _const_vec(ctot, dev, 1.0), _const_vec(ctot, dev, 0.0)
+            L.call("saunet_bn_finalize", ctot, stats[0].data_ptr(), stats[1].data_ptr(), float(count), None, one.data_ptr(), zero.data_ptr(),
+                   float(cfgs[0][1]), 0.0, None, None, xh[0].data_ptr(), xh[1].data_ptr(), None, None, 1, L.stream())
+        ctx.save_for_backward(buf, xh, *params, *saved)
         ctx.meta = (nl, c0, growth, count, training)
         ctx.mark_non_differentiable(stats)
         return buf, stats
@@ -860,11 +877,24 @@ class _DenseBlock(torch.autograd.Function):
     def backward(ctx, dbuf, _dstats):
         nl, c0, growth, count, training = ctx.meta
         t = ctx.saved_tensors
-        buf, params, saved = t[0], t[1:1 + 6 * nl], t[1 + 6 * nl:]
+        buf, xh, params, saved = t[0], t[1], t[2:2 + 6 * nl], t[2 + 6 * nl:]
         n, ctot, h, w = buf.shape
+        dev = buf.device
         dbuf = nhwc(dbuf)
         if not dbuf.is_contiguous(memory_format=_CL) or dbuf.shape[1] != ctot:
             dbuf = dbuf.contiguous(memory_format=_CL)
+        P = n * h * w
+        dt = L.dtype_code(buf)
+        # "linear" BN backward: every consumer adds s*g into dbuf from its dgrad epilogue; the -(A + B*xhat) terms
+        # are accumulated per channel and applied ONCE per 32-channel chunk right before that chunk is consumed
+        AB = torch.zeros(2, ctot, dtype=torch.float32, device=dev)
+
+        def correct(lo, hi):
+            if training:
+                d, x = dbuf[:, lo:hi], buf[:, lo:hi]
+                L.call("saunet_bn_backward_correct", dt, d.data_ptr(), ld_of(d), x.data_ptr(), ld_of(x), AB[0, lo:hi].data_ptr(),
+                       AB[1, lo:hi].data_ptr(), xh[0, lo:hi].data_ptr(), xh[1, lo:hi].data_ptr(), P, hi - lo, L.stream())
+
         grads = [None] * (6 * nl)
         for l in reversed(range(nl)):
             n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
@@ -873,16 +903,20 @@ class _DenseBlock(torch.autograd.Function):
             p2 = BNParams.__new__(BNParams); p2.buf = p2b
             cin = c0 + growth * l
             xin = buf[:, :cin]
+            correct(cin, cin + growth)
             dz2 = dbuf[:, cin:cin + growth]
             dw2 = conv_wgrad_raw(z1, dz2, c2w, 1, 1, pro=(p2.scale, p2.shift, True))
-            s2 = zeros_f64(2 * z1.shape[1], device=buf.device)
+            s2 = zeros_f64(2 * z1.shape[1], device=dev)
             da2 = conv_dgrad_raw(dz2, c2w, z1.shape, 1, 1, bn_epi=(z1, p2, True, s2))
             dz1, _, dg2, db2 = bn_backward(da2, z1, p2, True, count, training, dx=da2, presums=s2)
             dw1 = conv_wgrad_raw(xin, dz1, c1w, 1, 0, pro=(p1.scale, p1.shift, True))
-            s1 = zeros_f64(2 * cin, device=buf.device)
-            da1 = conv_dgrad_raw(dz1, c1w, (n, cin, h, w), 1, 0, bn_epi=(xin, p1, True, s1))
-            _, _, dg1, db1 = bn_backward(da1, xin, p1, True, count, training, dx=dbuf[:, :cin], accumulate=True, presums=s1)
-            grads[6 * l:6 * l + 6] = [dg1, db1, dw1, dg2, db2, dw2]
+            s1 = zeros_f64(2 * cin, device=dev)
+            conv_dgrad_raw(dz1, c1w, (n, cin, h, w), 1, 0, out=dbuf[:, :cin], bn_epi=(xin, p1, True, s1, True))
+            dgb = torch.empty(2, cin, dtype=torch.float32, device=dev)
+            L.call("saunet_bn_backward_coeff", cin, s1.data_ptr(), float(count), p1.scale.data_ptr(), AB[0].data_ptr(), AB[1].data_ptr(),
+                   dgb[0].data_ptr(), dgb[1].data_ptr(), 1 if training else 0, L.stream())
+            grads[6 * l:6 * l + 6] = [dgb[0], dgb[1], dw1, dg2, db2, dw2]
+        correct(0, c0)
         dx0 = dbuf[:, :c0] if ctx.needs_input_grad[0] else None
         return (dx0, None, None) + tuple(grads) + (None,) * (4 * nl)
 

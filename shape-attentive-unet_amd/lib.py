@@ -22,7 +22,8 @@ class ConvDesc(C.Structure):
 
 
 class BnEpilogue(C.Structure):
-    _fields_ = [("bn_x", C.c_void_p), ("ld_bn_x", C.c_int32), ("relu", C.c_int32), ("scale", C.c_void_p), ("shift", C.c_void_p),
+    _fields_ = [("bn_x", C.c_void_p), ("ld_bn_x", C.c_int32), ("relu", C.c_int32), ("accumulate", C.c_int32), ("reserved", C.c_int32),
+                ("scale", C.c_void_p), ("shift", C.c_void_p),
                 ("mean", C.c_void_p), ("invstd", C.c_void_p), ("sums", C.c_void_p)]
 
 
@@ -51,8 +52,11 @@ _SIGS = {
     "saunet_bn_backward_reduce": [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i64, i32, vp],
     "saunet_bn_backward_apply": [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, f64, i32, i32,
                                  vp, i32, vp, i32, vp, vp, i64, i32, vp],
+    "saunet_bn_backward_coeff": [i32, vp, f64, vp, vp, vp, vp, vp, i32, vp],
+    "saunet_bn_backward_correct": [i32, vp, i32, vp, i32, vp, vp, vp, vp, i64, i32, vp],
     "saunet_bilinear_forward": [i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp],
     "saunet_bilinear_backward": [i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp],
+    "saunet_im2col": [i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp],
     "saunet_pool2x2_forward": [i32, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp],
     "saunet_pool2x2_backward": [i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp],
     "saunet_copy_channels": [i32, i32, vp, i32, vp, i32, i64, i32, i32, vp],

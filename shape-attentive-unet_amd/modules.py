@@ -276,13 +276,17 @@ def densenet121(pretrained=False, **kw):
 
 
 class _Stem(nn.Sequential):
-    """conv0 (7x7 s2, 3->64) + norm0, no ReLU / pool (models/models.py:304-305).  The 3-channel image is padded
-    to 8 channels so the MFMA implicit-GEMM path (16-byte channel chunks) applies."""
+    """conv0 (7x7 s2, 3->64) + norm0, no ReLU / pool (models/models.py:304-305).  The 3-channel image is padded to 8
+    channels (16-byte chunks), lowered by im2col to a [P, 7*7*8] matrix and multiplied on the 1x1 MFMA kernels
+    (forward and weight gradient; the image needs no input gradient)."""
 
     def forward(self, x):
         conv, bn = self[0], self[1]
-        w8 = torch.nn.functional.pad(conv.weight, (0, 0, 0, 0, 0, 8 - conv.weight.shape[1]))
-        return HF.conv_bn_act(x, w8, None, bn, relu=False, stride=2, padding=3)
+        co, ci, kh, kw = conv.weight.shape
+        w8 = torch.nn.functional.pad(conv.weight, (0, 0, 0, 0, 0, 8 - ci))                 # [64, 8, 7, 7]
+        wk = w8.permute(0, 2, 3, 1).reshape(co, kh * kw * 8, 1, 1)                          # K order (kh, kw, c)
+        cols = HF.im2col(x, kh, kw, conv.stride[0], conv.padding[0])
+        return HF.conv_bn_act(cols, wk, None, bn, relu=False)
 
 
 class _Tail(nn.Sequential):
