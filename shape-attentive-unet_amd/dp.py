@@ -126,6 +126,8 @@ class GradientBuckets:
         return views
 
     def _launch(self, b):
+        from . import functional as HF
+        HF.WGRAD_SIDE.join()          # weight gradients are written on a side stream
         ps = self.buckets[b]
         for p in ps:
             if p.grad is None:

@@ -8,6 +8,7 @@ Backward passes are written by hand so that producer/consumer fusion survives di
   * concatenation is a write into a channel slice.
 """
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -253,8 +254,58 @@ def conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed=False, out=None,
     return out
 
 
+class SideStream:
+    """Weight-gradient kernels depend only on tensors that already exist and nothing in the backward chain depends on
+    them, so they run on a second HIP stream and overlap the dgrad / BatchNorm-backward chain (which matters most on the
+    low-resolution layers whose grids do not fill 256 CUs).  `join()` makes the main stream wait for them."""
+
+    def __init__(self):
+        self.enabled = os.environ.get("SAUNET_WGRAD_SIDE_STREAM", "0") == "1"   # measured neutral on MI355X: off by default
+        self.streams = {}
+        self.dirty = False
+
+    def get(self, device):
+        s = self.streams.get(device)
+        if s is None:
+            s = torch.cuda.Stream(device=device)
+            self.streams[device] = s
+        return s
+
+    def mark(self):
+        if not self.dirty:
+            self.dirty = True
+            try:   # join automatically when the running backward pass ends (safe for any optimiser / hook order)
+                torch.autograd.Variable._execution_engine.queue_callback(self.join)
+            except Exception:
+                pass
+
+    def join(self):
+        if not self.dirty:
+            return
+        for s in self.streams.values():
+            torch.cuda.current_stream(s.device).wait_stream(s)
+        self.dirty = False
+
+
+WGRAD_SIDE = SideStream()
+
+
 def conv_wgrad_raw(x, dy, weight, stride, pad, transposed=False, pro=None):
     x = nhwc(x); dy = nhwc(dy)
+    if WGRAD_SIDE.enabled and x.is_cuda and isinstance(weight, torch.nn.Parameter):   # leaf weights only: nothing in the
+        main = torch.cuda.current_stream(x.device)                                     # autograd graph reads their gradient
+        side = WGRAD_SIDE.get(x.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            dw = _conv_wgrad_impl(x, dy, weight, stride, pad, transposed, pro)
+        for t in (x, dy, dw) + ((pro[0], pro[1]) if pro else ()):
+            t.record_stream(side)
+        WGRAD_SIDE.mark()
+        return dw
+    return _conv_wgrad_impl(x, dy, weight, stride, pad, transposed, pro)
+
+
+def _conv_wgrad_impl(x, dy, weight, stride, pad, transposed=False, pro=None):
     dw = GRADS.take(weight.numel(), x.device).view(weight.shape)
     if transposed:
         _, cout, kh, kw = weight.shape
