@@ -318,6 +318,301 @@ template <typename T> static int dispatch_tile_fwd(const TileArgs& a, hipStream_
     return narrow ? launch_tile_fwd<T, 128, 128, 64, 4>(a, st) : launch_tile_fwd<T, 128, 128, 64, 8>(a, st);
 }
 
+// =====================================================================================================
+// conv3x3 "resident" forward: PERSISTENT workgroups (one per CU) keep ALL packed weights of their cout tile in LDS for
+// the whole launch and walk over 16x16 pixel tiles; while the MFMAs of unit u = (tile, channel block) run, the halo of
+// unit u+1 is already in flight into registers (one ~1 us MFMA phase hides the L2/HBM latency), then it is BN+ReLU
+// transformed and written to LDS.  LDS rows are padded (pitch = row bytes + 16) instead of XOR-swizzled, so every
+// fragment address is  lane_base + compile-time immediate  (no address VALU in the 9-tap x 4-substep MFMA loop).
+// Used when 9 * Cin_padded * BN weights fit next to one halo (DenseNet conv2 fwd/dgrad, the shape-stream ResBlocks).
+template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI>
+__global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_kernel(TileArgs a)
+{
+    constexpr int NT = (256 / WM) * (BN / WN) * 64;
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int KC = CPR * EPC;
+    constexpr int PITCH = CPR * 16 + 16;
+    constexpr int HALO_BYTES = NPIX * PITCH;
+    constexpr int WTAP = BN * PITCH;                 // one (cb, tap) weight tile
+    constexpr int H_ITERS = (NPIX * CPR + NT - 1) / NT;
+    constexpr int TI = WM / 32, TJ = WN / 32;
+    static_assert(NT % CPR == 0, "chunk index must be thread-invariant");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* s_halo = smem;
+    unsigned char* s_w = smem + HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
+    const int ncb = (a.Cin + KC - 1) / KC;
+    const int ntile = a.tiles_x * a.tiles_y * a.N;
+    const int nnt = (a.Cout + BN - 1) / BN;
+    const T* __restrict__ wg = (const T*)a.w;
+    const bool has_pro = a.pro_scale != nullptr;
+    const float relu_lo = a.pro_relu ? 0.f : -__builtin_inff();
+    const int chunk = tid % CPR;
+
+    // work items: (n-tile, pixel tile); a workgroup keeps one n-tile as long as possible so its weights stay resident
+    const int items = ntile * nnt;
+    const int per = (items + gridDim.x - 1) / gridDim.x;
+    const int it0 = blockIdx.x * per, it1 = min(it0 + per, items);
+    if (it0 >= it1) return;
+
+    int cur_nt = -1;
+    u32x4 hreg[H_ITERS];
+    bool hok[H_ITERS];
+
+    auto issue_halo = [&](int item, int cb) {   // global -> registers (no wait)
+        const int tile = item % ntile;
+        int bt = tile;
+        const int txi = bt % a.tiles_x; bt /= a.tiles_x;
+        const int tyi = bt % a.tiles_y; const int n = bt / a.tiles_y;
+        const T* xg = (const T*)a.x + (size_t)n * a.H * a.W * a.ldx;
+        const int c = cb * KC + chunk * EPC;
+        const bool cok = c < a.Cin;
+#pragma unroll
+        for (int i = 0; i < H_ITERS; ++i) {
+            const int q = tid + i * NT;
+            const int pix = q / CPR;
+            const int hy = pix / HPITCH, hx = pix - hy * HPITCH;
+            const int iy = tyi * TILE + hy - 1, ix = txi * TILE + hx - 1;
+            const bool ok = cok && q < NPIX * CPR && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            hok[i] = ok;
+            hreg[i] = *(const u32x4*)(xg + (ok ? (size_t)(iy * a.W + ix) * a.ldx + c : (size_t)0));
+        }
+    };
+    auto commit_halo = [&](int cb) {            // transform + registers -> LDS
+        const int c = cb * KC + chunk * EPC;
+        const int cs = c < a.Cin ? c : 0;
+        float sc[EPC], sh[EPC];
+        if (has_pro) {
+#pragma unroll
+            for (int j = 0; j < EPC; j += 4) {
+                f32x4 s4 = *(const f32x4*)(a.pro_scale + cs + j), t4 = *(const f32x4*)(a.pro_shift + cs + j);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { sc[j + q] = s4[q]; sh[j + q] = t4[q]; }
+            }
+        }
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < H_ITERS; ++i) {
+            const int q = tid + i * NT;
+            u32x4 v = hreg[i];
+            if (has_pro) {
+                float f[EPC];
+                Vec16<T>::unpack(v, f);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) f[j] = fmaxf(fmaf(f[j], sc[j], sh[j]), relu_lo);
+                v = Vec16<T>::pack(f);
+            }
+            if (q < NPIX * CPR) *(u32x4*)(s_halo + (q / CPR) * PITCH + chunk * 16) = hok[i] ? v : z;
+        }
+    };
+
+    f32x16 acc[TI][TJ];
+    // lane base addresses (bytes) of the A / B fragments
+    int abase[TI], bbase[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int row = wm0 + i * 32 + lr;
+        abase[i] = ((row >> 4) * HPITCH + (row & 15)) * PITCH + lh * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) bbase[j] = (wn0 + j * 32 + lr) * PITCH + lh * 16;
+
+    issue_halo(it0, 0);
+    for (int item = it0; item < it1; ++item) {
+        const int nt = item / ntile, tile = item - nt * ntile;
+        const int n0 = nt * BN;
+        if (nt != cur_nt) {   // (re)load this n-tile's weights: [cb][tap][BN rows][PITCH]
+            __syncthreads();
+            const int pieces = ncb * 9 * BN * CPR;
+            for (int q = tid; q < pieces; q += NT) {
+                const int ch = q % CPR; int t = q / CPR;
+                const int brow = t % BN; t /= BN;
+                const int tap = t % 9, cb = t / 9;
+                const int c = cb * KC + ch * EPC;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (n0 + brow < a.Cout && c < a.Cin) v = *(const u32x4*)(wg + ((size_t)(n0 + brow) * 9 + tap) * a.Cin + c);
+                *(u32x4*)(s_w + (cb * 9 + tap) * WTAP + brow * PITCH + ch * 16) = v;
+            }
+            cur_nt = nt;
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int cb = 0; cb < ncb; ++cb) {
+            __syncthreads();                 // previous unit's fragment reads (and the epilogue's use of the halo area) are done
+            commit_halo(cb);
+            __syncthreads();
+            // prefetch the next unit's halo while this unit's MFMAs run
+            if (cb + 1 < ncb) issue_halo(item, cb + 1);
+            else if (item + 1 < it1) issue_halo(item + 1, 0);
+            const unsigned char* wb = s_w + cb * 9 * WTAP;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                constexpr int dummy = 0; (void)dummy;
+                const int aoff = ((tap / 3) * HPITCH + (tap % 3)) * PITCH;
+#pragma unroll
+                for (int s = 0; s < CPR / 2; ++s) {
+                    u32x4 af[TI], bfr[TJ];
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) af[i] = *(const u32x4*)(s_halo + abase[i] + aoff + s * 32);
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) bfr[j] = *(const u32x4*)(wb + bbase[j] + tap * WTAP + s * 32);
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j) MmaT<T>::run(af[i], bfr[j], acc[i][j]);
+                }
+            }
+        }
+        // ---- epilogue for this tile (output staged in the halo area)
+        __syncthreads();
+        int bt = tile;
+        const int txi = bt % a.tiles_x; bt /= a.tiles_x;
+        const int tyi = bt % a.tiles_y; const int n = bt / a.tiles_y;
+        const int ty0 = tyi * TILE, tx0 = txi * TILE;
+        float* s_sum = (float*)(s_halo + 256 * BN * sizeof(T));
+        float* s_sq = s_sum + BN;
+        const bool do_stats = a.stat_sum != nullptr;
+        if (do_stats || BNEPI) for (int i = tid; i < 2 * BN; i += NT) s_sum[i] = 0.f;
+        if (do_stats) __syncthreads();
+        T* so = (T*)s_halo;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int col = wn0 + j * 32 + lr;
+            const float bv = (a.bias != nullptr && n0 + col < a.Cout) ? a.bias[n0 + col] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r];
+                    s1 += v; s2 += v * v;
+                    int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    Elem<T>::store(so + row * BN + col, v + bv);
+                }
+            if (do_stats) {
+                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                if (lh == 0) { atomicAdd(&s_sum[col], s1); atomicAdd(&s_sq[col], s2); }
+            }
+        }
+        __syncthreads();
+        if (do_stats && tid < BN && n0 + tid < a.Cout) {
+            atomicAdd(&a.stat_sum[n0 + tid], (double)s_sum[tid]);
+            atomicAdd(&a.stat_sumsq[n0 + tid], (double)s_sq[tid]);
+        }
+        constexpr int CH = BN / EPC;
+        constexpr int S_ITERS = (256 * CH) / NT;
+        static_assert((256 * CH) % NT == 0, "store loop must divide evenly");
+        T* __restrict__ yg = (T*)a.y + (size_t)n * a.H * a.W * a.ldy;
+        const int colv = n0 + (tid % CH) * EPC;
+        const bool cok = colv < a.Cout;
+        if constexpr (BNEPI) {
+            const T* __restrict__ bx = (const T*)a.epi.bn_x + (size_t)n * a.H * a.W * a.epi.ld_bn_x;
+            float e1[EPC], e2[EPC], esc[EPC], esh[EPC], emu[EPC], eis[EPC];
+            const int cs = cok ? colv : 0;
+#pragma unroll
+            for (int j = 0; j < EPC; j += 4) {
+                f32x4 v0 = *(const f32x4*)(a.epi.scale + cs + j), v1 = *(const f32x4*)(a.epi.shift + cs + j);
+                f32x4 v2 = *(const f32x4*)(a.epi.mean + cs + j), v3 = *(const f32x4*)(a.epi.invstd + cs + j);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { esc[j + q] = v0[q]; esh[j + q] = v1[q]; emu[j + q] = v2[q]; eis[j + q] = v3[q]; e1[j + q] = 0.f; e2[j + q] = 0.f; }
+            }
+            u32x4 xr[S_ITERS];
+#pragma unroll
+            for (int i = 0; i < S_ITERS; ++i) {
+                int row = (tid + i * NT) / CH;
+                size_t opix = (size_t)(ty0 + (row >> 4)) * a.W + tx0 + (row & 15);
+                xr[i] = *(const u32x4*)(bx + (cok ? opix * a.epi.ld_bn_x + colv : (size_t)0));
+            }
+#pragma unroll
+            for (int i = 0; i < S_ITERS; ++i) {
+                int p = tid + i * NT;
+                int row = p / CH, ch = p - row * CH;
+                size_t opix = (size_t)(ty0 + (row >> 4)) * a.W + tx0 + (row & 15);
+                float g[EPC], xv[EPC];
+                Vec16<T>::unpack(*(const u32x4*)(so + row * BN + ch * EPC), g);
+                Vec16<T>::unpack(xr[i], xv);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) {
+                    if (a.epi.relu && !(fmaf(xv[j], esc[j], esh[j]) > 0.f)) g[j] = 0.f;
+                    if (!cok) g[j] = 0.f;
+                    e1[j] += g[j];
+                    e2[j] = fmaf(g[j], (xv[j] - emu[j]) * eis[j], e2[j]);
+                }
+                if (cok) *(u32x4*)(yg + opix * a.ldy + colv) = Vec16<T>::pack(g);
+            }
+            const int ch = tid % CH;
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) { atomicAdd(&s_sum[ch * EPC + j], e1[j]); atomicAdd(&s_sq[ch * EPC + j], e2[j]); }
+            __syncthreads();
+            if (tid < BN && n0 + tid < a.Cout) {
+                atomicAdd(&a.epi.sums[n0 + tid], (double)s_sum[tid]);
+                atomicAdd(&a.epi.sums[a.Cout + n0 + tid], (double)s_sq[tid]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < S_ITERS; ++i) {
+                int p = tid + i * NT;
+                int row = p / CH, ch = p - row * CH;
+                size_t opix = (size_t)(ty0 + (row >> 4)) * a.W + tx0 + (row & 15);
+                if (cok) *(u32x4*)(yg + opix * a.ldy + colv) = *(const u32x4*)(so + row * BN + ch * EPC);
+            }
+        }
+    }
+}
+
+template <typename T, int BN, int WM, int WN, int CPR> static constexpr int res_lds_bytes(int ncb)
+{
+    return NPIX * (CPR * 16 + 16) + ncb * 9 * BN * (CPR * 16 + 16);
+}
+
+template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI> static int launch_res_fwd_i(const TileArgs& a, hipStream_t st)
+{
+    constexpr int NT = (256 / WM) * (BN / WN) * 64;
+    constexpr int EPC = 16 / sizeof(T);
+    const int ncb = (a.Cin + CPR * EPC - 1) / (CPR * EPC);
+    int lds = res_lds_bytes<T, BN, WM, WN, CPR>(ncb);
+    const int epi = 256 * BN * (int)sizeof(T) + 2 * BN * 4;
+    if (epi > NPIX * (CPR * 16 + 16)) lds += epi - NPIX * (CPR * 16 + 16);
+    auto kern = conv3x3_res_fwd_kernel<T, BN, WM, WN, CPR, BNEPI>;
+    static int attr_lds = 0;
+    if (lds > attr_lds) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_lds = lds; }
+    const int items = a.tiles_x * a.tiles_y * a.N * cdiv(a.Cout, BN);
+    const int per_cu = (160 * 1024) / lds > 0 ? (160 * 1024) / lds : 1;
+    int blocks = 256 * per_cu; if (blocks > items) blocks = items;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, st, a);
+    SAUNET_CHECK_LAUNCH("conv3x3_res_fwd");
+    return SAUNET_OK;
+}
+
+// does the resident-weight kernel apply, and with which tile?  (weights of one n-tile + one halo must fit in 160 KB)
+template <typename T> static int dispatch_res_fwd(const TileArgs& a, hipStream_t st, bool* handled)
+{
+    constexpr int EPC = 16 / sizeof(T);
+    const bool narrow = a.Cin <= 4 * EPC;
+    const int cpr = narrow ? 4 : 8;
+    const int ncb = (a.Cin + cpr * EPC - 1) / (cpr * EPC);
+    const int pitch = cpr * 16 + 16;
+    const int bn = a.Cout <= 32 ? 32 : (a.Cout <= 64 ? 64 : 128);
+    long lds = (long)NPIX * pitch + (long)ncb * 9 * bn * pitch;
+    const long epi = 256L * bn * sizeof(T) + 2 * bn * 4;
+    if (epi > (long)NPIX * pitch) lds += epi - (long)NPIX * pitch;
+    *handled = lds <= 156 * 1024 && (a.tiles_x * a.tiles_y * a.N) >= 256;
+    if (!*handled) return SAUNET_OK;
+#define RES(BN_, WM_, WN_, CPR_) (a.epi.bn_x ? launch_res_fwd_i<T, BN_, WM_, WN_, CPR_, true>(a, st) : launch_res_fwd_i<T, BN_, WM_, WN_, CPR_, false>(a, st))
+    if (bn == 32) return narrow ? RES(32, 64, 32, 4) : RES(32, 64, 32, 8);
+    if (bn == 64) return narrow ? RES(64, 64, 64, 4) : RES(64, 64, 64, 8);
+    return narrow ? RES(128, 128, 64, 4) : RES(128, 128, 64, 8);
+#undef RES
+}
+
 bool tile_fwd_supported(const saunet_conv_desc* d)
 {
     return !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->H % TILE == 0 && d->W % TILE == 0 &&
@@ -333,8 +628,9 @@ int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const 
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Cout = d->Cout; a.ldy = d->ldy;
     a.pro_relu = d->pro_relu; a.tiles_y = d->H / TILE; a.tiles_x = d->W / TILE;
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return set_error(SAUNET_BAD_ALIGN, "conv: pointers must be 16-byte aligned");
-    if (d->dtype == SAUNET_BF16) return dispatch_tile_fwd<u16>(a, st);
-    if (d->dtype == SAUNET_F32) return dispatch_tile_fwd<float>(a, st);
+    bool handled = false;
+    if (d->dtype == SAUNET_BF16) { int rc = dispatch_res_fwd<u16>(a, st, &handled); if (handled) return rc; return dispatch_tile_fwd<u16>(a, st); }
+    if (d->dtype == SAUNET_F32) { int rc = dispatch_res_fwd<float>(a, st, &handled); if (handled) return rc; return dispatch_tile_fwd<float>(a, st); }
     return set_error(SAUNET_BAD_DTYPE, "conv: dtype %d", d->dtype);
 }
 
