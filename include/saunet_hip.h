@@ -182,6 +182,10 @@ int saunet_dual_loss_backward(int dtype, const void* logits, int ldl, const void
  * out[n,h,w] in {0,255} as dtype.  work: int32 [N][3][H][W] scratch. */
 int saunet_canny(int dtype, const float* image_nchw3, int N, int H, int W, int low, int high, void* out, int32_t* work, void* stream);
 
+/* edge ground truth [N,1,H,W] in {0,1} from labels [N,H,W] (int64): radius-2 distance-transform edges of classes
+ * 1..num_classes, bit-identical to data/ac17_dataloader.py:231-258 (mask_to_onehot + onehot_to_binary_edges). */
+int saunet_mask_to_edges(const int64_t* seg, int N, int H, int W, int num_classes, float* edge, void* stream);
+
 /* ---- optimiser (train.py:166-216, radam.py:5-78) as multi-tensor kernels ------------------------*/
 typedef struct saunet_tensor_list { int32_t count; const void* ptrs[4][96]; int64_t numel[96]; } saunet_tensor_list;
 /* hyper-parameters live in a DEVICE float array so a captured hipGraph can be replayed after the host

@@ -115,9 +115,47 @@ __global__ __launch_bounds__(1024) void canny_hyst_kernel(int H, int W, int32_t*
     for (int i = threadIdx.x; i < npix; i += 1024) Elem<T>::store(o + i, map[i] == 2 ? 255.f : 0.f);
 }
 
+// Edge ground truth on the device (replaces the loader's three Euclidean distance transforms per slice,
+// /root/reference/data/ac17_dataloader.py:236-258): a pixel is an edge iff, for some class c in 1..3, a pixel of the
+// opposite membership lies within Euclidean distance 2 (EDT(m) + EDT(1-m) <= 2); outside the image counts as
+// "not class c" within the loader's one-pixel zero pad.
+__global__ __launch_bounds__(256) void mask_to_edges_kernel(const int64_t* __restrict__ seg, int N, int H, int W, int num_classes, float* __restrict__ edge)
+{
+    const long total = (long)N * H * W;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % W); long t = i / W; const int y = (int)(t % H); const int n = (int)(t / H);
+        const int64_t* s = seg + (long)n * H * W;
+        const int lab = (int)s[(long)y * W + x];
+        bool e = false;
+#pragma unroll
+        for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+            for (int dx = -2; dx <= 2; ++dx) {
+                if (dy * dy + dx * dx > 4 || (dy == 0 && dx == 0)) continue;
+                const int yy = y + dy, xx = x + dx;
+                if (yy < -1 || yy > H || xx < -1 || xx > W) continue;             // beyond the one-pixel pad: no partner
+                const bool inside = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+                const int other = inside ? (int)s[(long)yy * W + xx] : 0;
+                // membership differs for some class c in 1..num_classes  <=>  labels differ and one of them is a class
+                if (other != lab && ((lab >= 1 && lab <= num_classes) || (other >= 1 && other <= num_classes))) e = true;
+            }
+        edge[i] = e ? 1.f : 0.f;
+    }
+}
+
 }  // namespace saunet
 
 using namespace saunet;
+
+extern "C" int saunet_mask_to_edges(const int64_t* seg, int N, int H, int W, int num_classes, float* edge, void* stream)
+{
+    const long total = (long)N * H * W;
+    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(mask_to_edges_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, seg, N, H, W, num_classes, edge);
+    SAUNET_CHECK_LAUNCH("mask_to_edges");
+    return SAUNET_OK;
+}
+
 
 extern "C" int saunet_canny(int dtype, const float* image, int N, int H, int W, int low, int high, void* out, int32_t* work, void* stream)
 {

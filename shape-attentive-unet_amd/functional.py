@@ -1020,3 +1020,13 @@ def transition(buf, stats, m, training):
     _bump(m.norm)
     return _Transition.apply(buf, stats, m.norm.weight, m.norm.bias, m.norm.running_mean, m.norm.running_var, m.conv.weight,
                              m.norm.momentum, m.norm.eps, training)
+
+
+def mask_to_edges(seg, num_classes=3):
+    """seg: int64 [N,H,W] on the device -> float32 [N,1,H,W] edge ground truth (ac17_dataloader.py:231-258 on the GPU)."""
+    _check_dev(seg)
+    seg = seg.to(torch.int64).contiguous()
+    n, h, w = seg.shape
+    out = torch.empty((n, 1, h, w), dtype=torch.float32, device=seg.device)
+    L.call("saunet_mask_to_edges", seg.data_ptr(), n, h, w, int(num_classes), out.data_ptr(), L.stream())
+    return out

@@ -291,3 +291,18 @@ def test_canny_bit_exact_with_oracle():
         assert (got == want).all(), "canny mismatch: %d pixels differ" % int((got != want).sum())
         got16 = hf.canny(x.cuda(), 10, 100, dtype=torch.bfloat16).float().cpu().numpy()
         assert (got16 == want).all()
+
+
+def test_mask_to_edges_on_device_matches_loader_and_reference_fixture():
+    from oracle import saunet_ref as R, weights as Wt
+    from tests.golden_util import load
+    hf = HF()
+    g = load("loss.npz")
+    m = torch.from_numpy(g["m2e_mask"])[None]
+    assert (hf.mask_to_edges(m.cuda()).cpu().numpy()[0] == g["m2e_edge"]).all()          # fixture from the REAL reference
+    _, seg, edge = Wt.synthetic_batch(3, 96, 80, seed=9)
+    assert (hf.mask_to_edges(seg.cuda()).cpu() == edge).all()
+    r = np.random.default_rng(3)
+    rnd_seg = torch.from_numpy(r.integers(0, 4, (2, 40, 56)))
+    want = np.stack([R.mask_to_edges(s.numpy()) for s in rnd_seg])
+    assert (hf.mask_to_edges(rnd_seg.cuda()).cpu().numpy() == want).all()
