@@ -61,9 +61,9 @@ def kernel_roofline(S, dtype, batch, size):
     scale = torch.rand(cin, device="cuda") + 0.5
     shift = torch.randn(cin, device="cuda") * 0.1
     out = HF.new_act(n, cout, h, h, dtype, "cuda")
-    stats = torch.zeros(2, cout, dtype=torch.float64, device="cuda")
+    stats = torch.zeros(HF.STAT_R, 2, cout, dtype=torch.float64, device="cuda")
     def run():
-        HF.conv_forward_raw(x, w, None, 1, 1, pro=(scale, shift, True), out=out, stats=(stats[0], stats[1]))
+        HF.conv_forward_raw(x, w, None, 1, 1, pro=(scale, shift, True), out=out, stats=stats)
     for _ in range(5):
         run()
     torch.cuda.synchronize()

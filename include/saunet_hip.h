@@ -43,6 +43,10 @@ typedef struct saunet_conv_desc {
     int32_t KH, KW, stride, pad;
     int32_t transposed;            /* 1: ConvTranspose2d(k=4,s=2,p=1); x is the LOW-res input, y the 2x output */
     int32_t pro_relu;              /* prologue: a = x*pro_scale[c]+pro_shift[c], then max(a,0) if set */
+    /* Statistic accumulators may be REPLICATED: workgroup b adds into replica (b % stat_replicas) at
+     * base + replica*stat_rstride (elements).  Thousands of workgroups hitting the same 2*C float64 addresses serialise
+     * in the cross-XCD atomic path (+40 us on a 4096-block launch); 16 replicas remove that.  0/1 = single copy. */
+    int32_t stat_replicas, stat_rstride;
 } saunet_conv_desc;
 
 const char* saunet_last_error(void);
@@ -75,6 +79,7 @@ typedef struct saunet_bn_epilogue {
     int32_t reserved;
     const float* scale; const float* shift; const float* mean; const float* invstd;
     double* sums;
+    int32_t sums_replicas, sums_rstride;   /* replicated like the statistics (0/1 = single copy) */
 } saunet_bn_epilogue;
 int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                              const float* pro_scale, const float* pro_shift, void* y,
@@ -96,11 +101,14 @@ int saunet_channel_sum(int dtype, const void* dy, int64_t pixels, int C, int ld,
 /* ---- batch normalisation -------------------------------------------------------------------
  * replaces nn.BatchNorm2d / SynchronizedBatchNorm2d (single-device path = F.batch_norm,
  * lib/nn/modules/batchnorm.py:58-61) forward+backward; models/norm.py:16-22. */
-int saunet_bn_stats(int dtype, const void* x, int64_t pixels, int C, int ld, double* sum, double* sumsq, void* stream);
+int saunet_bn_stats(int dtype, const void* x, int64_t pixels, int C, int ld, double* sum, double* sumsq,
+                    int replicas, int rstride, void* stream);
+/* base[i] = sum_r base[r*rstride + i], i < n: collapse replicated accumulators into replica 0 */
+int saunet_sum_replicas(double* base, int n, int replicas, int rstride, void* stream);
 /* training=1: mean/var from (sum,sumsq,count) [+conv_bias], updates running stats with `momentum`
  * (unbiased var), writes scale=gamma*invstd, shift=beta-mean*scale, mean, invstd.
  * training=0: scale/shift from the running statistics. */
-int saunet_bn_finalize(int C, const double* sum, const double* sumsq, double count, const float* conv_bias,
+int saunet_bn_finalize(int C, const double* sum, const double* sumsq, int replicas, int rstride, double count, const float* conv_bias,
                        const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, float* scale, float* shift,
                        float* mean, float* invstd, int training, void* stream);
@@ -111,7 +119,7 @@ int saunet_affine_act(int dtype, const void* x, int ldx, const float* scale, con
  * sums[C:2C] += sum g*xhat  with xhat = (x-mean)*invstd   (float64 atomics, zeroed by caller) */
 int saunet_bn_backward_reduce(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,
                               const float* scale, const float* shift, const float* mean, const float* invstd,
-                              int relu, double* sums, int64_t pixels, int C, void* stream);
+                              int relu, double* sums, int replicas, int rstride, int64_t pixels, int C, void* stream);
 /* dx (+)= scale*(g - sum_g/count - xhat*sum_gxhat/count) (training) or scale*g (eval);
  * optionally dres = g.  dgamma/dbeta are written from `sums` (float32) when non-NULL. */
 int saunet_bn_backward_apply(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,

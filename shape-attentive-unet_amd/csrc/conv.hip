@@ -85,7 +85,7 @@ template <typename T> __global__ void pack_weight_multi_kernel(saunet_pack_list 
 struct PwArgs {
     const void* x; const void* w; void* y; const float* bias; const float* ps; const float* psh;
     double* ssum; double* ssq;
-    long P; int Cin, Cout, ldx, ldy, pro_relu;
+    long P; int Cin, Cout, ldx, ldy, pro_relu; int srep, srstride;
 };
 
 // Each block owns ITEMS = 256*PW_IT consecutive (pixel, cout) items; thread t handles items t, t+256, ...
@@ -129,8 +129,9 @@ template <typename T> __global__ __launch_bounds__(256) void pointwise_fwd_kerne
         if (fixed_co) { atomicAdd(&s_sum[co_last], rs); atomicAdd(&s_sq[co_last], rq); }
         __syncthreads();
         if (threadIdx.x < a.Cout) {
-            atomicAdd(&a.ssum[threadIdx.x], (double)s_sum[threadIdx.x]);
-            atomicAdd(&a.ssq[threadIdx.x], (double)s_sq[threadIdx.x]);
+            const size_t ro = (size_t)(blockIdx.x % a.srep) * a.srstride;
+            atomicAdd(&a.ssum[ro + threadIdx.x], (double)s_sum[threadIdx.x]);
+            atomicAdd(&a.ssq[ro + threadIdx.x], (double)s_sq[threadIdx.x]);
         }
     }
 }
@@ -190,9 +191,10 @@ template <typename T, int CIN_PAD> __global__ __launch_bounds__(256) void pointw
     }
     if (stats) {
         __syncthreads();
+        const size_t ro = (size_t)(blockIdx.x % a.srep) * a.srstride;
         for (int i = threadIdx.x; i < a.Cout; i += 256) {
-            atomicAdd(&a.ssum[i], (double)ssum[i]);
-            atomicAdd(&a.ssq[i], (double)ssum[a.Cout + i]);
+            atomicAdd(&a.ssum[ro + i], (double)ssum[i]);
+            atomicAdd(&a.ssq[ro + i], (double)ssum[a.Cout + i]);
         }
     }
 }
@@ -380,7 +382,8 @@ int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const voi
     if (epi) return set_error(SAUNET_UNSUPPORTED, "conv: the BN-backward epilogue needs the MFMA path");
     if (!is_pointwise(d)) return set_error(SAUNET_UNSUPPORTED, "conv: %dx%d s%d Cin=%d Cout=%d has no kernel", d->KH, d->KW, d->stride, d->Cin, d->Cout);
     if (ssum != nullptr && d->Cout > 64) return set_error(SAUNET_UNSUPPORTED, "pointwise stats need Cout <= 64");
-    PwArgs a{x, w, y, bias, ps, psh, ssum, ssq, (long)d->N * d->H * d->W, d->Cin, d->Cout, d->ldx, d->ldy, d->pro_relu};
+    PwArgs a{x, w, y, bias, ps, psh, ssum, ssq, (long)d->N * d->H * d->W, d->Cin, d->Cout, d->ldx, d->ldy, d->pro_relu,
+             d->stat_replicas > 1 ? d->stat_replicas : 1, d->stat_rstride};
     if (d->Cin <= 64 && d->Cout <= 64) {
         const int cpad = d->Cin <= 4 ? 4 : d->Cin <= 8 ? 8 : d->Cin <= 16 ? 16 : d->Cin <= 36 ? 36 : 64;
         long blocks = (a.P + 255) / 256; if (blocks > 2048) blocks = 2048;

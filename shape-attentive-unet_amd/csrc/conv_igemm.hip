@@ -19,7 +19,7 @@ namespace saunet {
 struct IgemmArgs {
     const void* x; const void* w; void* y;
     const float* bias; const float* pro_scale; const float* pro_shift;
-    double* stat_sum; double* stat_sumsq;
+    double* stat_sum; double* stat_sumsq; int stat_replicas, stat_rstride;
     int N, H, W, Cin, ldx;
     int Ho, Wo, Cout, ldy;
     int KH, KW, stride, pad;
@@ -55,7 +55,7 @@ template <int CPR> __device__ __forceinline__ int lds_off(int r, int c)
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int CPR, bool BNEPI>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_igemm_fwd_kernel(IgemmArgs a)
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void conv_igemm_fwd_kernel(IgemmArgs a)
 {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     constexpr int EPC = 16 / sizeof(T);       // elements per 16-byte chunk
@@ -95,24 +95,30 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_igemm_fwd_ker
     const int sgn = a.transposed ? -1 : 1;
     const bool has_pro = a.pro_scale != nullptr;
 
-    u32x4 areg[A_PER_T], breg[B_ITERS];
     const int nk = taps * a.kpt;
-
     const float relu_lo = a.pro_relu ? 0.f : -__builtin_inff();
-    // Loads are UNCONDITIONAL (out-of-range pieces read a safe in-bounds address and are zeroed by a select):
-    // a branch around each load would make the compiler wait for every load separately.
-    auto load_tile = [&](int tap, int cstep) {
+
+    // Two register stages: the loads of K-step k+2 are issued before the MFMAs of step k, and only converted
+    // (BN+ReLU prologue, zero padding) and written to LDS after the MFMAs of step k+1 -- a load has two MFMA phases to land.
+    // Loads are UNCONDITIONAL (out-of-range pieces read a safe in-bounds address and are zeroed by a select): a branch
+    // around each load would make the compiler wait for every load separately.
+    struct Stage { u32x4 a[A_PER_T]; u32x4 b[B_ITERS]; unsigned okmask; int cs; };
+    int itap = 0, icstep = 0;     // (tap, channel step) of the NEXT K-step to be issued
+    auto issue = [&](Stage& S) {
+        const int tap = itap, cstep = icstep;
+        if (++icstep == a.kpt) { icstep = 0; ++itap; }
         const int kh = tap / a.KW, kw = tap - kh * a.KW;
         const int c = cstep * KC + chunk * EPC;
         const bool cok = c < a.Cin;
-        const int cs = cok ? c : 0;
-        bool okv[A_PER_T];
+        S.cs = cok ? c : 0;
+        S.okmask = 0u;
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) {
             int ih = rih[i] + sgn * kh, iw = riw[i] + sgn * kw;
-            okv[i] = cok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-            size_t off = okv[i] ? ((size_t)(rbase[i] + ih * a.W + iw) * a.ldx + cs) : (size_t)0;
-            areg[i] = *(const u32x4*)(xg + off);
+            bool ok = cok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            S.okmask |= ok ? (1u << i) : 0u;
+            size_t off = ok ? ((size_t)(rbase[i] + ih * a.W + iw) * a.ldx + S.cs) : (size_t)0;
+            S.a[i] = *(const u32x4*)(xg + off);
         }
 #pragma unroll
         for (int i = 0; i < B_ITERS; ++i) {
@@ -120,44 +126,42 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_igemm_fwd_ker
             int brow = p / CPR, bch = p % CPR;
             int cb = cstep * KC + bch * EPC;
             bool ok = (B_ITERS * NT == BN * CPR || p < BN * CPR) && n0 + brow < a.Cout && cb < a.Cin;
+            S.okmask |= ok ? (1u << (16 + i)) : 0u;
             size_t off = ok ? (((size_t)(n0 + brow) * taps + tap) * a.Cin + cb) : (size_t)0;
-            u32x4 v = *(const u32x4*)(wg + off);
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            breg[i] = ok ? v : z;
+            S.b[i] = *(const u32x4*)(wg + off);
         }
+    };
+    auto commit = [&](Stage& S, int buf) {
+        unsigned char* sa = smem + buf * STAGE;
+        unsigned char* sb = sa + BM * CPR * 16;
+        const u32x4 z = {0u, 0u, 0u, 0u};
         if (has_pro) {
             float sc[EPC], sh[EPC];
 #pragma unroll
             for (int j = 0; j < EPC; j += 4) {
-                f32x4 s4 = *(const f32x4*)(a.pro_scale + cs + j), t4 = *(const f32x4*)(a.pro_shift + cs + j);
+                f32x4 s4 = *(const f32x4*)(a.pro_scale + S.cs + j), t4 = *(const f32x4*)(a.pro_shift + S.cs + j);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { sc[j + q] = s4[q]; sh[j + q] = t4[q]; }
             }
 #pragma unroll
             for (int i = 0; i < A_PER_T; ++i) {
                 float f[EPC];
-                Vec16<T>::unpack(areg[i], f);
+                Vec16<T>::unpack(S.a[i], f);
 #pragma unroll
                 for (int j = 0; j < EPC; ++j) f[j] = fmaxf(fmaf(f[j], sc[j], sh[j]), relu_lo);
-                areg[i] = Vec16<T>::pack(f);
+                S.a[i] = Vec16<T>::pack(f);
             }
         }
-        const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int i = 0; i < A_PER_T; ++i) areg[i] = okv[i] ? areg[i] : z;
-    };
-    auto store_tile = [&](int buf) {
-        unsigned char* sa = smem + buf * STAGE;
-        unsigned char* sb = sa + BM * CPR * 16;
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) {
             int row = tid / CPR + i * (NT / CPR);
-            *(u32x4*)(sa + lds_off<CPR>(row, chunk)) = areg[i];
+            *(u32x4*)(sa + lds_off<CPR>(row, chunk)) = (S.okmask >> i) & 1u ? S.a[i] : z;
         }
 #pragma unroll
         for (int i = 0; i < B_ITERS; ++i) {
             int p = tid + i * NT;
-            if (p < BN * CPR) *(u32x4*)(sb + lds_off<CPR>(p / CPR, p % CPR)) = breg[i];
+            if (B_ITERS * NT == BN * CPR || p < BN * CPR)
+                *(u32x4*)(sb + lds_off<CPR>(p / CPR, p % CPR)) = (S.okmask >> (16 + i)) & 1u ? S.b[i] : z;
         }
     };
 
@@ -169,14 +173,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_igemm_fwd_ker
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    int tap = 0, cstep = 0;
-    load_tile(0, 0);
-    store_tile(0);
-    __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
-        if (++cstep == a.kpt) { cstep = 0; ++tap; }
-        if (ks + 1 < nk) load_tile(tap, cstep);
+    auto compute = [&](int buf) {
         const unsigned char* sa = smem + buf * STAGE;
         const unsigned char* sb = sa + BM * CPR * 16;
         const int lr = lane & 31, lh = lane >> 5;
@@ -192,7 +189,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_igemm_fwd_ker
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
         }
-        if (ks + 1 < nk) store_tile(buf ^ 1);
+    };
+
+    Stage S0, S1;
+    issue(S0);
+    commit(S0, 0);
+    __syncthreads();
+    if (nk > 1) issue(S0);                       // step 1 in flight
+    for (int ks = 0; ks < nk; ks += 2) {
+        if (ks + 2 < nk) issue(S1);              // step ks+2
+        compute(0);
+        if (ks + 1 < nk) commit(S0, 1);
+        __syncthreads();
+        if (ks + 1 >= nk) break;
+        if (ks + 3 < nk) issue(S0);              // step ks+3
+        compute(1);
+        if (ks + 2 < nk) commit(S1, 0);
         __syncthreads();
     }
 
@@ -227,8 +239,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_igemm_fwd_ker
     }
     __syncthreads();
     if (do_stats && tid < BN && n0 + tid < a.Cout) {
-        atomicAdd(&a.stat_sum[n0 + tid], (double)s_sum[tid]);
-        atomicAdd(&a.stat_sumsq[n0 + tid], (double)s_sq[tid]);
+        const size_t ro = (size_t)(blockIdx.x % a.stat_replicas) * a.stat_rstride;
+        atomicAdd(&a.stat_sum[ro + n0 + tid], (double)s_sum[tid]);
+        atomicAdd(&a.stat_sumsq[ro + n0 + tid], (double)s_sq[tid]);
     }
     constexpr int CH = BN / EPC;  // 16-byte chunks per output row
     T* __restrict__ yg = (T*)a.y;
@@ -301,8 +314,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void conv_igemm_fwd_ker
         for (int j = 0; j < EPC; ++j) { atomicAdd(&s_sum[ch * EPC + j], e1[j]); atomicAdd(&s_sq[ch * EPC + j], e2[j]); }
         __syncthreads();
         if (tid < BN && n0 + tid < a.Cout) {
-            atomicAdd(&a.epi.sums[n0 + tid], (double)s_sum[tid]);
-            atomicAdd(&a.epi.sums[a.Cout + n0 + tid], (double)s_sq[tid]);
+            const size_t ro = (size_t)(blockIdx.x % a.epi.sums_replicas) * a.epi.sums_rstride;
+            atomicAdd(&a.epi.sums[ro + n0 + tid], (double)s_sum[tid]);
+            atomicAdd(&a.epi.sums[ro + a.Cout + n0 + tid], (double)s_sq[tid]);
         }
     }
 }
@@ -362,8 +376,9 @@ int igemm_forward(const saunet_conv_desc* d, const void* x, const void* w, const
                   const float* psh, void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st)
 {
     IgemmArgs a;
-    if (epi) a.epi = *epi; else a.epi.bn_x = nullptr;
+    if (epi) { a.epi = *epi; if (a.epi.sums_replicas < 1) a.epi.sums_replicas = 1; } else a.epi.bn_x = nullptr;
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.pro_scale = ps; a.pro_shift = psh; a.stat_sum = ssum; a.stat_sumsq = ssq;
+    a.stat_replicas = d->stat_replicas > 1 ? d->stat_replicas : 1; a.stat_rstride = d->stat_rstride;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
     a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.ldy = d->ldy;
     a.stride = d->stride; a.pad = d->pad; a.transposed = d->transposed; a.pro_relu = d->pro_relu;

@@ -17,11 +17,12 @@ namespace saunet {
 struct TileArgs {
     const void* x; const void* w; void* y;
     const float* bias; const float* pro_scale; const float* pro_shift;
-    double* stat_sum; double* stat_sumsq;
+    double* stat_sum; double* stat_sumsq; int stat_replicas, stat_rstride;
     int N, H, W, Cin, ldx, Cout, ldy;
     int pro_relu;
     int tiles_x, tiles_y;   // H/16, W/16
     saunet_bn_epilogue epi;
+    int lds_acc_off;        // resident kernel: byte offset of the block-lifetime accumulators in LDS
 };
 
 template <typename T> struct MmaT;
@@ -219,8 +220,9 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64, BNEPI ? 1 : 2) void co
     }
     __syncthreads();
     if (do_stats && tid < BN && n0 + tid < a.Cout) {
-        atomicAdd(&a.stat_sum[n0 + tid], (double)s_sum[tid]);
-        atomicAdd(&a.stat_sumsq[n0 + tid], (double)s_sq[tid]);
+        const size_t ro = (size_t)(blockIdx.x % a.stat_replicas) * a.stat_rstride;
+        atomicAdd(&a.stat_sum[ro + n0 + tid], (double)s_sum[tid]);
+        atomicAdd(&a.stat_sumsq[ro + n0 + tid], (double)s_sq[tid]);
     }
     constexpr int CH = BN / EPC;
     T* __restrict__ yg = (T*)a.y + (size_t)n * a.H * a.W * a.ldy;
@@ -283,8 +285,9 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64, BNEPI ? 1 : 2) void co
         for (int j = 0; j < EPC; ++j) { atomicAdd(&s_sum[ch * EPC + j], e1[j]); atomicAdd(&s_sq[ch * EPC + j], e2[j]); }
         __syncthreads();
         if (tid < BN && n0 + tid < a.Cout) {
-            atomicAdd(&a.epi.sums[n0 + tid], (double)s_sum[tid]);
-            atomicAdd(&a.epi.sums[a.Cout + n0 + tid], (double)s_sq[tid]);
+            const size_t ro = (size_t)(blockIdx.x % a.epi.sums_replicas) * a.epi.sums_rstride;
+            atomicAdd(&a.epi.sums[ro + n0 + tid], (double)s_sum[tid]);
+            atomicAdd(&a.epi.sums[ro + a.Cout + n0 + tid], (double)s_sq[tid]);
         }
     }
 }
@@ -338,8 +341,11 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
     constexpr int TI = WM / 32, TJ = WN / 32;
     static_assert(NT % CPR == 0, "chunk index must be thread-invariant");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // region 0: halo tile, re-used as the output staging tile of the epilogue (whichever is larger); then the weights
+    constexpr int EPI_BYTES = 256 * BN * (int)sizeof(T);
+    constexpr int R0_BYTES = HALO_BYTES > EPI_BYTES ? HALO_BYTES : EPI_BYTES;
     unsigned char* s_halo = smem;
-    unsigned char* s_w = smem + HALO_BYTES;
+    unsigned char* s_w = smem + R0_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
@@ -357,6 +363,27 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
     const int per = (items + gridDim.x - 1) / gridDim.x;
     const int it0 = blockIdx.x * per, it1 = min(it0 + per, items);
     if (it0 >= it1) return;
+
+    // block-lifetime accumulators (statistics / BN-backward sums): flushed to global memory once per n-tile, not per tile
+    float* s_acc = (float*)(smem + a.lds_acc_off);      // [2][BN]
+    for (int i = tid; i < 2 * BN; i += NT) s_acc[i] = 0.f;
+    auto flush_acc = [&](int nt) {
+        __syncthreads();
+        const int n0f = nt * BN;
+        if (tid < BN && n0f + tid < a.Cout) {
+            if constexpr (BNEPI) {
+                const size_t ro = (size_t)(blockIdx.x % a.epi.sums_replicas) * a.epi.sums_rstride;
+                atomicAdd(&a.epi.sums[ro + n0f + tid], (double)s_acc[tid]);
+                atomicAdd(&a.epi.sums[ro + a.Cout + n0f + tid], (double)s_acc[BN + tid]);
+            } else if (a.stat_sum != nullptr) {
+                const size_t ro = (size_t)(blockIdx.x % a.stat_replicas) * a.stat_rstride;
+                atomicAdd(&a.stat_sum[ro + n0f + tid], (double)s_acc[tid]);
+                atomicAdd(&a.stat_sumsq[ro + n0f + tid], (double)s_acc[BN + tid]);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * BN; i += NT) s_acc[i] = 0.f;
+    };
 
     int cur_nt = -1;
     u32x4 hreg[H_ITERS];
@@ -425,6 +452,7 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
         const int nt = item / ntile, tile = item - nt * ntile;
         const int n0 = nt * BN;
         if (nt != cur_nt) {   // (re)load this n-tile's weights: [cb][tap][BN rows][PITCH]
+            if (cur_nt >= 0) flush_acc(cur_nt);
             __syncthreads();
             const int pieces = ncb * 9 * BN * CPR;
             for (int q = tid; q < pieces; q += NT) {
@@ -477,11 +505,9 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
         const int txi = bt % a.tiles_x; bt /= a.tiles_x;
         const int tyi = bt % a.tiles_y; const int n = bt / a.tiles_y;
         const int ty0 = tyi * TILE, tx0 = txi * TILE;
-        float* s_sum = (float*)(s_halo + 256 * BN * sizeof(T));
-        float* s_sq = s_sum + BN;
-        const bool do_stats = a.stat_sum != nullptr;
-        if (do_stats || BNEPI) for (int i = tid; i < 2 * BN; i += NT) s_sum[i] = 0.f;
-        if (do_stats) __syncthreads();
+        float* s_sum = s_acc;
+        float* s_sq = s_acc + BN;
+        const bool do_stats = !BNEPI && a.stat_sum != nullptr;
         T* so = (T*)s_halo;
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
@@ -503,10 +529,6 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
             }
         }
         __syncthreads();
-        if (do_stats && tid < BN && n0 + tid < a.Cout) {
-            atomicAdd(&a.stat_sum[n0 + tid], (double)s_sum[tid]);
-            atomicAdd(&a.stat_sumsq[n0 + tid], (double)s_sq[tid]);
-        }
         constexpr int CH = BN / EPC;
         constexpr int S_ITERS = (256 * CH) / NT;
         static_assert((256 * CH) % NT == 0, "store loop must divide evenly");
@@ -551,11 +573,6 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
             const int ch = tid % CH;
 #pragma unroll
             for (int j = 0; j < EPC; ++j) { atomicAdd(&s_sum[ch * EPC + j], e1[j]); atomicAdd(&s_sq[ch * EPC + j], e2[j]); }
-            __syncthreads();
-            if (tid < BN && n0 + tid < a.Cout) {
-                atomicAdd(&a.epi.sums[n0 + tid], (double)s_sum[tid]);
-                atomicAdd(&a.epi.sums[a.Cout + n0 + tid], (double)s_sq[tid]);
-            }
         } else {
 #pragma unroll
             for (int i = 0; i < S_ITERS; ++i) {
@@ -566,6 +583,7 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
             }
         }
     }
+    flush_acc(cur_nt);
 }
 
 template <typename T, int BN, int WM, int WN, int CPR> static constexpr int res_lds_bytes(int ncb)
@@ -573,14 +591,15 @@ template <typename T, int BN, int WM, int WN, int CPR> static constexpr int res_
     return NPIX * (CPR * 16 + 16) + ncb * 9 * BN * (CPR * 16 + 16);
 }
 
-template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI> static int launch_res_fwd_i(const TileArgs& a, hipStream_t st)
+template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI> static int launch_res_fwd_i(const TileArgs& a_in, hipStream_t st)
 {
+    TileArgs a = a_in;
     constexpr int NT = (256 / WM) * (BN / WN) * 64;
     constexpr int EPC = 16 / sizeof(T);
     const int ncb = (a.Cin + CPR * EPC - 1) / (CPR * EPC);
-    int lds = res_lds_bytes<T, BN, WM, WN, CPR>(ncb);
-    const int epi = 256 * BN * (int)sizeof(T) + 2 * BN * 4;
-    if (epi > NPIX * (CPR * 16 + 16)) lds += epi - NPIX * (CPR * 16 + 16);
+    constexpr int HALO_B = NPIX * (CPR * 16 + 16), EPI_B = 256 * BN * (int)sizeof(T);
+    int lds = (HALO_B > EPI_B ? HALO_B : EPI_B) + ncb * 9 * BN * (CPR * 16 + 16);
+    a.lds_acc_off = lds; lds += 2 * BN * 4;
     auto kern = conv3x3_res_fwd_kernel<T, BN, WM, WN, CPR, BNEPI>;
     static int attr_lds = 0;
     if (lds > attr_lds) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_lds = lds; }
@@ -601,10 +620,9 @@ template <typename T> static int dispatch_res_fwd(const TileArgs& a, hipStream_t
     const int ncb = (a.Cin + cpr * EPC - 1) / (cpr * EPC);
     const int pitch = cpr * 16 + 16;
     const int bn = a.Cout <= 32 ? 32 : (a.Cout <= 64 ? 64 : 128);
-    long lds = (long)NPIX * pitch + (long)ncb * 9 * bn * pitch;
-    const long epi = 256L * bn * sizeof(T) + 2 * bn * 4;
-    if (epi > (long)NPIX * pitch) lds += epi - (long)NPIX * pitch;
-    *handled = lds <= 156 * 1024 && (a.tiles_x * a.tiles_y * a.N) >= 256;
+    const long halo_b = (long)NPIX * pitch, epi_b = 256L * bn * sizeof(T);
+    long lds = (halo_b > epi_b ? halo_b : epi_b) + (long)ncb * 9 * bn * pitch + 2 * bn * 4;
+    *handled = lds <= 154 * 1024 && (a.tiles_x * a.tiles_y * a.N) >= 256;
     if (!*handled) return SAUNET_OK;
 #define RES(BN_, WM_, WN_, CPR_) (a.epi.bn_x ? launch_res_fwd_i<T, BN_, WM_, WN_, CPR_, true>(a, st) : launch_res_fwd_i<T, BN_, WM_, WN_, CPR_, false>(a, st))
     if (bn == 32) return narrow ? RES(32, 64, 32, 4) : RES(32, 64, 32, 8);
@@ -623,8 +641,9 @@ int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const 
                  void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st)
 {
     TileArgs a;
-    if (epi) a.epi = *epi; else a.epi.bn_x = nullptr;
+    if (epi) { a.epi = *epi; if (a.epi.sums_replicas < 1) a.epi.sums_replicas = 1; } else a.epi.bn_x = nullptr;
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.pro_scale = ps; a.pro_shift = psh; a.stat_sum = ssum; a.stat_sumsq = ssq;
+    a.stat_replicas = d->stat_replicas > 1 ? d->stat_replicas : 1; a.stat_rstride = d->stat_rstride;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Cout = d->Cout; a.ldy = d->ldy;
     a.pro_relu = d->pro_relu; a.tiles_y = d->H / TILE; a.tiles_x = d->W / TILE;
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return set_error(SAUNET_BAD_ALIGN, "conv: pointers must be 16-byte aligned");

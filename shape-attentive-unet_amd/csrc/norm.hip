@@ -27,7 +27,7 @@ template <typename T, int V> struct ChunkIO {
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, long P, int C, int ld, long rpb,
-                                                       double* __restrict__ gsum, double* __restrict__ gsq)
+                                                       double* __restrict__ gsum, double* __restrict__ gsq, int reps, int rstride)
 {
     extern __shared__ double s_red[];  // [2][C]
     for (int i = threadIdx.x; i < 2 * C; i += 256) s_red[i] = 0.0;
@@ -61,10 +61,20 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) { atomicAdd(&gsum[c], s_red[c]); atomicAdd(&gsq[c], s_red[C + c]); }
+    const size_t ro = (size_t)(blockIdx.x % reps) * rstride;
+    for (int c = threadIdx.x; c < C; c += 256) { atomicAdd(&gsum[ro + c], s_red[c]); atomicAdd(&gsq[ro + c], s_red[C + c]); }
 }
 
-__global__ void bn_finalize_kernel(int C, const double* __restrict__ sum, const double* __restrict__ sq, double count,
+__global__ void sum_replicas_kernel(double* __restrict__ base, int n, int reps, int rstride)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = base[i];
+    for (int r = 1; r < reps; ++r) s += base[(size_t)r * rstride + i];
+    base[i] = s;
+}
+
+__global__ void bn_finalize_kernel(int C, const double* __restrict__ sum, const double* __restrict__ sq, int reps, int rstride, double count,
                                    const float* __restrict__ cbias, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
@@ -74,8 +84,10 @@ __global__ void bn_finalize_kernel(int C, const double* __restrict__ sum, const 
     if (c >= C) return;
     float mean, invstd;
     if (training) {
-        double m = sum[c] / count;
-        double var = sq[c] / count - m * m;
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < reps; ++r) { s1 += sum[(size_t)r * rstride + c]; s2 += sq[(size_t)r * rstride + c]; }
+        double m = s1 / count;
+        double var = s2 / count - m * m;
         if (var < 0.0) var = 0.0;
         if (cbias) m += (double)cbias[c];
         mean = (float)m;
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x
 struct BnBwdArgs {
     const void* dy; int lddy; const void* x; int ldx; const void* res; int ldr;
     const float* scale; const float* shift; const float* mean; const float* invstd; int relu;
-    double* sums; double count; int training, accumulate;
+    double* sums; int sreps, srstride; double count; int training, accumulate;
     void* dx; int lddx; void* dres; int lddres; float* dgamma; float* dbeta;
     long P; int C; long rpb;
 };
@@ -183,7 +195,8 @@ template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_reduc
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * a.C; c += 256) atomicAdd(&a.sums[c], s_red[c]);
+    const size_t ro = (size_t)(blockIdx.x % a.sreps) * a.srstride;
+    for (int c = threadIdx.x; c < 2 * a.C; c += 256) atomicAdd(&a.sums[ro + c], s_red[c]);
 }
 
 template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a)
@@ -301,27 +314,36 @@ using namespace saunet;
 
 extern "C" {
 
-int saunet_bn_stats(int dtype, const void* x, int64_t pixels, int C, int ld, double* sum, double* sumsq, void* stream)
+int saunet_sum_replicas(double* base, int n, int replicas, int rstride, void* stream)
 {
+    if (replicas <= 1) return SAUNET_OK;
+    hipLaunchKernelGGL(sum_replicas_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, base, n, replicas, rstride);
+    SAUNET_CHECK_LAUNCH("sum_replicas");
+    return SAUNET_OK;
+}
+
+int saunet_bn_stats(int dtype, const void* x, int64_t pixels, int C, int ld, double* sum, double* sumsq, int replicas, int rstride, void* stream)
+{
+    if (replicas < 1) replicas = 1;
     hipStream_t st = (hipStream_t)stream;
     if (C > 4096) return set_error(SAUNET_UNSUPPORTED, "bn_stats: C=%d > 4096", C);
     const bool vec = vec_ok(dtype, C, {ld}, {x});
     int blocks; const int V = vec ? (dtype == SAUNET_BF16 ? 8 : 4) : 1;
     long rpb = rows_per_block(pixels, C, V, &blocks);
-#define CALL(TT, VV) hipLaunchKernelGGL((bn_stats_kernel<TT, VV>), dim3(blocks), dim3(256), 2 * C * sizeof(double), st, (const TT*)x, (long)pixels, C, ld, rpb, sum, sumsq)
+#define CALL(TT, VV) hipLaunchKernelGGL((bn_stats_kernel<TT, VV>), dim3(blocks), dim3(256), 2 * C * sizeof(double), st, (const TT*)x, (long)pixels, C, ld, rpb, sum, sumsq, replicas, rstride)
     DISPATCH_TV(dtype, vec, CALL);
 #undef CALL
     SAUNET_CHECK_LAUNCH("bn_stats");
     return SAUNET_OK;
 }
 
-int saunet_bn_finalize(int C, const double* sum, const double* sumsq, double count, const float* conv_bias,
+int saunet_bn_finalize(int C, const double* sum, const double* sumsq, int replicas, int rstride, double count, const float* conv_bias,
                        const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, float* scale, float* shift,
                        float* mean, float* invstd, int training, void* stream)
 {
     if (!training && (!running_mean || !running_var)) return set_error(SAUNET_BAD_SHAPE, "bn_finalize: eval mode needs running stats");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, sum, sumsq, count, conv_bias,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, sum, sumsq, replicas < 1 ? 1 : replicas, rstride, count, conv_bias,
                        gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd, training);
     SAUNET_CHECK_LAUNCH("bn_finalize");
     return SAUNET_OK;
@@ -343,12 +365,12 @@ int saunet_affine_act(int dtype, const void* x, int ldx, const float* scale, con
 
 int saunet_bn_backward_reduce(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,
                               const float* scale, const float* shift, const float* mean, const float* invstd,
-                              int relu, double* sums, int64_t pixels, int C, void* stream)
+                              int relu, double* sums, int replicas, int rstride, int64_t pixels, int C, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
     const bool vec = residual ? vec_ok(dtype, C, {lddy, ldx, ldr}, {dy, x, residual}) : vec_ok(dtype, C, {lddy, ldx}, {dy, x});
     BnBwdArgs a{}; a.dy = dy; a.lddy = lddy; a.x = x; a.ldx = ldx; a.res = residual; a.ldr = ldr; a.scale = scale; a.shift = shift;
-    a.mean = mean; a.invstd = invstd; a.relu = relu; a.sums = sums; a.P = pixels; a.C = C;
+    a.mean = mean; a.invstd = invstd; a.relu = relu; a.sums = sums; a.sreps = replicas < 1 ? 1 : replicas; a.srstride = rstride; a.P = pixels; a.C = C;
     int blocks; const int V = vec ? (dtype == SAUNET_BF16 ? 8 : 4) : 1;
     a.rpb = rows_per_block(pixels, C, V, &blocks);
 #define CALL(TT, VV) hipLaunchKernelGGL((bn_bwd_reduce_kernel<TT, VV>), dim3(blocks), dim3(256), 2 * C * sizeof(double), st, a)

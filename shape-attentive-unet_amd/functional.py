@@ -77,7 +77,7 @@ class ZeroArena:
         return out
 
 
-STATS = ZeroArena(torch.float64, 1 << 18)      # 2 MB chunks
+STATS = ZeroArena(torch.float64, 1 << 21)      # 16 MB chunks
 GRADS = ZeroArena(torch.float32, 1 << 24)      # 64 MB chunks
 
 
@@ -86,6 +86,21 @@ def zeros_f64(*shape, device):
     for s_ in shape:
         n *= s_
     return STATS.take(n, device).view(*shape)
+
+
+STAT_R = 16   # replicated statistic accumulators (see saunet_conv_desc.stat_replicas)
+
+
+def new_stats(c, device):
+    """zeroed float64 accumulators [R, 2, C]: row 0 = sum, row 1 = sum of squares (or sum g / sum g*xhat in backward)"""
+    return zeros_f64(STAT_R, 2, c, device=device)
+
+
+def collapse_stats(st):
+    """sum the replicas into replica 0 and return it as a flat [2*C] view"""
+    r, two, c = st.shape
+    L.call("saunet_sum_replicas", st.data_ptr(), 2 * c, r, st.stride(0), L.stream())
+    return st[0].reshape(2 * c)
 
 
 def begin_step():
@@ -185,6 +200,7 @@ def _desc(x, cout, ldy, ho, wo, kh, kw, stride, pad, transposed=False, pro_relu=
     d.KH, d.KW, d.stride, d.pad = kh, kw, stride, pad
     d.transposed = 1 if transposed else 0
     d.pro_relu = 1 if pro_relu else 0
+    d.stat_replicas, d.stat_rstride = 1, 0
     return d
 
 
@@ -196,7 +212,8 @@ def conv_out_hw(h, w, kh, kw, stride, pad, transposed):
 
 def conv_forward_raw(x, weight, bias, stride, pad, transposed=False, pro=None, out=None, stats=None):
     """y = conv(prologue(x), weight) + bias.  pro = (scale, shift, relu) or None.
-    out: optional pre-allocated (channel-slice) destination.  stats = (sum, sumsq) float64 accumulators."""
+    out: optional pre-allocated (channel-slice) destination.  stats = [R, 2, Cout] float64 accumulators (may be a
+    channel slice of a wider [R, 2, Ctot] buffer)."""
     _check_dev(x)
     x = nhwc(x)
     if transposed:
@@ -210,9 +227,11 @@ def conv_forward_raw(x, weight, bias, stride, pad, transposed=False, pro=None, o
         out = new_act(x.shape[0], cout, ho, wo, x.dtype, x.device)
     wp = PACKS.get(weight, L.PACK_CONVT_FWD if transposed else L.PACK_FWD, x.dtype)
     d = _desc(x, cout, ld_of(out), ho, wo, kh, kw, stride, pad, transposed, bool(pro and pro[2]))
+    if stats is not None:
+        d.stat_replicas, d.stat_rstride = stats.shape[0], stats.stride(0)
     L.call("saunet_conv2d_forward", C.byref(d), x.data_ptr(), wp.data_ptr(), L.ptr(bias),
            L.ptr(pro[0]) if pro else None, L.ptr(pro[1]) if pro else None, out.data_ptr(),
-           L.ptr(stats[0]) if stats else None, L.ptr(stats[1]) if stats else None, L.stream())
+           stats[0, 0].data_ptr() if stats is not None else None, stats[0, 1].data_ptr() if stats is not None else None, L.stream())
     return out
 
 
@@ -246,6 +265,7 @@ def conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed=False, out=None,
         e.accumulate = 1 if (len(bn_epi) > 4 and bn_epi[4]) else 0
         e.scale, e.shift, e.mean, e.invstd = p.scale.data_ptr(), p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr()
         e.sums = sums.data_ptr()
+        e.sums_replicas, e.sums_rstride = (sums.shape[0], sums.stride(0)) if sums.dim() == 3 else (1, 0)
         L.call("saunet_conv2d_forward_ex", C.byref(d), dy.data_ptr(), wp.data_ptr(), None, None, None, out.data_ptr(), None, None,
                C.byref(e), L.stream())
         return out
@@ -343,8 +363,9 @@ def bn_stats(x, stats=None):
     x = nhwc(x)
     n, c, h, w = x.shape
     if stats is None:
-        stats = zeros_f64(2, c, device=x.device)
-    L.call("saunet_bn_stats", L.dtype_code(x), x.data_ptr(), n * h * w, c, ld_of(x), stats[0].data_ptr(), stats[1].data_ptr(), L.stream())
+        stats = new_stats(c, x.device)
+    L.call("saunet_bn_stats", L.dtype_code(x), x.data_ptr(), n * h * w, c, ld_of(x), stats[0, 0].data_ptr(), stats[0, 1].data_ptr(),
+           stats.shape[0], stats.stride(0), L.stream())
     return stats
 
 
@@ -361,10 +382,13 @@ class BNParams:
     invstd = property(lambda s: s.buf[3])
 
 
-def bn_finalize(stats_sum, stats_sq, count, gamma, beta, rmean, rvar, momentum, eps, training, conv_bias=None):
+def bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum, eps, training, conv_bias=None):
+    """stats: [R, 2, C] accumulators (or a channel slice of them); None in eval mode"""
     c = gamma.shape[0]
     p = BNParams(c, gamma.device)
-    L.call("saunet_bn_finalize", c, L.ptr(stats_sum), L.ptr(stats_sq), float(count), L.ptr(conv_bias), gamma.data_ptr(),
+    reps, rstr = (stats.shape[0], stats.stride(0)) if stats is not None else (1, 0)
+    L.call("saunet_bn_finalize", c, stats[0, 0].data_ptr() if stats is not None else None,
+           stats[0, 1].data_ptr() if stats is not None else None, reps, rstr, float(count), L.ptr(conv_bias), gamma.data_ptr(),
            beta.data_ptr(), float(eps), float(momentum), L.ptr(rmean), L.ptr(rvar), p.scale.data_ptr(), p.shift.data_ptr(),
            p.mean.data_ptr(), p.invstd.data_ptr(), 1 if training else 0, L.stream())
     return p
@@ -398,11 +422,13 @@ def bn_backward(dy, x, p, relu, count, training, residual=None, dx=None, accumul
     dt = L.dtype_code(x)
     if presums is not None:
         # dy is already g = dy*[relu mask] and the two sums were taken in the producing dgrad kernel's epilogue
-        sums, relu = presums, False
+        sums, relu = collapse_stats(presums), False
     else:
-        sums = zeros_f64(2 * c, device=dev)
+        st = new_stats(c, dev)
         L.call("saunet_bn_backward_reduce", dt, dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), rp, rl, p.scale.data_ptr(),
-               p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), 1 if relu else 0, sums.data_ptr(), P, c, L.stream())
+               p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), 1 if relu else 0, st.data_ptr(), st.shape[0], st.stride(0),
+               P, c, L.stream())
+        sums = collapse_stats(st)
     if sync_group is not None and training:
         torch.distributed.all_reduce(sums, group=sync_group)
     if dx is None:
@@ -467,15 +493,14 @@ class _ConvBNAct(torch.autograd.Function):
     def forward(ctx, x, weight, bias, gamma, beta, rmean, rvar, residual, stride, pad, transposed, relu, momentum, eps, training, group):
         x = nhwc(x)
         cout = weight.shape[1] if transposed else weight.shape[0]
-        stats = zeros_f64(2, cout, device=x.device) if training else None
-        z = conv_forward_raw(x, weight, bias, stride, pad, transposed, stats=(stats[0], stats[1]) if training else None)
+        stats = new_stats(cout, x.device) if training else None
+        z = conv_forward_raw(x, weight, bias, stride, pad, transposed, stats=stats)
         count = z.shape[0] * z.shape[2] * z.shape[3]
         if group is not None and training:
             # SynchronizedBatchNorm: global batch statistics = all-reduce of (sum, sumsq); count scales with the world
             torch.distributed.all_reduce(stats, group=group)
             count *= torch.distributed.get_world_size(group)
-        p = bn_finalize(stats[0] if training else None, stats[1] if training else None, count, gamma, beta, rmean, rvar,
-                        momentum, eps, training, conv_bias=bias)
+        p = bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum, eps, training, conv_bias=bias)
         y = affine_act(z, p.scale, p.shift, relu, residual)
         ctx.save_for_backward(x, weight, z, p.buf, residual if residual is not None else z.new_empty(0))
         ctx.cfg = (stride, pad, transposed, relu, training, count, bias is not None, residual is not None, group)
@@ -524,8 +549,7 @@ class _BNAct(torch.autograd.Function):
         count = n * h * w
         if training and stats is None:
             stats = bn_stats(x)
-        p = bn_finalize(stats[0] if training else None, stats[1] if training else None, count, gamma, beta, rmean, rvar,
-                        momentum, eps, training)
+        p = bn_finalize(stats if training else None, count, gamma, beta, rmean, rvar, momentum, eps, training)
         y = affine_act(x, p.scale, p.shift, relu)
         ctx.save_for_backward(x, p.buf)
         ctx.cfg = (relu, training, count)
@@ -894,30 +918,30 @@ class _DenseBlock(torch.autograd.Function):
         ctot = c0 + growth * nl
         dev = x0.device
         buf = new_act(n, ctot, h, w, x0.dtype, dev)
-        stats = zeros_f64(2, ctot, device=dev)
+        stats = new_stats(ctot, dev)
         copy_channels(x0, buf[:, :c0])
         count = n * h * w
         if training:
-            bn_stats(buf[:, :c0], stats[:, :c0])
+            bn_stats(buf[:, :c0], stats[:, :, :c0])
         saved = []
         for l in range(nl):
             n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
             n1rm, n1rv, n2rm, n2rv = bufs[4 * l:4 * l + 4]
             mom, eps = cfgs[l]
             cin = c0 + growth * l
-            p1 = bn_finalize(stats[0, :cin], stats[1, :cin], count, n1w, n1b, n1rm, n1rv, mom, eps, training)
-            st2 = zeros_f64(2, c1w.shape[0], device=dev) if training else None
-            z1 = conv_forward_raw(buf[:, :cin], c1w, None, 1, 0, pro=(p1.scale, p1.shift, True),
-                                  stats=(st2[0], st2[1]) if training else None)
-            p2 = bn_finalize(st2[0] if training else None, st2[1] if training else None, count, n2w, n2b, n2rm, n2rv, mom, eps, training)
+            p1 = bn_finalize(stats[:, :, :cin] if training else None, count, n1w, n1b, n1rm, n1rv, mom, eps, training)
+            st2 = new_stats(c1w.shape[0], dev) if training else None
+            z1 = conv_forward_raw(buf[:, :cin], c1w, None, 1, 0, pro=(p1.scale, p1.shift, True), stats=st2)
+            p2 = bn_finalize(st2, count, n2w, n2b, n2rm, n2rv, mom, eps, training)
             conv_forward_raw(z1, c2w, None, 1, 1, pro=(p2.scale, p2.shift, True), out=buf[:, cin:cin + growth],
-                             stats=(stats[0, cin:cin + growth], stats[1, cin:cin + growth]) if training else None)
+                             stats=stats[:, :, cin:cin + growth] if training else None)
             saved += [z1, p1.buf, p2.buf]
         # xhat = x*xs + xt for every concat channel (gamma=1, beta=0): what the deferred backward correction needs
         xh = torch.zeros(2, ctot, dtype=torch.float32, device=dev)
         if training:
             one, zero = _const_vec(ctot, dev, 1.0), _const_vec(ctot, dev, 0.0)
-            L.call("saunet_bn_finalize", ctot, stats[0].data_ptr(), stats[1].data_ptr(), float(count), None, one.data_ptr(), zero.data_ptr(),
+            L.call("saunet_bn_finalize", ctot, stats[0, 0].data_ptr(), stats[0, 1].data_ptr(), stats.shape[0], stats.stride(0), float(count),
+                   None, one.data_ptr(), zero.data_ptr(),
                    float(cfgs[0][1]), 0.0, None, None, xh[0].data_ptr(), xh[1].data_ptr(), None, None, 1, L.stream())
         ctx.save_for_backward(buf, xh, *params, *saved)
         ctx.meta = (nl, c0, growth, count, training)
@@ -957,14 +981,14 @@ class _DenseBlock(torch.autograd.Function):
             correct(cin, cin + growth)
             dz2 = dbuf[:, cin:cin + growth]
             dw2 = conv_wgrad_raw(z1, dz2, c2w, 1, 1, pro=(p2.scale, p2.shift, True))
-            s2 = zeros_f64(2 * z1.shape[1], device=dev)
+            s2 = new_stats(z1.shape[1], dev)
             da2 = conv_dgrad_raw(dz2, c2w, z1.shape, 1, 1, bn_epi=(z1, p2, True, s2))
             dz1, _, dg2, db2 = bn_backward(da2, z1, p2, True, count, training, dx=da2, presums=s2)
             dw1 = conv_wgrad_raw(xin, dz1, c1w, 1, 0, pro=(p1.scale, p1.shift, True))
-            s1 = zeros_f64(2 * cin, device=dev)
+            s1 = new_stats(cin, dev)
             conv_dgrad_raw(dz1, c1w, (n, cin, h, w), 1, 0, out=dbuf[:, :cin], bn_epi=(xin, p1, True, s1, True))
             dgb = torch.empty(2, cin, dtype=torch.float32, device=dev)
-            L.call("saunet_bn_backward_coeff", cin, s1.data_ptr(), float(count), p1.scale.data_ptr(), AB[0].data_ptr(), AB[1].data_ptr(),
+            L.call("saunet_bn_backward_coeff", cin, collapse_stats(s1).data_ptr(), float(count), p1.scale.data_ptr(), AB[0].data_ptr(), AB[1].data_ptr(),
                    dgb[0].data_ptr(), dgb[1].data_ptr(), 1 if training else 0, L.stream())
             grads[6 * l:6 * l + 6] = [dgb[0], dgb[1], dw1, dg2, db2, dw2]
         correct(0, c0)
@@ -991,7 +1015,7 @@ class _Transition(torch.autograd.Function):
         buf = nhwc(buf)
         n, c, h, w = buf.shape
         count = n * h * w
-        p = bn_finalize(stats[0] if training else None, stats[1] if training else None, count, gamma, beta, rmean, rvar, momentum, eps, training)
+        p = bn_finalize(stats if training else None, count, gamma, beta, rmean, rvar, momentum, eps, training)
         z = conv_forward_raw(buf, weight, None, 1, 0, pro=(p.scale, p.shift, True))
         y = new_act(n, z.shape[1], h // 2, w // 2, z.dtype, z.device)
         L.call("saunet_pool2x2_forward", L.dtype_code(z), 0, z.data_ptr(), n, h, w, z.shape[1], ld_of(z), y.data_ptr(), ld_of(y), L.stream())
@@ -1010,7 +1034,7 @@ class _Transition(torch.autograd.Function):
         dz = new_act(n, co, h, w, dy.dtype, dy.device)
         L.call("saunet_pool2x2_backward", L.dtype_code(dy), 0, None, dy.data_ptr(), n, h, w, co, 0, ld_of(dy), dz.data_ptr(), ld_of(dz), 0, L.stream())
         dw = conv_wgrad_raw(buf, dz, weight, 1, 0, pro=(p.scale, p.shift, True))
-        sb = zeros_f64(2 * c, device=buf.device)
+        sb = new_stats(c, buf.device)
         da = conv_dgrad_raw(dz, weight, buf.shape, 1, 0, bn_epi=(buf, p, True, sb))
         dbuf, _, dg, db = bn_backward(da, buf, p, True, count, training, dx=da, presums=sb)
         return dbuf, None, dg, db, None, None, dw, None, None, None

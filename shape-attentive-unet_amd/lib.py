@@ -18,13 +18,13 @@ PACK_FWD, PACK_DGRAD, PACK_CONVT_FWD, PACK_CONVT_DGRAD = 0, 1, 2, 3
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dtype", "N", "H", "W", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "KH", "KW", "stride", "pad",
-        "transposed", "pro_relu")]
+        "transposed", "pro_relu", "stat_replicas", "stat_rstride")]
 
 
 class BnEpilogue(C.Structure):
     _fields_ = [("bn_x", C.c_void_p), ("ld_bn_x", C.c_int32), ("relu", C.c_int32), ("accumulate", C.c_int32), ("reserved", C.c_int32),
                 ("scale", C.c_void_p), ("shift", C.c_void_p),
-                ("mean", C.c_void_p), ("invstd", C.c_void_p), ("sums", C.c_void_p)]
+                ("mean", C.c_void_p), ("invstd", C.c_void_p), ("sums", C.c_void_p), ("sums_replicas", C.c_int32), ("sums_rstride", C.c_int32)]
 
 
 class PackList(C.Structure):
@@ -46,10 +46,11 @@ _SIGS = {
     "saunet_conv2d_wgrad": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i64, vp],
     "saunet_conv2d_wgrad_workspace": [C.POINTER(ConvDesc)],
     "saunet_channel_sum": [i32, vp, i64, i32, i32, vp, vp],
-    "saunet_bn_stats": [i32, vp, i64, i32, i32, vp, vp, vp],
-    "saunet_bn_finalize": [i32, vp, vp, f64, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp],
+    "saunet_bn_stats": [i32, vp, i64, i32, i32, vp, vp, i32, i32, vp],
+    "saunet_sum_replicas": [vp, i32, i32, i32, vp],
+    "saunet_bn_finalize": [i32, vp, vp, i32, i32, f64, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp],
     "saunet_affine_act": [i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, i64, i32, vp],
-    "saunet_bn_backward_reduce": [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i64, i32, vp],
+    "saunet_bn_backward_reduce": [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, i32, i64, i32, vp],
     "saunet_bn_backward_apply": [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, f64, i32, i32,
                                  vp, i32, vp, i32, vp, vp, i64, i32, vp],
     "saunet_bn_backward_coeff": [i32, vp, f64, vp, vp, vp, vp, vp, i32, vp],

@@ -44,6 +44,10 @@ def close(a, b, tol, what=""):
 
 
 CONV_CASES = [
+    # >= 256 pixel tiles: the persistent resident-weight 3x3 kernel (conv3x3_res_fwd_kernel) takes these
+    (4, 128, 128, 128, 32, 3, 1, 1),   # DenseNet conv2 forward geometry; its dgrad is the BN=128 narrow-K variant
+    (4, 64, 128, 128, 64, 3, 1, 1),    # res1
+    (1, 16, 256, 256, 16, 3, 1, 1),    # res3
     # (N, Cin, H, W, Cout, k, stride, pad)
     (2, 128, 16, 16, 32, 3, 1, 1),     # DenseNet conv2
     (2, 64, 16, 16, 128, 1, 1, 0),     # DenseNet conv1
@@ -113,9 +117,10 @@ def test_conv_prologue_stats_and_channel_slices(dtype):
         a = q(a, dtype)
     yr = F.conv2d(a, q(wt, dtype), None, 1, 1)
     bd = to_dev(buf, dtype)
-    stats = torch.zeros(2, ctot, dtype=torch.float64, device="cuda")
+    stats_r = torch.zeros(hf.STAT_R, 2, ctot, dtype=torch.float64, device="cuda")      # replicated accumulators
     hf.conv_forward_raw(bd[:, :cin], wt.cuda(), None, 1, 1, pro=(scale.cuda(), shift.cuda(), True), out=bd[:, 128:160],
-                        stats=(stats[0, 128:160], stats[1, 128:160]))
+                        stats=stats_r[:, :, 128:160])
+    stats = stats_r.sum(0)
     tol = TOL[dtype]
     close(bd[:, 128:160], yr, tol, "slice out")
     close(bd[:, :128], q(buf, dtype)[:, :128], 0, "untouched channels")

@@ -86,7 +86,7 @@ def test_sgd_trajectory_config1():
     assert traj[-1] < traj[0] - 0.5
 
 
-@pytest.mark.parametrize("B,H,W,seed", [(1, 64, 96, 7), (3, 64, 64, 9)])
+@pytest.mark.parametrize("B,H,W,seed", [(1, 64, 96, 7), (3, 64, 64, 9), (4, 256, 256, 13)])   # the last one reaches every large-grid kernel variant
 def test_other_shapes_against_oracle(B, H, W, seed):
     S, spec, sd, net, sm = make_net(seed)
     img, seg, edge = Wt.synthetic_batch(B, H, W, seed=100 + seed)
