@@ -10,6 +10,7 @@ namespace saunet {
 // ------------------------------------------------------------------------------------------ bilinear
 struct BilArgs {
     const void* src; void* dst; int N, H, W, C, lds, Ho, Wo, ldd; float sy, sx; int accumulate;
+    FastDiv dcv, dwo, dho, dw, dh;     // channel groups, output width/height, input width/height
 };
 
 __device__ __forceinline__ void bil_coord(int o, float scale, int in, int& i0, int& i1, float& l1)
@@ -21,23 +22,48 @@ __device__ __forceinline__ void bil_coord(int o, float scale, int in, int& i0, i
     l1 = s - (float)i0;
 }
 
-// one thread per (output pixel, channel): y = hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11)
-template <typename T> __global__ __launch_bounds__(256) void bilinear_fwd_kernel(BilArgs a)
+// V consecutive channels (one 16-byte vector, or a single element when V == 1) of one output pixel per thread:
+// y = hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11).  The kernel is write-bound (the source is 4..256x smaller).
+template <typename T, int V> __global__ __launch_bounds__(256) void bilinear_fwd_kernel(BilArgs a)
 {
-    const long total = (long)a.N * a.Ho * a.Wo * a.C;
+    const unsigned CV = a.C / V;
+    const unsigned total = (unsigned)a.N * a.Ho * a.Wo * CV;
     const T* x = (const T*)a.src; T* y = (T*)a.dst;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        int c = (int)(i % a.C); long t = i / a.C;
-        int ow = (int)(t % a.Wo); t /= a.Wo; int oh = (int)(t % a.Ho); int n = (int)(t / a.Ho);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned t = a.dcv.div(i); const int c = (int)(i - t * CV) * V;
+        const unsigned t2 = a.dwo.div(t); const int ow = (int)(t - t2 * a.Wo);
+        const unsigned n = a.dho.div(t2); const int oh = (int)(t2 - n * a.Ho);
         int y0, y1, x0, x1; float ly, lx;
         bil_coord(oh, a.sy, a.H, y0, y1, ly); bil_coord(ow, a.sx, a.W, x0, x1, lx);
         const float hy = 1.f - ly, hx = 1.f - lx;
-        const T* b = x + (long)n * a.H * a.W * a.lds + c;
-        float v00 = Elem<T>::load(b + ((long)y0 * a.W + x0) * a.lds), v01 = Elem<T>::load(b + ((long)y0 * a.W + x1) * a.lds);
-        float v10 = Elem<T>::load(b + ((long)y1 * a.W + x0) * a.lds), v11 = Elem<T>::load(b + ((long)y1 * a.W + x1) * a.lds);
-        float v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
-        Elem<T>::store(y + (((long)n * a.Ho + oh) * a.Wo + ow) * a.ldd + c, v);
+        const T* b = x + (size_t)n * a.H * a.W * a.lds + c;
+        const T* p00 = b + ((size_t)y0 * a.W + x0) * a.lds; const T* p01 = b + ((size_t)y0 * a.W + x1) * a.lds;
+        const T* p10 = b + ((size_t)y1 * a.W + x0) * a.lds; const T* p11 = b + ((size_t)y1 * a.W + x1) * a.lds;
+        T* o = y + (size_t)t * a.ldd + c;
+        if constexpr (V == 1) {
+            float v00 = Elem<T>::load(p00), v01 = Elem<T>::load(p01), v10 = Elem<T>::load(p10), v11 = Elem<T>::load(p11);
+            Elem<T>::store(o, hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11));
+        } else {
+            const u32x4 r00 = *(const u32x4*)p00, r01 = *(const u32x4*)p01, r10 = *(const u32x4*)p10, r11 = *(const u32x4*)p11;
+            float f00[V], f01[V], f10[V], f11[V], r[V];
+            Vec16<T>::unpack(r00, f00); Vec16<T>::unpack(r01, f01); Vec16<T>::unpack(r10, f10); Vec16<T>::unpack(r11, f11);
+#pragma unroll
+            for (int j = 0; j < V; ++j) r[j] = hy * (hx * f00[j] + lx * f01[j]) + ly * (hx * f10[j] + lx * f11[j]);
+            *(u32x4*)o = Vec16<T>::pack(r);
+        }
     }
+}
+
+// window of output rows (or columns) whose two sources can include input index i
+__device__ __forceinline__ void bil_window(int i, float scale, int on, int& lo, int& hi)
+{
+    lo = 0; hi = on - 1;
+    if (scale > 0.f) { lo = max(0, (int)floorf((i - 1) / scale)); hi = min(on - 1, (int)ceilf((i + 1) / scale)); }
+}
+__device__ __forceinline__ float bil_weight(int o, float scale, int in, int i)
+{
+    int i0, i1; float l; bil_coord(o, scale, in, i0, i1, l);
+    return (i0 == i ? 1.f - l : 0.f) + (i1 == i ? l : 0.f);
 }
 
 // gather form of the adjoint (deterministic, no atomics, dtype-agnostic): for every INPUT pixel visit the output
@@ -45,29 +71,27 @@ template <typename T> __global__ __launch_bounds__(256) void bilinear_fwd_kernel
 template <typename T, int V> __global__ __launch_bounds__(256) void bilinear_bwd_kernel(BilArgs a)
 {
     // here src = dy [N,Ho,Wo,C] (lds), dst = dx [N,H,W,C] (ldd)
-    const int CV = a.C / V;
-    const long total = (long)a.N * a.H * a.W * CV;
+    const unsigned CV = a.C / V;
+    const unsigned total = (unsigned)a.N * a.H * a.W * CV;
     const T* dy = (const T*)a.src; T* dx = (T*)a.dst;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        int c = (int)(i % CV) * V; long t = i / CV;
-        int ix = (int)(t % a.W); t /= a.W; int iy = (int)(t % a.H); int n = (int)(t / a.H);
-        int oy_lo = 0, oy_hi = a.Ho - 1, ox_lo = 0, ox_hi = a.Wo - 1;
-        if (a.sy > 0.f) { oy_lo = max(0, (int)floorf((iy - 1) / a.sy)); oy_hi = min(a.Ho - 1, (int)ceilf((iy + 1) / a.sy)); }
-        if (a.sx > 0.f) { ox_lo = max(0, (int)floorf((ix - 1) / a.sx)); ox_hi = min(a.Wo - 1, (int)ceilf((ix + 1) / a.sx)); }
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned t = a.dcv.div(i); const int c = (int)(i - t * CV) * V;
+        const unsigned t2 = a.dw.div(t); const int ix = (int)(t - t2 * a.W);
+        const unsigned n = a.dh.div(t2); const int iy = (int)(t2 - n * a.H);
+        int oy_lo, oy_hi, ox_lo, ox_hi;
+        bil_window(iy, a.sy, a.Ho, oy_lo, oy_hi); bil_window(ix, a.sx, a.Wo, ox_lo, ox_hi);
         float acc[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[j] = 0.f;
-        const T* b = dy + (long)n * a.Ho * a.Wo * a.lds + c;
+        const T* b = dy + (size_t)n * a.Ho * a.Wo * a.lds + c;
         for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-            int y0, y1; float ly; bil_coord(oy, a.sy, a.H, y0, y1, ly);
-            float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+            const float wy = bil_weight(oy, a.sy, a.H, iy);
             if (wy == 0.f) continue;
             for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-                int x0, x1; float lx; bil_coord(ox, a.sx, a.W, x0, x1, lx);
-                float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+                const float wx = bil_weight(ox, a.sx, a.W, ix);
                 if (wx == 0.f) continue;
                 const float wgt = wy * wx;
-                const T* q = b + ((long)oy * a.Wo + ox) * a.lds;
+                const T* q = b + ((size_t)oy * a.Wo + ox) * a.lds;
                 if constexpr (V == 1) acc[0] = fmaf(wgt, Elem<T>::load(q), acc[0]);
                 else {
                     float f[V];
@@ -77,7 +101,7 @@ template <typename T, int V> __global__ __launch_bounds__(256) void bilinear_bwd
                 }
             }
         }
-        T* o = dx + (((long)n * a.H + iy) * a.W + ix) * a.ldd + c;
+        T* o = dx + (size_t)t * a.ldd + c;
         if constexpr (V == 1) {
             if (a.accumulate) acc[0] += Elem<T>::load(o);
             Elem<T>::store(o, acc[0]);
@@ -89,6 +113,36 @@ template <typename T, int V> __global__ __launch_bounds__(256) void bilinear_bwd
                 for (int j = 0; j < V; ++j) acc[j] += f[j];
             }
             *(u32x4*)o = Vec16<T>::pack(acc);
+        }
+    }
+}
+
+// Same adjoint for few-channel maps under a large zoom (the 1-channel c3/c4/c5 edge maps, 8..32x): one WAVE per
+// (input pixel, channel); the lanes share the output window and a wave reduction finishes the sum.
+template <typename T> __global__ __launch_bounds__(256) void bilinear_bwd_wave_kernel(BilArgs a)
+{
+    const unsigned total = (unsigned)a.N * a.H * a.W * a.C;
+    const T* dy = (const T*)a.src; T* dx = (T*)a.dst;
+    const int lane = threadIdx.x & 63;
+    for (unsigned i = blockIdx.x * 4u + (threadIdx.x >> 6); i < total; i += gridDim.x * 4u) {
+        const unsigned t = a.dcv.div(i); const int c = (int)(i - t * a.C);
+        const unsigned t2 = a.dw.div(t); const int ix = (int)(t - t2 * a.W);
+        const unsigned n = a.dh.div(t2); const int iy = (int)(t2 - n * a.H);
+        int oy_lo, oy_hi, ox_lo, ox_hi;
+        bil_window(iy, a.sy, a.Ho, oy_lo, oy_hi); bil_window(ix, a.sx, a.Wo, ox_lo, ox_hi);
+        const int ww = ox_hi - ox_lo + 1, cnt = (oy_hi - oy_lo + 1) * ww;
+        const T* b = dy + (size_t)n * a.Ho * a.Wo * a.lds + c;
+        float acc = 0.f;
+        for (int k = lane; k < cnt; k += 64) {
+            const int r = k / ww, oy = oy_lo + r, ox = ox_lo + (k - r * ww);
+            const float wgt = bil_weight(oy, a.sy, a.H, iy) * bil_weight(ox, a.sx, a.W, ix);
+            acc = fmaf(wgt, Elem<T>::load(b + ((size_t)oy * a.Wo + ox) * a.lds), acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            T* o = dx + (size_t)t * a.ldd + c;
+            if (a.accumulate) acc += Elem<T>::load(o);
+            Elem<T>::store(o, acc);
         }
     }
 }
@@ -177,6 +231,31 @@ __global__ __launch_bounds__(256) void copy_channels_kernel(const TS* __restrict
         float v = Elem<TS>::load(s + p * lds + c);
         if (acc) v += Elem<TD>::load(d + p * ldd + c);
         Elem<TD>::store(d + p * ldd + c, v);
+    }
+}
+
+// 8 consecutive elements as floats (two 16-byte vectors of f32, one of bf16)
+__device__ __forceinline__ void load8(const float* p, float* f) { Vec16<float>::unpack(*(const u32x4*)p, f); Vec16<float>::unpack(*(const u32x4*)(p + 4), f + 4); }
+__device__ __forceinline__ void load8(const u16* p, float* f) { Vec16<u16>::unpack(*(const u32x4*)p, f); }
+__device__ __forceinline__ void store8(float* p, const float* f) { *(u32x4*)p = Vec16<float>::pack(f); *(u32x4*)(p + 4) = Vec16<float>::pack(f + 4); }
+__device__ __forceinline__ void store8(u16* p, const float* f) { *(u32x4*)p = Vec16<u16>::pack(f); }
+
+// vector form: rows are 16-byte aligned on both sides and C % 8 == 0; one thread moves 8 channels
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void copy_channels_vec_kernel(const TS* __restrict__ s, int lds, TD* __restrict__ d, int ldd, unsigned total, FastDiv dcv, int acc)
+{
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned p = dcv.div(i); const int c = (int)(i - p * dcv.d) * 8;
+        float f[8];
+        load8(s + (size_t)p * lds + c, f);
+        TD* o = d + (size_t)p * ldd + c;
+        if (acc) {
+            float g[8];
+            load8(o, g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += g[j];
+        }
+        store8(o, f);
     }
 }
 
@@ -379,25 +458,49 @@ using namespace saunet;
 
 extern "C" {
 
+static int bil_args(BilArgs& a, const void* src, void* dst, int N, int H, int W, int C, int lds, int Ho, int Wo, int ldd, int accumulate, int V, bool over_input)
+{
+    const long total = (long)N * (over_input ? (long)H * W : (long)Ho * Wo) * (C / V);
+    if (total >= (1L << 32)) return set_error(SAUNET_UNSUPPORTED, "bilinear: %ld work items exceed 32-bit indexing", total);
+    a = BilArgs{src, dst, N, H, W, C, lds, Ho, Wo, ldd, Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f, accumulate,
+                FastDiv::make((unsigned)(C / V)), FastDiv::make((unsigned)Wo), FastDiv::make((unsigned)Ho), FastDiv::make((unsigned)W), FastDiv::make((unsigned)H)};
+    return SAUNET_OK;
+}
+
 int saunet_bilinear_forward(int dtype, const void* x, int N, int H, int W, int C, int ldx, void* y, int Ho, int Wo, int ldy, void* stream)
 {
-    BilArgs a{x, y, N, H, W, C, ldx, Ho, Wo, ldy, Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f, 0};
-    const long total = (long)N * Ho * Wo * C;
-#define CALL(TT) hipLaunchKernelGGL(bilinear_fwd_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a)
-    DISPATCH_T(dtype, CALL);
-#undef CALL
+    const int epc = dtype == SAUNET_BF16 ? 8 : 4;
+    const bool vec = C % epc == 0 && ldx % epc == 0 && ldy % epc == 0 && !(((uintptr_t)x | (uintptr_t)y) & 15);
+    BilArgs a;
+    if (int rc = bil_args(a, x, y, N, H, W, C, ldx, Ho, Wo, ldy, 0, vec ? epc : 1, false)) return rc;
+    const long total = (long)N * Ho * Wo * (vec ? C / epc : C);
+    long blocks = (total + 255) / 256; if (blocks > 32768) blocks = 32768; if (blocks < 1) blocks = 1;
+    hipStream_t st = (hipStream_t)stream; dim3 g((unsigned)blocks);
+    if (dtype == SAUNET_F32) { if (vec) hipLaunchKernelGGL((bilinear_fwd_kernel<float, 4>), g, dim3(256), 0, st, a); else hipLaunchKernelGGL((bilinear_fwd_kernel<float, 1>), g, dim3(256), 0, st, a); }
+    else if (dtype == SAUNET_BF16) { if (vec) hipLaunchKernelGGL((bilinear_fwd_kernel<u16, 8>), g, dim3(256), 0, st, a); else hipLaunchKernelGGL((bilinear_fwd_kernel<u16, 1>), g, dim3(256), 0, st, a); }
+    else return set_error(SAUNET_BAD_DTYPE, "dtype %d", dtype);
     SAUNET_CHECK_LAUNCH("bilinear_forward");
     return SAUNET_OK;
 }
 
 int saunet_bilinear_backward(int dtype, const void* dy, int N, int Ho, int Wo, int C, int lddy, void* dx, int H, int W, int lddx, int accumulate, void* stream)
 {
-    BilArgs a{dy, dx, N, H, W, C, lddy, Ho, Wo, lddx, Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f, accumulate};
     const int epc = dtype == SAUNET_BF16 ? 8 : 4;
     const bool vec = C % epc == 0 && lddy % epc == 0 && lddx % epc == 0 && !(((uintptr_t)dy | (uintptr_t)dx) & 15);
+    // outputs gathered per input element; few channels under a large zoom leave too few threads -> one wave per element
+    const long window = ((long)(2 * ((Ho + H - 1) / H) + 1)) * (2 * ((Wo + W - 1) / W) + 1);
+    const bool wave = !vec && window >= 64;
+    BilArgs a;
+    if (int rc = bil_args(a, dy, dx, N, H, W, C, lddy, Ho, Wo, lddx, accumulate, vec ? epc : 1, true)) return rc;
     const long total = (long)N * H * W * (vec ? C / epc : C);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SAUNET_F32) { if (vec) hipLaunchKernelGGL((bilinear_bwd_kernel<float, 4>), dim3(grid_for(total)), dim3(256), 0, st, a); else hipLaunchKernelGGL((bilinear_bwd_kernel<float, 1>), dim3(grid_for(total)), dim3(256), 0, st, a); }
+    if (wave) {
+        long blocks = (total + 3) / 4; if (blocks > 32768) blocks = 32768;
+#define CALL(TT) hipLaunchKernelGGL(bilinear_bwd_wave_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, st, a)
+        DISPATCH_T(dtype, CALL);
+#undef CALL
+    }
+    else if (dtype == SAUNET_F32) { if (vec) hipLaunchKernelGGL((bilinear_bwd_kernel<float, 4>), dim3(grid_for(total)), dim3(256), 0, st, a); else hipLaunchKernelGGL((bilinear_bwd_kernel<float, 1>), dim3(grid_for(total)), dim3(256), 0, st, a); }
     else if (dtype == SAUNET_BF16) { if (vec) hipLaunchKernelGGL((bilinear_bwd_kernel<u16, 8>), dim3(grid_for(total)), dim3(256), 0, st, a); else hipLaunchKernelGGL((bilinear_bwd_kernel<u16, 1>), dim3(grid_for(total)), dim3(256), 0, st, a); }
     else return set_error(SAUNET_BAD_DTYPE, "dtype %d", dtype);
     SAUNET_CHECK_LAUNCH("bilinear_backward");
@@ -445,11 +548,24 @@ int saunet_copy_channels(int dtype_src, int dtype_dst, const void* src, int lds,
 {
     const long total = pixels * C;
     hipStream_t st = (hipStream_t)stream; dim3 g(grid_for(total)), b(256);
-    if (dtype_src == SAUNET_F32 && dtype_dst == SAUNET_F32) hipLaunchKernelGGL((copy_channels_kernel<float, float>), g, b, 0, st, (const float*)src, lds, (float*)dst, ldd, (long)pixels, C, accumulate);
-    else if (dtype_src == SAUNET_F32 && dtype_dst == SAUNET_BF16) hipLaunchKernelGGL((copy_channels_kernel<float, u16>), g, b, 0, st, (const float*)src, lds, (u16*)dst, ldd, (long)pixels, C, accumulate);
-    else if (dtype_src == SAUNET_BF16 && dtype_dst == SAUNET_F32) hipLaunchKernelGGL((copy_channels_kernel<u16, float>), g, b, 0, st, (const u16*)src, lds, (float*)dst, ldd, (long)pixels, C, accumulate);
-    else if (dtype_src == SAUNET_BF16 && dtype_dst == SAUNET_BF16) hipLaunchKernelGGL((copy_channels_kernel<u16, u16>), g, b, 0, st, (const u16*)src, lds, (u16*)dst, ldd, (long)pixels, C, accumulate);
-    else return set_error(SAUNET_BAD_DTYPE, "copy_channels: dtypes %d %d", dtype_src, dtype_dst);
+    if ((dtype_src != SAUNET_F32 && dtype_src != SAUNET_BF16) || (dtype_dst != SAUNET_F32 && dtype_dst != SAUNET_BF16))
+        return set_error(SAUNET_BAD_DTYPE, "copy_channels: dtypes %d %d", dtype_src, dtype_dst);
+    const int as = dtype_src == SAUNET_BF16 ? 8 : 4, ad = dtype_dst == SAUNET_BF16 ? 8 : 4;
+    const bool vec = C % 8 == 0 && lds % as == 0 && ldd % ad == 0 && !(((uintptr_t)src | (uintptr_t)dst) & 15) && total / 8 < (1L << 32);
+    if (vec) {
+        const unsigned tv = (unsigned)(total / 8);
+        long blocks = ((long)tv + 255) / 256; if (blocks > 32768) blocks = 32768; if (blocks < 1) blocks = 1;
+        dim3 gv((unsigned)blocks);
+        const FastDiv dcv = FastDiv::make((unsigned)(C / 8));
+        if (dtype_src == SAUNET_F32 && dtype_dst == SAUNET_F32) hipLaunchKernelGGL((copy_channels_vec_kernel<float, float>), gv, b, 0, st, (const float*)src, lds, (float*)dst, ldd, tv, dcv, accumulate);
+        else if (dtype_src == SAUNET_F32) hipLaunchKernelGGL((copy_channels_vec_kernel<float, u16>), gv, b, 0, st, (const float*)src, lds, (u16*)dst, ldd, tv, dcv, accumulate);
+        else if (dtype_dst == SAUNET_F32) hipLaunchKernelGGL((copy_channels_vec_kernel<u16, float>), gv, b, 0, st, (const u16*)src, lds, (float*)dst, ldd, tv, dcv, accumulate);
+        else hipLaunchKernelGGL((copy_channels_vec_kernel<u16, u16>), gv, b, 0, st, (const u16*)src, lds, (u16*)dst, ldd, tv, dcv, accumulate);
+    }
+    else if (dtype_src == SAUNET_F32 && dtype_dst == SAUNET_F32) hipLaunchKernelGGL((copy_channels_kernel<float, float>), g, b, 0, st, (const float*)src, lds, (float*)dst, ldd, (long)pixels, C, accumulate);
+    else if (dtype_src == SAUNET_F32) hipLaunchKernelGGL((copy_channels_kernel<float, u16>), g, b, 0, st, (const float*)src, lds, (u16*)dst, ldd, (long)pixels, C, accumulate);
+    else if (dtype_dst == SAUNET_F32) hipLaunchKernelGGL((copy_channels_kernel<u16, float>), g, b, 0, st, (const u16*)src, lds, (float*)dst, ldd, (long)pixels, C, accumulate);
+    else hipLaunchKernelGGL((copy_channels_kernel<u16, u16>), g, b, 0, st, (const u16*)src, lds, (u16*)dst, ldd, (long)pixels, C, accumulate);
     SAUNET_CHECK_LAUNCH("copy_channels");
     return SAUNET_OK;
 }
