@@ -161,6 +161,37 @@ int saunet_gate_mul_forward(int dtype, const void* x, int ldx, const void* alpha
 int saunet_gate_mul_backward(int dtype, const void* x, int ldx, const void* alpha, const void* dy, int lddy,
                              void* dx, int lddx, void* dalpha, int64_t pixels, int C, void* stream);
 
+/* ---- fused GatedSpatialConv2d (models/GSConv.py:16-57; call sites models/models.py:341-352) ----------------------
+ * Replaces  cat -> BN(C+1) -> conv1x1(C+1,C+1) -> relu -> conv1x1(C+1,1) -> BN(1) -> sigmoid -> x*(alpha+1) -> conv1x1(C,C)
+ * for C = 8/16/32 feature channels + 1 gating channel, bf16 storage, training-mode batch norm.  One thread owns one
+ * pixel; intermediate maps never reach memory; backward recomputes them.  Parameter vectors are float32:
+ *   bn0 [4][C+1] = scale, shift, mean, invstd of BN(C+1) (saunet_bn_finalize layout);  bn1 [4][1] likewise for BN(1);
+ *   w1 [C+1][C+1], b1 [C+1], w2 [C+1], b2 [1] the two gate convolutions;  wm [C][C] the module weight (no bias).
+ * forward_z:   z[p] = w2 . relu(w1 . bn0(cat_p) + b1) + b2 (float32) and its sum / sum of squares (replicated float64
+ *              accumulators, zeroed by the caller) for BN(1).
+ * forward_out: alpha = sigmoid(bn1(z)) ; y = wm . (feat * (alpha + 1)).
+ * backward_q:  q = dL/d bn1(z) per pixel; dwm [C][C], dbn1 = {dgamma1, dbeta1}, K[3] (dz = K0*q + K1 + K2*z).
+ * backward_sums: dw1, db1, dw2, db2, dbn0 = {dgamma0 [C+1], dbeta0 [C+1]}, E [3][C+1] (dcat = E0*da0 + E1 + E2*cat).
+ * backward_apply: dfeat [P][C], dgate [P].
+ * workspace: saunet_gate_backward_workspace(pixels) bytes, shared by backward_q and backward_sums. */
+int saunet_gate_forward_z(int dtype, int C, const void* feat, int ldf, const void* gate, int ldg, int64_t pixels, const float* bn0,
+                          const float* w1, const float* b1, const float* w2, const float* b2, float* z, double* zsum, double* zsq,
+                          int replicas, int rstride, void* stream);
+int saunet_gate_forward_out(int dtype, int C, const void* feat, int ldf, const float* z, int64_t pixels, const float* bn1, const float* wm,
+                            void* y, int ldy, void* alpha, void* stream);
+int64_t saunet_gate_backward_workspace(int64_t pixels);
+int saunet_gate_backward_q(int dtype, int C, const void* dy, int lddy, const void* feat, int ldf, const float* z, const void* dalpha,
+                           int64_t pixels, const float* bn1, const float* wm, float* q, float* dwm, float* dbn1, float* K,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+int saunet_gate_backward_sums(int dtype, int C, const void* feat, int ldf, const void* gate, int ldg, const float* q, const float* z,
+                              int64_t pixels, const float* K, const float* bn0, const float* w1, const float* b1, const float* w2,
+                              float* dw1, float* db1, float* dw2, float* db2, float* dbn0, float* E,
+                              void* workspace, int64_t workspace_bytes, void* stream);
+int saunet_gate_backward_apply(int dtype, int C, const void* dy, int lddy, const void* feat, int ldf, const void* gate, int ldg,
+                               const float* q, const float* z, int64_t pixels, const float* K, const float* E, const float* bn0,
+                               const float* w1, const float* b1, const float* w2, const float* bn1, const float* wm,
+                               void* dfeat, int lddf, void* dgate, int lddg, void* stream);
+
 /* ---- dual attention tail (attention_blocks.py:50-57,165-173,237) ------------------------------
  * pooled[n,c] = mean_hw F ;  out = (S+1) * F * se[n,c] */
 int saunet_global_avgpool(int dtype, const void* x, int N, int HW, int C, int ldx, float* pooled, void* stream);

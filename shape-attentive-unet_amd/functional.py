@@ -735,6 +735,89 @@ def gate_mul(x, alpha):
     return _GateMul.apply(x, alpha)
 
 
+class _GatedConv(torch.autograd.Function):
+    """Fused GatedSpatialConv2d (GSConv.py:16-57) for bf16 storage and training-mode batch norm: two forward passes
+    (z, then y/alpha) and three backward passes that recompute the gate chain per pixel (csrc/gate.hip)."""
+
+    @staticmethod
+    def forward(ctx, feat, gate, g0, b0, rm0, rv0, w1, b1, w2, b2, g1, bb1, rm1, rv1, wm, mom0, eps0, mom1, eps1, training):
+        feat = nhwc(feat); gate = nhwc(gate)
+        _check_dev(feat)
+        n, c, h, w = feat.shape
+        P, dev, c1 = n * h * w, feat.device, c + 1
+        st0 = st1 = None
+        if training:
+            st0 = new_stats(c1, dev)
+            bn_stats(feat, st0[:, :, :c]); bn_stats(gate, st0[:, :, c:])
+            st1 = new_stats(1, dev)
+        p0 = bn_finalize(st0, P, g0, b0, rm0, rv0, mom0, eps0, training)
+        z = torch.empty(P, dtype=torch.float32, device=dev)
+        L.call("saunet_gate_forward_z", L.BF16, c, feat.data_ptr(), ld_of(feat), gate.data_ptr(), ld_of(gate), P, p0.buf.data_ptr(),
+               w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), z.data_ptr(),
+               st1[0, 0].data_ptr() if training else None, st1[0, 1].data_ptr() if training else None,
+               st1.shape[0] if training else 1, st1.stride(0) if training else 0, L.stream())
+        p1 = bn_finalize(st1, P, g1, bb1, rm1, rv1, mom1, eps1, training)
+        y = new_act(n, c, h, w, feat.dtype, dev)
+        alpha = new_act(n, 1, h, w, feat.dtype, dev)
+        L.call("saunet_gate_forward_out", L.BF16, c, feat.data_ptr(), ld_of(feat), z.data_ptr(), P, p1.buf.data_ptr(), wm.data_ptr(),
+               y.data_ptr(), ld_of(y), alpha.data_ptr(), L.stream())
+        ctx.save_for_backward(feat, gate, z, p0.buf, p1.buf, w1, b1, w2, wm)
+        ctx.set_materialize_grads(False)
+        ctx.training = training
+        return y, alpha
+
+    @staticmethod
+    def backward(ctx, dy, dalpha):
+        feat, gate, z, p0, p1, w1, b1, w2, wm = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("fused gated convolution: backward needs training-mode batch norm (use the unfused path)")
+        n, c, h, w = feat.shape
+        P, dev, c1 = n * h * w, feat.device, c + 1
+        dy = nhwc(dy) if dy is not None else new_act(n, c, h, w, feat.dtype, dev, zero=True)
+        if dalpha is not None:
+            dalpha = nhwc(dalpha).contiguous()
+        nbytes = L.load().saunet_gate_backward_workspace(P)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        q = torch.empty(P, dtype=torch.float32, device=dev)
+        sizes = [c * c, 2, 3, c1 * c1, c1, c1, 1, 2 * c1, 3 * c1]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        dwm, dbn1, K, dw1, db1, dw2, db2, dbn0, E = torch.split(flat, sizes)
+        st = L.stream()
+        L.call("saunet_gate_backward_q", L.BF16, c, dy.data_ptr(), ld_of(dy), feat.data_ptr(), ld_of(feat), z.data_ptr(), L.ptr(dalpha), P,
+               p1.data_ptr(), wm.data_ptr(), q.data_ptr(), dwm.data_ptr(), dbn1.data_ptr(), K.data_ptr(), ws.data_ptr(), nbytes, st)
+        L.call("saunet_gate_backward_sums", L.BF16, c, feat.data_ptr(), ld_of(feat), gate.data_ptr(), ld_of(gate), q.data_ptr(), z.data_ptr(), P,
+               K.data_ptr(), p0.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
+               db2.data_ptr(), dbn0.data_ptr(), E.data_ptr(), ws.data_ptr(), nbytes, st)
+        dfeat = new_act(n, c, h, w, feat.dtype, dev)
+        dgate = new_act(n, 1, h, w, feat.dtype, dev)
+        L.call("saunet_gate_backward_apply", L.BF16, c, dy.data_ptr(), ld_of(dy), feat.data_ptr(), ld_of(feat), gate.data_ptr(), ld_of(gate),
+               q.data_ptr(), z.data_ptr(), P, K.data_ptr(), E.data_ptr(), p0.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+               p1.data_ptr(), wm.data_ptr(), dfeat.data_ptr(), ld_of(dfeat), dgate.data_ptr(), ld_of(dgate), st)
+        return (dfeat, dgate, dbn0[:c1], dbn0[c1:], None, None, dw1.view_as(w1), db1, dw2.view_as(w2), db2, dbn1[0:1], dbn1[1:2], None, None,
+                dwm.view_as(wm), None, None, None, None, None)
+
+
+def gated_conv_fusable(feat, gate, m):
+    """the fused kernels cover bf16 storage, C in {8,16,32}, no module bias, 16-byte aligned feature rows, and (for
+    autograd) training-mode batch norm"""
+    c = feat.shape[1]
+    if feat.dtype != torch.bfloat16 or gate.dtype != torch.bfloat16 or c not in (8, 16, 32) or m.bias is not None or gate.shape[1] != 1:
+        return False
+    if not m.training and torch.is_grad_enabled():
+        return False
+    f = nhwc(feat)
+    return ld_of(f) % 8 == 0 and f.data_ptr() % 16 == 0
+
+
+def gated_conv(feat, gate, m):
+    """m: a GatedSpatialConv2d-like module (``_gate_conv`` Sequential + own 1x1 weight).  Returns (y, alpha)."""
+    g = m._gate_conv
+    _bump(g[0]); _bump(g[4])
+    return _GatedConv.apply(feat, gate, g[0].weight, g[0].bias, g[0].running_mean, g[0].running_var, g[1].weight, g[1].bias,
+                            g[3].weight, g[3].bias, g[4].weight, g[4].bias, g[4].running_mean, g[4].running_var, m.weight,
+                            g[0].momentum, g[0].eps, g[4].momentum, g[4].eps, m.training)
+
+
 class _DualAttTail(torch.autograd.Function):
     """out = (S + 1) * F * sigmoid(fc2(relu(fc1(avgpool(F)))))  (attention_blocks.py:50-57, 237)."""
 

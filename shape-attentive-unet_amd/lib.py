@@ -65,6 +65,12 @@ _SIGS = {
     "saunet_sigmoid_backward": [i32, vp, i32, vp, i32, vp, i32, i64, i32, i32, vp],
     "saunet_gate_mul_forward": [i32, vp, i32, vp, vp, i32, i64, i32, vp],
     "saunet_gate_mul_backward": [i32, vp, i32, vp, vp, i32, vp, i32, vp, i64, i32, vp],
+    "saunet_gate_forward_z": [i32, i32, vp, i32, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "saunet_gate_forward_out": [i32, i32, vp, i32, vp, i64, vp, vp, vp, i32, vp, vp],
+    "saunet_gate_backward_workspace": [i64],
+    "saunet_gate_backward_q": [i32, i32, vp, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp],
+    "saunet_gate_backward_sums": [i32, i32, vp, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp],
+    "saunet_gate_backward_apply": [i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp],
     "saunet_global_avgpool": [i32, vp, i32, i32, i32, i32, vp, vp],
     "saunet_se_excite": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "saunet_se_excite_backward": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -123,6 +123,8 @@ class GatedSpatialConv2d(nn.Conv2d):
 
     def forward(self, input_features, gating_features):
         g = self._gate_conv
+        if HF.gated_conv_fusable(input_features, gating_features, self):
+            return HF.gated_conv(input_features, gating_features, self)
         a = HF.batch_norm_act(HF.cat([input_features, gating_features]), g[0], relu=False)
         a = HF.relu(HF.conv2d(a, g[1].weight, g[1].bias))
         # conv (C+1 -> 1) -> BatchNorm(1) -> sigmoid
