@@ -1,6 +1,7 @@
 // C-ABI front for the convolution family: weight packing, dispatch between the MFMA implicit-GEMM
 // kernels (conv_igemm.hip) and the small-channel pointwise kernels below, bias gradient.
 #include "common.h"
+#include "mma_tiles.h"
 
 namespace saunet {
 
@@ -281,6 +282,82 @@ template <typename T, int WPT> __global__ __launch_bounds__(256) void pointwise_
         if (wco[k] >= 0) atomicAdd(a.dw + wco[k] * a.sM + wci[k] * a.sN, acc[k]);
 }
 
+// Few outputs, many inputs, few pixels (the C -> 1 projections c3/c4/c5/phi at 1/8..1/32 resolution): a weighted channel
+// sum.  thread = input channel (coalesced rows), blockIdx.y = pixel split, float atomics into the zeroed dw.
+template <typename T> __global__ __launch_bounds__(256) void pointwise_wgrad_fewout_kernel(PwWgradArgs a)
+{
+    const int ci = blockIdx.x * 256 + threadIdx.x;
+    if (ci >= a.Cin) return;
+    const long p0 = blockIdx.y * a.pix_per_block, p1 = min(p0 + a.pix_per_block, a.P);
+    const float sc = a.ps ? a.ps[ci] : 1.f, sh = a.ps ? a.psh[ci] : 0.f;
+    const float relu_lo = (a.ps && a.pro_relu) ? 0.f : -__builtin_inff();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long p = p0; p < p1; ++p) {
+        const float v = fmaxf(fmaf(Elem<T>::load((const T*)a.x + p * a.ldx + ci), sc, sh), relu_lo);
+#pragma unroll
+        for (int co = 0; co < 4; ++co)
+            if (co < a.Cout) acc[co] = fmaf(Elem<T>::load((const T*)a.dy + p * a.lddy + co), v, acc[co]);
+    }
+#pragma unroll
+    for (int co = 0; co < 4; ++co)
+        if (co < a.Cout) atomicAdd(a.dw + co * a.sM + ci * a.sN, acc[co]);
+}
+
+// Small channel counts at full resolution (d2/d3/fuse/final of the shape stream and head: Cin <= 32*CIT, Cout <= 32, bf16):
+// one thread per pixel loads its rows with 16-byte vectors, a wave transposes its 64 pixels through LDS and the outer
+// products run on the matrix cores (mma_tiles.h); one float atomic per weight per block.
+template <int CIT, bool VD> __global__ __launch_bounds__(256) void pointwise_wgrad_mma_kernel(PwWgradArgs a)
+{
+    extern __shared__ u16 w_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u16* tX = w_lds + wave * (CIT + 1) * G_TILE; u16* tD = tX + CIT * G_TILE;
+    const u16* __restrict__ x = (const u16*)a.x; const u16* __restrict__ dy = (const u16*)a.dy;
+    f32x16 acc[CIT];
+#pragma unroll
+    for (int t = 0; t < CIT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const unsigned P = (unsigned)a.P;
+    for (unsigned base = blockIdx.x * 256u; base < P; base += gridDim.x * 256u) {
+        const unsigned p = base + threadIdx.x; const bool live = p < P; const size_t pp = live ? p : 0;
+#pragma unroll
+        for (int g = 0; g < CIT * 4; ++g) {
+            if (g * 8 < a.Cin) {
+                const u32x4 v = *(const u32x4*)(x + pp * a.ldx + g * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { tX[(g * 8 + 2 * j) * GP + lane] = (u16)(v[j] & 0xffffu); tX[(g * 8 + 2 * j + 1) * GP + lane] = (u16)(v[j] >> 16); }
+            }
+        }
+        if constexpr (VD) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g * 8 < a.Cout) {
+                    u32x4 v = *(const u32x4*)(dy + pp * a.lddy + g * 8);
+                    if (!live) v = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { tD[(g * 8 + 2 * j) * GP + lane] = (u16)(v[j] & 0xffffu); tD[(g * 8 + 2 * j + 1) * GP + lane] = (u16)(v[j] >> 16); }
+                }
+            }
+        } else {
+            for (int c = 0; c < a.Cout; ++c) tD[c * GP + lane] = live ? dy[pp * a.lddy + c] : (u16)0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < CIT; ++t) tile_mma(tD, a.Cout, tX + t * G_TILE, a.Cin - 32 * t, lane, acc[t]);
+        __syncthreads();
+    }
+    float* red = (float*)w_lds;
+    for (int i = threadIdx.x; i < CIT * 1024; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < CIT; ++t) tile_flush(red + t * 1024, acc[t], lane);
+    __syncthreads();
+    for (int i = threadIdx.x; i < CIT * 1024; i += 256) {
+        const int t = i >> 10, co = (i >> 5) & 31, ci = t * 32 + (i & 31);
+        if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + co * a.sM + ci * a.sN, red[i]);
+    }
+}
+
 // out[c] += sum_p x[p][c]: per-thread float partials (flushed to double every 128 rows), one LDS double
 // atomic per thread, one global double atomic per channel per block
 template <typename T> __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ x, long P, int C, int ld,
@@ -345,8 +422,14 @@ int saunet_pack_weight_multi(const saunet_pack_list* pl, int dtype, void* stream
 {
     if (pl->count <= 0 || pl->count > 64) return set_error(SAUNET_BAD_SHAPE, "pack_multi: %d entries", pl->count);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SAUNET_F32) hipLaunchKernelGGL(pack_weight_multi_kernel<float>, dim3(64, pl->count), dim3(256), 0, st, *pl);
-    else if (dtype == SAUNET_BF16) hipLaunchKernelGGL(pack_weight_multi_kernel<u16>, dim3(64, pl->count), dim3(256), 0, st, *pl);
+    long biggest = 1;
+    for (int e = 0; e < pl->count; ++e) {
+        const long t = (long)pl->dims[e][0] * pl->dims[e][1] * pl->dims[e][2] * pl->dims[e][3];
+        if (t > biggest) biggest = t;
+    }
+    long bx = (biggest + 1023) / 1024; if (bx > 2048) bx = 2048;     // ~4 elements per thread for the largest entry; small entries' extra blocks exit at once
+    if (dtype == SAUNET_F32) hipLaunchKernelGGL(pack_weight_multi_kernel<float>, dim3((unsigned)bx, pl->count), dim3(256), 0, st, *pl);
+    else if (dtype == SAUNET_BF16) hipLaunchKernelGGL(pack_weight_multi_kernel<u16>, dim3((unsigned)bx, pl->count), dim3(256), 0, st, *pl);
     else return set_error(SAUNET_BAD_DTYPE, "pack_multi: dtype %d", dtype);
     SAUNET_CHECK_LAUNCH("pack_weight_multi");
     return SAUNET_OK;
@@ -451,6 +534,30 @@ int saunet_conv2d_wgrad(const saunet_conv_desc* d, const void* x, const void* dy
     if (!is_pointwise(d)) return set_error(SAUNET_UNSUPPORTED, "wgrad: %dx%d Cin=%d Cout=%d has no kernel", d->KH, d->KW, d->Cin, d->Cout);
     const int nW = d->Cin * d->Cout;
     PwWgradArgs a{x, dy, dw, ps, psh, (long)d->N * d->H * d->W, d->Cin, d->Cout, d->ldx, d->ldy, d->pro_relu, 0, (long)d->Cin, 1, 32};
+    if (d->Cout <= 4 && d->Cin >= 64) {
+        const int ctiles = (d->Cin + 255) / 256;
+        long splits = 1024 / ctiles; if (splits > (a.P + 15) / 16) splits = (a.P + 15) / 16; if (splits < 1) splits = 1;
+        a.pix_per_block = (a.P + splits - 1) / splits;
+        splits = (a.P + a.pix_per_block - 1) / a.pix_per_block;
+        if (d->dtype == SAUNET_F32) hipLaunchKernelGGL(pointwise_wgrad_fewout_kernel<float>, dim3(ctiles, (unsigned)splits), dim3(256), 0, st, a);
+        else if (d->dtype == SAUNET_BF16) hipLaunchKernelGGL(pointwise_wgrad_fewout_kernel<u16>, dim3(ctiles, (unsigned)splits), dim3(256), 0, st, a);
+        else return set_error(SAUNET_BAD_DTYPE, "wgrad: dtype %d", d->dtype);
+        SAUNET_CHECK_LAUNCH("pointwise_wgrad_fewout");
+        return SAUNET_OK;
+    }
+    if (d->dtype == SAUNET_BF16 && ps == nullptr && d->Cin % 8 == 0 && d->ldx % 8 == 0 && !((uintptr_t)x & 15) && d->Cin <= 64 && d->Cout <= 32 &&
+        a.P >= 4096 && a.P < (1L << 32) - (1 << 20)) {
+        const bool vd = d->Cout % 8 == 0 && d->ldy % 8 == 0 && !((uintptr_t)dy & 15);
+        const int cit = d->Cin <= 32 ? 1 : 2;
+        long blocks = (a.P + 255) / 256; if (blocks > 512) blocks = 512;
+        const size_t lds = sizeof(u16) * 4 * (cit + 1) * G_TILE;
+#define PW_MMA(CIT, VD) hipLaunchKernelGGL((pointwise_wgrad_mma_kernel<CIT, VD>), dim3((unsigned)blocks), dim3(256), lds, st, a)
+        if (cit == 1) { if (vd) PW_MMA(1, true); else PW_MMA(1, false); }
+        else { if (vd) PW_MMA(2, true); else PW_MMA(2, false); }
+#undef PW_MMA
+        SAUNET_CHECK_LAUNCH("pointwise_wgrad_mma");
+        return SAUNET_OK;
+    }
     long blocks = (a.P + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
     a.pix_per_block = ((a.P + blocks - 1) / blocks + 31) / 32 * 32;
     blocks = (a.P + a.pix_per_block - 1) / a.pix_per_block;

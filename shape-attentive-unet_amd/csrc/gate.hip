@@ -20,50 +20,12 @@
 // mfma_f32_32x32x16_bf16 with K = pixels; per-block partial tiles go to a workspace and a small reduce + finalize pair
 // turns them into gradients and the per-channel coefficients of the next pass.  bf16 storage only.
 #include "common.h"
+#include "mma_tiles.h"
 
 namespace saunet {
 
-constexpr int GP = 72;            // LDS tile row pitch in bf16 elements: 64 pixels + 8 pad (144 B, 16-byte aligned rows)
-constexpr int G_TILE = 32 * GP;   // a 32-row tile
-constexpr int G_MISC = 8 * GP;    // an 8-row tile for the leftover rows (channel 32 of the 33-channel case, dz, ones)
 constexpr int Q_WS = 1056;        // floats per block of pass 1: 32x32 dWm tile + {sum q, sum q*zhat} (+ pad)
 constexpr int S_WS = 7 * 1024;    // floats per block of pass 2: seven 32x32 product tiles
-
-__device__ __forceinline__ u16 to_bf16(float v) { return __builtin_bit_cast(u16, (__bf16)v); }
-
-template <int C> __device__ __forceinline__ void load_row(const u16* __restrict__ p, float* f)
-{
-#pragma unroll
-    for (int g = 0; g < C / 8; ++g) Vec16<u16>::unpack(*(const u32x4*)(p + 8 * g), f + 8 * g);
-}
-template <int C> __device__ __forceinline__ void store_row(u16* __restrict__ p, const float* f)
-{
-#pragma unroll
-    for (int g = 0; g < C / 8; ++g) *(u32x4*)(p + 8 * g) = Vec16<u16>::pack(f + 8 * g);
-}
-
-// MFMA operand fragment: 8 consecutive pixels of row (lane & 31) of a [row][pixel] tile; rows >= nrows read as zero
-__device__ __forceinline__ bf16x8_t tile_frag(const u16* tile, int lane, int ks, int nrows)
-{
-    const int r = lane & 31;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (r < nrows) v = *(const u32x4*)(tile + r * GP + ks * 16 + (lane >> 5) * 8);
-    return __builtin_bit_cast(bf16x8_t, v);
-}
-// acc[i][j] += sum over the wave's 64 pixels of A[i][p] * B[j][p]
-__device__ __forceinline__ void tile_mma(const u16* ta, int ra, const u16* tb, int rb, int lane, f32x16& acc)
-{
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_frag(ta, lane, ks, ra), tile_frag(tb, lane, ks, rb), acc, 0, 0, 0);
-}
-// add a wave's 32x32 accumulator into a float LDS tile
-__device__ __forceinline__ void tile_flush(float* red, const f32x16& acc, int lane)
-{
-    const int lr = lane & 31, lh = lane >> 5;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) atomicAdd(&red[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + lr], acc[r]);
-}
 
 template <int C> __device__ __forceinline__ void load_cat(const u16* __restrict__ feat, int ldf, const u16* __restrict__ gate, int ldg, size_t p, float* cat)
 {
@@ -237,14 +199,14 @@ void gate_bwd_q_kernel(const u16* __restrict__ dy, int lddy, const u16* __restri
     for (int i = threadIdx.x; i < Q_WS; i += 256) ws[(size_t)blockIdx.x * Q_WS + i] = red[i];
 }
 
-// out[e] = sum_b ws[b][e]
+// out[e] += sum_b ws[b][e]  (out zeroed by the caller; blockIdx.y strides the partial blocks)
 __global__ __launch_bounds__(256) void gate_reduce_kernel(const float* __restrict__ ws, int nblocks, int stride, int n, float* __restrict__ out)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)ws[(size_t)b * stride + e];
-    out[e] = (float)s;
+    float s = 0.f;
+    for (int b = blockIdx.y; b < nblocks; b += gridDim.y) s += ws[(size_t)b * stride + e];
+    atomicAdd(&out[e], s);
 }
 
 // red = reduced pass-1 workspace.  Outputs: dwm [C][C], dbn1 = {dgamma1, dbeta1}, K = {K0, K1, K2} with dz = K0*q + K1 + K2*z
@@ -476,7 +438,8 @@ int saunet_gate_backward_q(int dtype, int C, const void* dy, int lddy, const voi
                                     (unsigned)pixels, bn1, wm, q, ws)
     GATE_C(C, CALL);
 #undef CALL
-    hipLaunchKernelGGL(gate_reduce_kernel, dim3((Q_WS + 255) / 256), dim3(256), 0, st, ws, blocks, Q_WS, Q_WS, red);
+    if (hipMemsetAsync(red, 0, sizeof(float) * Q_WS, st) != hipSuccess) return set_error(SAUNET_LAUNCH_FAILED, "gate_backward_q: memset");
+    hipLaunchKernelGGL(gate_reduce_kernel, dim3((Q_WS + 255) / 256, 32), dim3(256), 0, st, ws, blocks, Q_WS, Q_WS, red);
     hipLaunchKernelGGL(gate_bwd_q_finalize_kernel, dim3(1), dim3(256), 0, st, C, red, bn1, (float)pixels, dwm, dbn1, K);
     SAUNET_CHECK_LAUNCH("gate_backward_q");
     return SAUNET_OK;
@@ -497,7 +460,8 @@ int saunet_gate_backward_sums(int dtype, int C, const void* feat, int ldf, const
                                     (unsigned)pixels, K, bn0, w1, b1, w2, ws)
     GATE_C(C, CALL);
 #undef CALL
-    hipLaunchKernelGGL(gate_reduce_kernel, dim3((S_WS + 255) / 256), dim3(256), 0, st, ws, blocks, S_WS, S_WS, red);
+    if (hipMemsetAsync(red, 0, sizeof(float) * S_WS, st) != hipSuccess) return set_error(SAUNET_LAUNCH_FAILED, "gate_backward_sums: memset");
+    hipLaunchKernelGGL(gate_reduce_kernel, dim3((S_WS + 255) / 256, 32), dim3(256), 0, st, ws, blocks, S_WS, S_WS, red);
     hipLaunchKernelGGL(gate_bwd_sums_finalize_kernel, dim3(1), dim3(256), 0, st, C, red, bn0, (float)pixels, dw1, db1, dw2, db2, dbn0, E);
     SAUNET_CHECK_LAUNCH("gate_backward_sums");
     return SAUNET_OK;

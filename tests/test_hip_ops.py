@@ -62,6 +62,12 @@ CONV_CASES = [
     (2, 1, 16, 16, 32, 1, 1, 0),       # expand (pointwise, Cin 1)
     (2, 32, 16, 16, 4, 1, 1, 0),       # final
     (2, 16, 16, 16, 8, 1, 1, 0),       # d3
+    # >= 4096 pixels, small channels: the matrix-core pointwise weight gradient (pointwise_wgrad_mma_kernel)
+    (2, 32, 48, 48, 16, 1, 1, 0),      # d2
+    (1, 64, 64, 72, 32, 1, 1, 0),      # two input tiles
+    (2, 32, 64, 40, 4, 1, 1, 0),       # final (scalar dy rows)
+    (1, 8, 72, 64, 1, 1, 1, 0),        # fuse
+    (3, 1024, 8, 8, 1, 1, 1, 0),       # c5: many inputs, one output, few pixels (pointwise_wgrad_fewout_kernel)
 ]
 
 
