@@ -192,6 +192,21 @@ int saunet_gate_backward_apply(int dtype, int C, const void* dy, int lddy, const
                                const float* w1, const float* b1, const float* w2, const float* bn1, const float* wm,
                                void* dfeat, int lddf, void* dgate, int lddg, void* stream);
 
+/* ---- fused Conv2d(1,C,1x1) -> BatchNorm2d(C) -> ReLU on a one-channel float32 map (SAUNet.expand, models/models.py:316,367) ----
+ * y_c = w_c*a + b_c makes the batch statistics of y analytic in those of a, so the layer is out_c = relu(A_c*a + B_c).
+ * expand_coeff: from sum / sum-of-squares of a (replicated float64 accumulators as written by saunet_bn_stats) builds
+ *   coef [4][C] = {A, B, k, gamma*invstd} and mu_var = {mean, biased variance of a}; updates the running statistics.
+ *   Eval mode (training = 0) uses the running statistics instead (sum / sumsq may be NULL).
+ * expand_forward: y [P][ldy] (float32 or bf16) from a [P].
+ * expand_backward (training-mode statistics): sums = zeroed [replicas][2][C] float64 scratch; writes dw [C], db [C] (zeros; may be
+ *   NULL), dgamma [C], dbeta [C], D [2] (scratch) and da [P] (float32). */
+int saunet_expand_coeff(int C, const double* sum, const double* sumsq, int replicas, int rstride, double count, const float* w, const float* b,
+                        const float* gamma, const float* beta, float eps, float momentum, float* rmean, float* rvar, float* coef, float* mu_var,
+                        int training, void* stream);
+int saunet_expand_forward(int dtype, const float* a, int64_t pixels, int C, const float* coef, void* y, int ldy, int relu, void* stream);
+int saunet_expand_backward(int dtype, const void* dy, int lddy, const float* a, int64_t pixels, int C, const float* coef, const float* mu_var, int relu,
+                           double* sums, int replicas, int rstride, float* dw, float* db, float* dgamma, float* dbeta, float* D, float* da, void* stream);
+
 /* ---- dual attention tail (attention_blocks.py:50-57,165-173,237) ------------------------------
  * pooled[n,c] = mean_hw F ;  out = (S+1) * F * se[n,c] */
 int saunet_global_avgpool(int dtype, const void* x, int N, int HW, int C, int ldx, float* pooled, void* stream);

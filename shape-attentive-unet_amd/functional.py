@@ -818,6 +818,58 @@ def gated_conv(feat, gate, m):
                             g[0].momentum, g[0].eps, g[4].momentum, g[4].eps, m.training)
 
 
+class _ExpandBNAct(torch.autograd.Function):
+    """Conv2d(1, C, 1x1) -> BatchNorm -> ReLU on a one-channel float32 map as ONE per-pixel affine map (csrc/expand.hip)."""
+
+    @staticmethod
+    def forward(ctx, a, w, b, gamma, beta, rmean, rvar, momentum, eps, training, relu, out_dtype):
+        a = nhwc(a)
+        _check_dev(a)
+        n, _, h, wd = a.shape
+        P, dev, c = n * h * wd, a.device, w.shape[0]
+        stats = bn_stats(a) if training else None
+        coef = torch.empty(4, c, dtype=torch.float32, device=dev)
+        mv = torch.empty(2, dtype=torch.float32, device=dev)
+        L.call("saunet_expand_coeff", c, stats[0, 0].data_ptr() if training else None, stats[0, 1].data_ptr() if training else None,
+               stats.shape[0] if training else 1, stats.stride(0) if training else 0, float(P), w.data_ptr(), L.ptr(b), gamma.data_ptr(),
+               beta.data_ptr(), float(eps), float(momentum), L.ptr(rmean), L.ptr(rvar), coef.data_ptr(), mv.data_ptr(), 1 if training else 0, L.stream())
+        y = new_act(n, c, h, wd, out_dtype, dev)
+        L.call("saunet_expand_forward", L.dtype_code(y), a.data_ptr(), P, c, coef.data_ptr(), y.data_ptr(), ld_of(y), 1 if relu else 0, L.stream())
+        ctx.save_for_backward(a, coef, mv)
+        ctx.cfg = (relu, training, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, coef, mv = ctx.saved_tensors
+        relu, training, has_bias = ctx.cfg
+        if not training:
+            raise RuntimeError("fused expand: backward needs training-mode batch norm (use the unfused path)")
+        dy = nhwc(dy)
+        n, c, h, wd = dy.shape
+        P, dev = n * h * wd, dy.device
+        sums = new_stats(c, dev)
+        flat = torch.empty(4 * c + 2, dtype=torch.float32, device=dev)
+        dw, db, dg, dbeta, D = flat[:c], flat[c:2 * c], flat[2 * c:3 * c], flat[3 * c:4 * c], flat[4 * c:]
+        da = torch.empty_like(a)
+        L.call("saunet_expand_backward", L.dtype_code(dy), dy.data_ptr(), ld_of(dy), a.data_ptr(), P, c, coef.data_ptr(), mv.data_ptr(), 1 if relu else 0,
+               sums.data_ptr(), sums.shape[0], sums.stride(0), dw.data_ptr(), db.data_ptr(), dg.data_ptr(), dbeta.data_ptr(), D.data_ptr(), da.data_ptr(),
+               L.stream())
+        return da, dw.view(c, 1, 1, 1), (db if has_bias else None), dg, dbeta, None, None, None, None, None, None, None
+
+
+def expand_fusable(x, conv, bn):
+    c = conv.out_channels
+    return (conv.in_channels == 1 and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and c in (32, 64)
+            and x.dtype == torch.float32 and x.is_cuda and (bn.training or not torch.is_grad_enabled()))
+
+
+def expand_bn_act(x, conv, bn, relu=True, out_dtype=None):
+    _bump(bn)
+    return _ExpandBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, bn.training,
+                              relu, out_dtype or x.dtype)
+
+
 class _DualAttTail(torch.autograd.Function):
     """out = (S + 1) * F * sigmoid(fc2(relu(fc1(avgpool(F)))))  (attention_blocks.py:50-57, 237)."""
 

@@ -71,6 +71,9 @@ _SIGS = {
     "saunet_gate_backward_q": [i32, i32, vp, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp],
     "saunet_gate_backward_sums": [i32, i32, vp, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp],
     "saunet_gate_backward_apply": [i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp],
+    "saunet_expand_coeff": [i32, vp, vp, i32, i32, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, vp],
+    "saunet_expand_forward": [i32, vp, i64, i32, vp, vp, i32, i32, vp],
+    "saunet_expand_backward": [i32, vp, i32, vp, i64, i32, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "saunet_global_avgpool": [i32, vp, i32, i32, i32, i32, vp, vp],
     "saunet_se_excite": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "saunet_se_excite_backward": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],

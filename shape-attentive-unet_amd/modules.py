@@ -76,9 +76,12 @@ class ConvBNReLU(nn.Sequential):
         super().__init__(nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride, padding=padding, bias=bias),
                          nn.BatchNorm2d(out_planes), nn.ReLU(inplace=True))
 
-    def forward(self, x):
+    def forward(self, x, out_dtype=None):
         conv, bn = self[0], self[1]
-        return HF.conv_bn_act(x, conv.weight, conv.bias, bn, relu=True, stride=conv.stride[0], padding=conv.padding[0])
+        if HF.expand_fusable(x, conv, bn):
+            return HF.expand_bn_act(x, conv, bn, relu=True, out_dtype=out_dtype)      # 1 -> C broadcast (SAUNet.expand)
+        y = HF.conv_bn_act(x, conv.weight, conv.bias, bn, relu=True, stride=conv.stride[0], padding=conv.padding[0])
+        return y if out_dtype is None or out_dtype == y.dtype else HF.cast(y, out_dtype)
 
 
 def conv3x3_bn_relu(in_planes, out_planes, stride=1):
@@ -403,7 +406,7 @@ class SAUNet(nn.Module):
 
         canny = HF.canny(x, 10, 100, dtype=torch.float32)                 # on device, no host round trip
         acts = HF.sigmoid(conv(self.cw, HF.cat([edge_out, canny])))
-        edge = HF.cast(self.expand(acts), self.compute_dtype)
+        edge = self.expand(acts, out_dtype=self.compute_dtype)
 
         conv2u, conv3u, conv4u = up(conv2, scale_factor=2), up(conv3, scale_factor=2), up(conv4, scale_factor=2)
         center = self.center(HF.max_pool2x2(conv5))

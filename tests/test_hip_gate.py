@@ -83,3 +83,34 @@ def test_fused_gate_eval_forward_uses_running_stats():
         ra = torch.sigmoid(F.batch_norm(z, g[4].running_mean.double(), g[4].running_var.double(), g[4].weight.double(), g[4].bias.double(), False, 0.0, g[4].eps))
         ry = F.conv2d(f * (ra + 1), m.weight.double())
     assert rel(y, ry) < 1e-2 and rel(alpha, ra) < 1e-2
+
+
+@pytest.mark.parametrize("out_dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("shape", [(2, 32, 40), (1, 24, 24)])
+def test_fused_expand_matches_float64(out_dtype, tol, shape):
+    """SAUNet.expand: Conv2d(1, 32, 1x1) -> BatchNorm -> ReLU on a one-channel float32 map (csrc/expand.hip)."""
+    import saunet_amd as S
+    torch.manual_seed(11)
+    n, (h, w) = shape[0], shape[1:]
+    m = S.ConvBNReLU(1, 32, kernel_size=1, padding=0).cuda().train()
+    with torch.no_grad():
+        m[1].weight.uniform_(0.5, 1.5); m[1].bias.uniform_(-0.5, 0.5); m[0].weight.normal_(0, 1.0); m[0].bias.normal_(0, 0.3)
+    a = torch.rand(n, 1, h, w, device="cuda").requires_grad_(True)
+    assert S.functional.expand_fusable(a, m[0], m[1])
+    y = m(a, out_dtype=out_dtype)
+    assert y.dtype == out_dtype
+    cot = torch.randn(y.shape, device="cuda").to(out_dtype)
+    (y.float() * cot.float()).sum().backward()
+    d = torch.float64
+    p = lambda t: t.detach().to(d).requires_grad_(True)
+    ra, rw, rb, rg, rbeta = p(a), p(m[0].weight), p(m[0].bias), p(m[1].weight), p(m[1].bias)
+    ry = F.relu(F.batch_norm(F.conv2d(ra, rw, rb), None, None, rg, rbeta, True, 0.0, m[1].eps))
+    (ry * cot.double()).sum().backward()
+    assert rel(y, ry) < tol
+    assert rel(a.grad, ra.grad) < 10 * tol, rel(a.grad, ra.grad)
+    assert rel(m[0].weight.grad, rw.grad) < 10 * tol
+    assert rel(m[1].weight.grad, rg.grad) < 10 * tol and rel(m[1].bias.grad, rbeta.grad) < 10 * tol
+    assert float(m[0].bias.grad.abs().max()) == 0.0
+    conv_out = F.conv2d(a.detach().double(), m[0].weight.double(), m[0].bias.double())
+    assert torch.allclose(m[1].running_mean.double(), 0.1 * conv_out.mean((0, 2, 3)), atol=1e-5)
+    assert torch.allclose(m[1].running_var.double(), 0.9 + 0.1 * conv_out.var((0, 2, 3), unbiased=True), atol=1e-4)
