@@ -124,7 +124,7 @@ int saunet_bn_backward_reduce(int dtype, const void* dy, int lddy, const void* x
  * optionally dres = g.  dgamma/dbeta are written from `sums` (float32) when non-NULL. */
 int saunet_bn_backward_apply(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,
                              const float* scale, const float* shift, const float* mean, const float* invstd,
-                             int relu, const double* sums, double count, int training, int accumulate,
+                             int relu, const double* sums, int sums_replicas, int sums_rstride, double count, int training, int accumulate,
                              void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta,
                              int64_t pixels, int C, void* stream);
 
@@ -132,7 +132,7 @@ int saunet_bn_backward_apply(int dtype, const void* dy, int lddy, const void* x,
  *   dx_c = sum_k s_kc*g_k  -  (A_c + B_c*xhat_c),   A_c = sum_k s_kc*mean(g_k),  B_c = sum_k s_kc*mean(g_k*xhat)
  * The first term is accumulated by the dgrad epilogue (accumulate=1); `coeff` folds one consumer's reduction into A/B
  * (and emits that BatchNorm's dgamma/dbeta); `correct` applies -(A + B*xhat) once per channel chunk, in place. */
-int saunet_bn_backward_coeff(int C, const double* sums, double count, const float* scale, float* A, float* B,
+int saunet_bn_backward_coeff(int C, const double* sums, int sums_replicas, int sums_rstride, double count, const float* scale, float* A, float* B,
                              float* dgamma, float* dbeta, int training, void* stream);
 int saunet_bn_backward_correct(int dtype, void* dx, int lddx, const void* x, int ldx, const float* A, const float* B,
                                const float* xhat_scale, const float* xhat_shift, int64_t pixels, int C, void* stream);

@@ -80,19 +80,28 @@ __global__ __launch_bounds__(256) void canny_nms_kernel(int N, int H, int W, int
 // pass 3: hysteresis by in-place relaxation (monotone: 0 -> 2 only), one workgroup per image, until a
 // sweep changes nothing; then emit {0,255}.  Result = pixels 8-connected to a strong pixel through
 // candidates, identical to the stack-based flood fill of the CPU algorithm.
-template <typename T>
+// LDS = true: the whole map of the image lives in LDS as bytes (H*W <= 152 KiB, e.g. 256x256 = 64 KiB) and the sweeps
+// never touch memory; otherwise the sweeps relax the int32 map in global memory.
+template <typename T, bool LDS>
 __global__ __launch_bounds__(1024) void canny_hyst_kernel(int H, int W, int32_t* __restrict__ work, T* __restrict__ out)
 {
+    extern __shared__ unsigned char h_map[];
     const long plane = (long)H * W;
-    volatile int32_t* map = work + (long)blockIdx.x * 3 * plane + 2 * plane;
+    volatile int32_t* gmap = work + (long)blockIdx.x * 3 * plane + 2 * plane;
+    volatile unsigned char* lmap = h_map;
     __shared__ int changed;
     const int npix = H * W;
+    if constexpr (LDS) {
+        for (int i = threadIdx.x; i < npix; i += 1024) lmap[i] = (unsigned char)gmap[i];
+        __syncthreads();
+    }
+    auto at = [&](int i) -> int { if constexpr (LDS) return lmap[i]; else return gmap[i]; };
     for (int it = 0; it < npix; ++it) {
         if (threadIdx.x == 0) changed = 0;
         __syncthreads();
         int any = 0;
         for (int i = threadIdx.x; i < npix; i += 1024) {
-            if (map[i] != 0) continue;
+            if (at(i) != 0) continue;
             const int y = i / W, x = i - y * W;
             bool hit = false;
 #pragma unroll
@@ -100,9 +109,9 @@ __global__ __launch_bounds__(1024) void canny_hyst_kernel(int H, int W, int32_t*
 #pragma unroll
                 for (int dx = -1; dx <= 1; ++dx) {
                     const int yy = y + dy, xx = x + dx;
-                    if ((dy | dx) != 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W && map[yy * W + xx] == 2) hit = true;
+                    if ((dy | dx) != 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W && at(yy * W + xx) == 2) hit = true;
                 }
-            if (hit) { map[i] = 2; any = 1; }
+            if (hit) { if constexpr (LDS) lmap[i] = 2; else gmap[i] = 2; any = 1; }
         }
         if (any) changed = 1;
         __threadfence_block();
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(1024) void canny_hyst_kernel(int H, int W, int32_t*
         if (!c) break;
     }
     T* o = out + (long)blockIdx.x * plane;
-    for (int i = threadIdx.x; i < npix; i += 1024) Elem<T>::store(o + i, map[i] == 2 ? 255.f : 0.f);
+    for (int i = threadIdx.x; i < npix; i += 1024) Elem<T>::store(o + i, at(i) == 2 ? 255.f : 0.f);
 }
 
 // Edge ground truth on the device (replaces the loader's three Euclidean distance transforms per slice,
@@ -165,9 +174,21 @@ extern "C" int saunet_canny(int dtype, const float* image, int N, int H, int W, 
     long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(canny_sobel_kernel, dim3((unsigned)blocks), dim3(256), 0, st, image, N, H, W, work);
     hipLaunchKernelGGL(canny_nms_kernel, dim3((unsigned)blocks), dim3(256), 0, st, N, H, W, low, high, work);
-    if (dtype == SAUNET_F32) hipLaunchKernelGGL(canny_hyst_kernel<float>, dim3(N), dim3(1024), 0, st, H, W, work, (float*)out);
-    else if (dtype == SAUNET_BF16) hipLaunchKernelGGL(canny_hyst_kernel<u16>, dim3(N), dim3(1024), 0, st, H, W, work, (u16*)out);
-    else return set_error(SAUNET_BAD_DTYPE, "canny: dtype %d", dtype);
+    if (dtype != SAUNET_F32 && dtype != SAUNET_BF16) return set_error(SAUNET_BAD_DTYPE, "canny: dtype %d", dtype);
+    const size_t map_bytes = (size_t)H * W;
+    if (map_bytes <= 152 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)canny_hyst_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            (void)hipFuncSetAttribute((const void*)canny_hyst_kernel<u16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            attr_set = true;
+        }
+        if (dtype == SAUNET_F32) hipLaunchKernelGGL((canny_hyst_kernel<float, true>), dim3(N), dim3(1024), map_bytes, st, H, W, work, (float*)out);
+        else hipLaunchKernelGGL((canny_hyst_kernel<u16, true>), dim3(N), dim3(1024), map_bytes, st, H, W, work, (u16*)out);
+    } else {
+        if (dtype == SAUNET_F32) hipLaunchKernelGGL((canny_hyst_kernel<float, false>), dim3(N), dim3(1024), 0, st, H, W, work, (float*)out);
+        else hipLaunchKernelGGL((canny_hyst_kernel<u16, false>), dim3(N), dim3(1024), 0, st, H, W, work, (u16*)out);
+    }
     SAUNET_CHECK_LAUNCH("canny");
     return SAUNET_OK;
 }

@@ -199,6 +199,14 @@ template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_reduc
     for (int c = threadIdx.x; c < 2 * a.C; c += 256) atomicAdd(&a.sums[ro + c], s_red[c]);
 }
 
+// sum over the replicated accumulators (saunet_bn_epilogue.sums_replicas)
+__device__ __forceinline__ double rep_sum(const double* __restrict__ s, int reps, int rstride, int i)
+{
+    double v = 0.0;
+    for (int r = 0; r < reps; ++r) v += s[(size_t)r * rstride + i];
+    return v;
+}
+
 template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a)
 {
     const long p0 = blockIdx.x * a.rpb, p1 = min(p0 + a.rpb, a.P);
@@ -206,7 +214,9 @@ template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_apply
     const T* dy = (const T*)a.dy; const T* x = (const T*)a.x; const T* res = (const T*)a.res;
     T* dx = (T*)a.dx; T* dres = (T*)a.dres;
     if (blockIdx.x == 0 && a.dgamma) {
-        for (int c = threadIdx.x; c < a.C; c += 256) { a.dbeta[c] = (float)a.sums[c]; a.dgamma[c] = (float)a.sums[a.C + c]; }
+        for (int c = threadIdx.x; c < a.C; c += 256) {
+            a.dbeta[c] = (float)rep_sum(a.sums, a.sreps, a.srstride, c); a.dgamma[c] = (float)rep_sum(a.sums, a.sreps, a.srstride, a.C + c);
+        }
     }
     for (int cb = 0; cb < CH; cb += 256) {
         const int cw = min(256, CH - cb), rl = 256 / cw;
@@ -217,8 +227,8 @@ template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_apply
         for (int j = 0; j < V; ++j) {
             const int c = ch * V + j;
             s[j] = a.scale[c]; t[j] = a.shift[c]; mu[j] = a.mean[c]; is[j] = a.invstd[c];
-            c1[j] = a.training ? (float)(a.sums[c] / a.count) : 0.f;
-            c2[j] = a.training ? (float)(a.sums[a.C + c] / a.count) : 0.f;
+            c1[j] = a.training ? (float)(rep_sum(a.sums, a.sreps, a.srstride, c) / a.count) : 0.f;
+            c2[j] = a.training ? (float)(rep_sum(a.sums, a.sreps, a.srstride, a.C + c) / a.count) : 0.f;
         }
         for (long p = p0 + r0; p < p1; p += rl) {
             float g[V], xv[V], r[V], o[V];
@@ -244,12 +254,12 @@ template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_apply
     }
 }
 
-__global__ void bn_bwd_coeff_kernel(int C, const double* __restrict__ sums, double count, const float* __restrict__ scale,
+__global__ void bn_bwd_coeff_kernel(int C, const double* __restrict__ sums, int reps, int rstride, double count, const float* __restrict__ scale,
                                     float* __restrict__ A, float* __restrict__ B, float* __restrict__ dgamma, float* __restrict__ dbeta, int training)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double s1 = sums[c], s2 = sums[C + c];
+    const double s1 = rep_sum(sums, reps, rstride, c), s2 = rep_sum(sums, reps, rstride, C + c);
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
     if (training) { A[c] += scale[c] * (float)(s1 / count); B[c] += scale[c] * (float)(s2 / count); }
@@ -380,10 +390,11 @@ int saunet_bn_backward_reduce(int dtype, const void* dy, int lddy, const void* x
     return SAUNET_OK;
 }
 
-int saunet_bn_backward_coeff(int C, const double* sums, double count, const float* scale, float* A, float* B,
+int saunet_bn_backward_coeff(int C, const double* sums, int sums_replicas, int sums_rstride, double count, const float* scale, float* A, float* B,
                              float* dgamma, float* dbeta, int training, void* stream)
 {
-    hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, sums, count, scale, A, B, dgamma, dbeta, training);
+    hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, sums, sums_replicas < 1 ? 1 : sums_replicas, sums_rstride,
+                       count, scale, A, B, dgamma, dbeta, training);
     SAUNET_CHECK_LAUNCH("bn_backward_coeff");
     return SAUNET_OK;
 }
@@ -404,7 +415,7 @@ int saunet_bn_backward_correct(int dtype, void* dx, int lddx, const void* x, int
 
 int saunet_bn_backward_apply(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,
                              const float* scale, const float* shift, const float* mean, const float* invstd,
-                             int relu, const double* sums, double count, int training, int accumulate,
+                             int relu, const double* sums, int sums_replicas, int sums_rstride, double count, int training, int accumulate,
                              void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta,
                              int64_t pixels, int C, void* stream)
 {
@@ -413,7 +424,8 @@ int saunet_bn_backward_apply(int dtype, const void* dy, int lddy, const void* x,
     if (residual) vec = vec && vec_ok(dtype, C, {ldr}, {residual});
     if (dres) vec = vec && vec_ok(dtype, C, {lddres}, {dres});
     BnBwdArgs a{}; a.dy = dy; a.lddy = lddy; a.x = x; a.ldx = ldx; a.res = residual; a.ldr = ldr; a.scale = scale; a.shift = shift;
-    a.mean = mean; a.invstd = invstd; a.relu = relu; a.sums = (double*)sums; a.count = count; a.training = training;
+    a.mean = mean; a.invstd = invstd; a.relu = relu; a.sums = (double*)sums; a.sreps = sums_replicas < 1 ? 1 : sums_replicas; a.srstride = sums_rstride;
+    a.count = count; a.training = training;
     a.accumulate = accumulate; a.dx = dx; a.lddx = lddx; a.dres = dres; a.lddres = lddres; a.dgamma = dgamma; a.dbeta = dbeta;
     a.P = pixels; a.C = C;
     int blocks; const int V = vec ? (dtype == SAUNET_BF16 ? 8 : 4) : 1;

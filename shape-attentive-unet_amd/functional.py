@@ -422,13 +422,14 @@ def bn_backward(dy, x, p, relu, count, training, residual=None, dx=None, accumul
     dt = L.dtype_code(x)
     if presums is not None:
         # dy is already g = dy*[relu mask] and the two sums were taken in the producing dgrad kernel's epilogue
-        sums, relu = collapse_stats(presums), False
+        st, relu = presums, False
     else:
         st = new_stats(c, dev)
         L.call("saunet_bn_backward_reduce", dt, dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), rp, rl, p.scale.data_ptr(),
                p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), 1 if relu else 0, st.data_ptr(), st.shape[0], st.stride(0),
                P, c, L.stream())
-        sums = collapse_stats(st)
+    # one tiny launch folds the replicas: every apply thread re-adding 16 copies costs far more than that launch
+    sums, sreps, srstr = collapse_stats(st), 1, 0
     if sync_group is not None and training:
         torch.distributed.all_reduce(sums, group=sync_group)
     if dx is None:
@@ -436,7 +437,7 @@ def bn_backward(dy, x, p, relu, count, training, residual=None, dx=None, accumul
     dres = new_act(n, c, h, w, x.dtype, dev) if want_dres else None
     dgb = torch.empty(2, c, dtype=torch.float32, device=dev)
     L.call("saunet_bn_backward_apply", dt, dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), rp, rl, p.scale.data_ptr(),
-           p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), 1 if relu else 0, sums.data_ptr(), float(count),
+           p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), 1 if relu else 0, sums.data_ptr(), sreps, srstr, float(count),
            1 if training else 0, 1 if accumulate else 0, dx.data_ptr(), ld_of(dx), L.ptr(dres),
            ld_of(dres) if dres is not None else 0, dgb[0].data_ptr(), dgb[1].data_ptr(), P, c, L.stream())
     return dx, dres, dgb[0], dgb[1]
@@ -1023,7 +1024,7 @@ class _Relu(torch.autograd.Function):
         dummy = torch.zeros(2 * c, dtype=torch.float64, device=dev)
         # identity-statistics BN backward in eval mode == dy * [y > 0]
         L.call("saunet_bn_backward_apply", L.dtype_code(y), dy.data_ptr(), ld_of(dy), y.data_ptr(), ld_of(y), None, 0, one.data_ptr(),
-               zero.data_ptr(), zero.data_ptr(), one.data_ptr(), 1, dummy.data_ptr(), 1.0, 0, 0, dx.data_ptr(), ld_of(dx), None, 0, None, None,
+               zero.data_ptr(), zero.data_ptr(), one.data_ptr(), 1, dummy.data_ptr(), 1, 0, 1.0, 0, 0, dx.data_ptr(), ld_of(dx), None, 0, None, None,
                n * h * w, c, L.stream())
         return dx
 
@@ -1123,7 +1124,7 @@ class _DenseBlock(torch.autograd.Function):
             s1 = new_stats(cin, dev)
             conv_dgrad_raw(dz1, c1w, (n, cin, h, w), 1, 0, out=dbuf[:, :cin], bn_epi=(xin, p1, True, s1, True))
             dgb = torch.empty(2, cin, dtype=torch.float32, device=dev)
-            L.call("saunet_bn_backward_coeff", cin, collapse_stats(s1).data_ptr(), float(count), p1.scale.data_ptr(), AB[0].data_ptr(), AB[1].data_ptr(),
+            L.call("saunet_bn_backward_coeff", cin, s1.data_ptr(), s1.shape[0], s1.stride(0), float(count), p1.scale.data_ptr(), AB[0].data_ptr(), AB[1].data_ptr(),
                    dgb[0].data_ptr(), dgb[1].data_ptr(), 1 if training else 0, L.stream())
             grads[6 * l:6 * l + 6] = [dgb[0], dgb[1], dw1, dg2, db2, dw2]
         correct(0, c0)

@@ -51,9 +51,9 @@ _SIGS = {
     "saunet_bn_finalize": [i32, vp, vp, i32, i32, f64, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp],
     "saunet_affine_act": [i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, i64, i32, vp],
     "saunet_bn_backward_reduce": [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, i32, i64, i32, vp],
-    "saunet_bn_backward_apply": [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, f64, i32, i32,
+    "saunet_bn_backward_apply": [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, i32, f64, i32, i32,
                                  vp, i32, vp, i32, vp, vp, i64, i32, vp],
-    "saunet_bn_backward_coeff": [i32, vp, f64, vp, vp, vp, vp, vp, i32, vp],
+    "saunet_bn_backward_coeff": [i32, vp, i32, i32, f64, vp, vp, vp, vp, vp, i32, vp],
     "saunet_bn_backward_correct": [i32, vp, i32, vp, i32, vp, vp, vp, vp, i64, i32, vp],
     "saunet_bilinear_forward": [i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp],
     "saunet_bilinear_backward": [i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp],

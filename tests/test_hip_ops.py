@@ -295,7 +295,8 @@ def test_canny_bit_exact_with_oracle():
     img, _, _ = Wt.synthetic_batch(3, 64, 96, seed=17)
     r = np.random.default_rng(0)
     noisy = torch.from_numpy((r.standard_normal((2, 1, 64, 96)) * 3).astype(np.float32)).repeat(1, 3, 1, 1)
-    for x in (img, noisy, torch.zeros(1, 3, 32, 32)):
+    big = torch.from_numpy((r.standard_normal((1, 1, 400, 400)) * 2).astype(np.float32)).repeat(1, 3, 1, 1)   # > 152 KiB map: global-memory sweeps
+    for x in (img, noisy, torch.zeros(1, 3, 32, 32), big):
         want = oc.canny_batch(x.numpy())
         got = hf.canny(x.cuda(), 10, 100, dtype=torch.float32).cpu().numpy()
         assert got.shape == want.shape
