@@ -388,6 +388,17 @@ static bool is_pointwise(const saunet_conv_desc* d)
     return d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->transposed && d->Ho == d->H && d->Wo == d->W;
 }
 
+// A pointwise conv over maps that are not multiples of the 16x16 pixel tile (8x8, 24x40, ...) is re-described as N' images of
+// 16x16 pixels when the pixel count allows: the tiled weight-gradient kernel only needs 256-pixel groups of contiguous rows.
+static bool dense_pointwise_rows(const saunet_conv_desc* d, saunet_conv_desc* out)
+{
+    const long P = (long)d->N * d->H * d->W;
+    if ((d->H % 16 == 0 && d->W % 16 == 0) || P % 256 != 0) return false;
+    *out = *d;
+    out->N = (int)(P / 256); out->H = out->W = out->Ho = out->Wo = 16;
+    return true;
+}
+
 }  // namespace saunet
 
 using namespace saunet;
@@ -508,6 +519,8 @@ int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const voi
 
 int64_t saunet_conv2d_wgrad_workspace(const saunet_conv_desc* d)
 {
+    saunet_conv_desc flat;
+    if (is_pointwise(d) && dense_pointwise_rows(d, &flat)) d = &flat;
     if (igemm_supported(d) && tile_wgrad_supported(d)) {
         size_t need = 0;
         int rc = tile_wgrad(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &need, true, nullptr);
@@ -525,6 +538,8 @@ int saunet_conv2d_wgrad(const saunet_conv_desc* d, const void* x, const void* dy
                         void* workspace, int64_t workspace_bytes, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
+    saunet_conv_desc flat;
+    if (is_pointwise(d) && dense_pointwise_rows(d, &flat)) d = &flat;     // pixels are just rows for a 1x1 conv: any map shape tiles
     if (igemm_supported(d)) {
         if (tile_wgrad_supported(d)) return tile_wgrad(d, x, dy, ps, psh, dw, workspace, (size_t)workspace_bytes, nullptr, true, st);
         return igemm_wgrad(d, x, dy, ps, psh, dw, st);

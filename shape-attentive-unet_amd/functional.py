@@ -344,6 +344,12 @@ def _conv_wgrad_impl(x, dy, weight, stride, pad, transposed=False, pro=None):
         cols = im2col(dy, 4, 4, 2, 1)
         dwp = _conv_wgrad_impl(cols, x, _ShapeOnly((ci, 16 * co, 1, 1)), 1, 0)
         return dwp.view(ci, 4, 4, co).permute(0, 3, 1, 2).contiguous()
+    if (not transposed and pro is None and tuple(weight.shape[2:]) == (3, 3) and stride == 1 and pad == 1 and (x.shape[2] % 16 or x.shape[3] % 16)
+            and (x.shape[0] * x.shape[2] * x.shape[3]) % 256 == 0 and x.shape[1] % 8 == 0 and weight.shape[0] % 8 == 0):
+        # 3x3 convs on maps smaller than the 16x16 pixel tile (the 8x8 `center`): im2col (a few MB) + pointwise weight gradient
+        co, ci = weight.shape[0], weight.shape[1]
+        dwp = _conv_wgrad_impl(im2col(x, 3, 3, 1, 1), dy, _ShapeOnly((co, 9 * ci, 1, 1)), 1, 0)
+        return dwp.view(co, 3, 3, ci).permute(0, 3, 1, 2).contiguous()
     dw = GRADS.take(weight.numel(), x.device).view(weight.shape)
     if transposed:
         _, cout, kh, kw = weight.shape

@@ -68,6 +68,8 @@ CONV_CASES = [
     (2, 32, 64, 40, 4, 1, 1, 0),       # final (scalar dy rows)
     (1, 8, 72, 64, 1, 1, 1, 0),        # fuse
     (3, 1024, 8, 8, 1, 1, 1, 0),       # c5: many inputs, one output, few pixels (pointwise_wgrad_fewout_kernel)
+    (4, 64, 8, 8, 32, 3, 1, 1),        # `center`-like 8x8 map: weight gradient through im2col + pointwise rows
+    (4, 64, 8, 8, 128, 1, 1, 0),       # pointwise on an 8x8 map: rows regrouped into 16x16 tiles for the tiled wgrad
 ]
 
 
