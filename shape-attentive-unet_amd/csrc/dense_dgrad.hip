@@ -1,0 +1,213 @@
+// DenseNet conv1 data gradient with the fused "linear" BatchNorm-backward epilogue -- the single largest kernel of the
+// training step (58 launches: every dense layer sends its 128-channel bottleneck gradient back to ALL earlier channels).
+//
+//     G[p][c]   = sum_k g[p][k] * W[c][k]                    K = 128 (bn_size * growth), c < Cin_i (64 .. 1024)
+//     G         = G * [x[p][c]*scale[c] + shift[c] > 0]      ReLU mask of the layer's norm1 (recomputed from the concat buffer)
+//     sums[c]  += G ,  sums[Cin+c] += G * xhat               the two BN-backward sums (float64, replicated)
+//     y[p][c]  += scale[c] * G                               accumulate into the block's gradient buffer ("linear" BN backward)
+//
+// Traffic per launch: g once, x once, y read + write  ->  (128 + 3*Cin) * 2 B per pixel; 20 flop/B, i.e. HBM bound.
+// The generic implicit-GEMM kernel (conv_igemm.hip) runs this with a 128x128 block tile: operands staged through LDS,
+// the accumulator tile transposed through LDS again, and the x / y tiles requested only after the K loop -- two blocks
+// per CU, every block serialising  load -> MFMA -> load -> store  with nothing else to hide the latencies (~1.9 TB/s).
+// Here every WAVE is independent and there is no LDS staging and no barrier at all:
+//   * the product is computed TRANSPOSED (rows = channels, columns = pixels): both MFMA operands are then 16-byte
+//     K-contiguous pieces of g rows / packed weight rows and go straight from global memory into registers;
+//   * a wave keeps the g fragments of its 32 pixels (32 VGPRs) for all channel tiles;
+//   * in the accumulator layout a lane owns ONE pixel and 4 runs of 4 consecutive channels, so x / y are read and y is
+//     written as 8-byte pieces per lane (the two half-waves complete 16 B per pixel row per instruction) -- requested for
+//     a whole 64-channel group (one 128-byte line per row) before the MFMAs, with the next tile's weights in flight;
+//   * per-channel sums over the 32 pixels of a tile are five DPP adds per value (VALU, not the LDS crossbar), then one
+//     LDS atomic per channel per wave tile and one float64 atomic per channel per block.
+#include "common.h"
+#include <stdlib.h>
+
+namespace saunet {
+
+struct DenseDgradArgs {
+    const u16* g; int ldg; const u16* w; const u16* x; int ldx; u16* y; int ldy;
+    const float* scale; const float* shift; const float* mean; const float* invstd;
+    double* sums; int reps, rstride;
+    unsigned P; int Cin, relu, accumulate, group;
+};
+
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ float dpp_add(float v)
+{
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(moved);
+}
+// sum over the 32 lanes of each wave half; valid in lanes 16..31 and 48..63
+__device__ __forceinline__ float half_wave_sum(float v)
+{
+    v = dpp_add<0xB1>(v);          // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);          // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);         // row_half_mirror
+    v = dpp_add<0x140>(v);         // row_mirror  -> every lane of a 16-lane row holds the row sum
+    v = dpp_add<0x142, 0xa>(v);    // row_bcast:15 into rows 1 and 3
+    return v;
+}
+
+constexpr int DG_GROUP = 256;          // channels per block (weights of one group live in LDS: 256 rows x 272 B)
+constexpr int DG_WPITCH = 136;         // u16 per LDS weight row: 128 + 8 pad -> 16 consecutive rows hit 16 different 16-byte bank groups
+constexpr int DG_WAVES = 4;
+
+// grid = (pixel-tile workers, channel groups of 256).  The block's weight rows are copied to LDS once; every WAVE then streams
+// over 32-pixel tiles on its own (no barrier after the prologue): g fragments of the tile in registers, and for every 64-channel
+// step (= one 128-byte line of the x / y rows) two 32x32 MFMA tiles whose A fragments come from LDS.
+// Accumulator layout -> memory layout: after the MFMA a lane owns pixel (lane & 31) and the 4-channel runs 8j + 4*(lane >> 5);
+// one v_permlane32_swap per value pair trades runs with the partner lane (same pixel, other half-wave) so that a lane owns
+// 8 CONSECUTIVE channels twice per tile: x / y are then read and written as 16-byte pieces (measured 5.4 TB/s for this
+// row-piece pattern against 3.8 TB/s with 8-byte pieces; scripts/probes/rowpiece_probe.hip).
+__global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgradArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char d_smem[];
+    const int g0 = blockIdx.y * a.group;
+    const int GC = min(a.group, a.Cin - g0);           // channels of this group (multiple of 8)
+    const int GCP = (GC + 31) & ~31;
+    u16* s_w = (u16*)d_smem;                             // [GCP][DG_WPITCH]
+    float* s_par = (float*)(d_smem + (size_t)GCP * DG_WPITCH * 2);   // [4][GCP] scale, shift, invstd, -mean*invstd
+    float* s_sum = s_par + 4 * GCP;                      // [2][GCP]
+    constexpr int NT = DG_WAVES * 64;
+    for (int i = threadIdx.x; i < GCP * 16; i += NT) {
+        const int r = i >> 4, ch = i & 15;
+        *(u32x4*)(s_w + r * DG_WPITCH + ch * 8) = *(const u32x4*)(a.w + (size_t)min(g0 + r, a.Cin - 1) * 128 + ch * 8);
+    }
+    for (int i = threadIdx.x; i < GCP; i += NT) {
+        const bool ok = i < GC;
+        const float is = ok ? a.invstd[g0 + i] : 0.f;
+        s_par[i] = ok ? a.scale[g0 + i] : 0.f; s_par[GCP + i] = ok ? a.shift[g0 + i] : 0.f;
+        s_par[2 * GCP + i] = is; s_par[3 * GCP + i] = ok ? -a.mean[g0 + i] * is : 0.f;
+        s_sum[i] = 0.f; s_sum[GCP + i] = 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+    const unsigned ntp = (a.P + 31) / 32;
+    const unsigned stride = gridDim.x * DG_WAVES;
+    const int nsteps = (GCP + 63) / 64;                  // 64-channel steps in the group
+
+    // x / y pieces of one 64-channel step: piece i (tile t = i >> 1, run r = i & 1) = channels step*64 + 32t + 16r + 8*lh .. +8
+    struct XY { u32x4 x[4], y[4]; };
+    auto request = [&](size_t pp, int step, XY& o) {
+        const u16* xr = a.x + pp * a.ldx + g0 + step * 64 + 8 * lh;
+        const u16* yr = a.y + pp * a.ldy + g0 + step * 64 + 8 * lh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = step * 64 + 16 * i + 8 * lh < GC;
+            o.x[i] = ok ? *(const u32x4*)(xr + 16 * i) : u32x4{0u, 0u, 0u, 0u};
+            o.y[i] = (ok && a.accumulate) ? *(const u32x4*)(yr + 16 * i) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    unsigned touched = 0u, pf = 0u;
+    for (unsigned tp = blockIdx.x * DG_WAVES + wave; tp < ntp; tp += stride) {
+        const unsigned p = tp * 32u + lr;
+        const bool live = p < a.P;
+        const size_t pp = live ? p : a.P - 1;
+        u32x4 gf[8];
+        {
+            const u16* grow = a.g + pp * a.ldg + lh * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) gf[ks] = live ? *(const u32x4*)(grow + ks * 16) : u32x4{0u, 0u, 0u, 0u};
+        }
+        XY cur, nxt;
+        request(pp, 0, cur);
+        {   // touch the g rows of this wave's next pixel tile (one load per 128-byte line) so that they wait in the L2
+            const unsigned pn = (tp + stride) * 32u + lr;
+            touched ^= pf;
+            if (pn < a.P) pf = *(const unsigned*)(a.g + (size_t)pn * a.ldg + lh * 64);
+        }
+        u16* yrow = a.y + pp * a.ldy + g0 + 8 * lh;
+        for (int step = 0; step < nsteps; ++step) {
+            if (step + 1 < nsteps) request(pp, step + 1, nxt);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ct = step * 64 + 32 * t;           // first channel of this MFMA tile inside the group
+                if (ct >= GCP) continue;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                const u16* wrow = s_w + (ct + lr) * DG_WPITCH + lh * 8;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const u32x4 wf = *(const u32x4*)(wrow + ks * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, gf[ks]), acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    // runs 2r (A) and 2r+1 (B) -> this lane's 8 consecutive channels cl .. cl+7
+                    float G[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * r + q]), __float_as_uint(acc[8 * r + 4 + q]), false, false);
+                        G[q] = __uint_as_float(sw[0]); G[4 + q] = __uint_as_float(sw[1]);
+                    }
+                    const int cl = ct + 16 * r + 8 * lh;
+                    const bool ok = live && cl < GC;
+                    float xf[8], yf[8], o[8];
+                    Vec16<u16>::unpack(cur.x[2 * t + r], xf); Vec16<u16>::unpack(cur.y[2 * t + r], yf);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 sc = *(const f32x4*)(s_par + cl + 4 * h), sh = *(const f32x4*)(s_par + GCP + cl + 4 * h);
+                        const f32x4 a1 = *(const f32x4*)(s_par + 2 * GCP + cl + 4 * h), a0 = *(const f32x4*)(s_par + 3 * GCP + cl + 4 * h);
+                        float e1[4], e2[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int e = 4 * h + q;
+                            const bool keep = ok && (!a.relu || fmaf(xf[e], sc[q], sh[q]) > 0.f);
+                            const float Gv = keep ? G[e] : 0.f;
+                            e1[q] = half_wave_sum(Gv); e2[q] = half_wave_sum(Gv * fmaf(xf[e], a1[q], a0[q]));
+                            o[e] = a.accumulate ? fmaf(sc[q], Gv, yf[e]) : Gv;
+                        }
+                        if (lr == 31) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { atomicAdd(&s_sum[cl + 4 * h + q], e1[q]); atomicAdd(&s_sum[GCP + cl + 4 * h + q], e2[q]); }
+                        }
+                    }
+                    if (ok) *(u32x4*)(yrow + cl - 8 * lh) = Vec16<u16>::pack(o);
+                }
+            }
+            cur = nxt;
+        }
+    }
+    if (a.P == 0xffffffffu && (touched ^ pf) == 0x5a5a5a5au) s_sum[0] += 1.f;     // never true: keeps the touch loads alive
+    __syncthreads();
+    const size_t ro = (size_t)(blockIdx.x % a.reps) * a.rstride;
+    for (int i = threadIdx.x; i < GC; i += NT) {
+        atomicAdd(&a.sums[ro + g0 + i], (double)s_sum[i]);
+        atomicAdd(&a.sums[ro + a.Cin + g0 + i], (double)s_sum[GCP + i]);
+    }
+}
+
+bool dense_dgrad_supported(const saunet_conv_desc* d, const float* bias, const float* ps, const saunet_bn_epilogue* epi)
+{
+    return epi != nullptr && epi->bn_x != nullptr && d->dtype == SAUNET_BF16 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 &&
+           !d->transposed && d->Cin == 128 && d->Cout % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && epi->ld_bn_x % 8 == 0 &&
+           bias == nullptr && ps == nullptr && d->Cout <= 2048 && (long)d->N * d->H * d->W < (1L << 31);
+}
+
+int dense_dgrad_forward(const saunet_conv_desc* d, const void* x, const void* w, void* y, const saunet_bn_epilogue* epi, hipStream_t st)
+{
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)epi->bn_x) & 15)
+        return set_error(SAUNET_BAD_ALIGN, "dense dgrad: operands must be 16-byte aligned");
+    DenseDgradArgs a;
+    a.g = (const u16*)x; a.ldg = d->ldx; a.w = (const u16*)w; a.x = (const u16*)epi->bn_x; a.ldx = epi->ld_bn_x; a.y = (u16*)y; a.ldy = d->ldy;
+    a.scale = epi->scale; a.shift = epi->shift; a.mean = epi->mean; a.invstd = epi->invstd;
+    a.sums = epi->sums; a.reps = epi->sums_replicas > 1 ? epi->sums_replicas : 1; a.rstride = epi->sums_rstride;
+    a.P = (unsigned)((long)d->N * d->H * d->W); a.Cin = d->Cout; a.relu = epi->relu; a.accumulate = epi->accumulate;
+    // channels per block: 256 (weights copied to LDS once per block) when every wave gets many pixel tiles, fewer on the
+    // low-resolution blocks where the copy would dominate and more blocks are needed to fill the chip
+    const long ntp = ((long)a.P + 31) / 32;
+    a.group = ntp >= 4096 ? DG_GROUP : (ntp >= 1024 ? 128 : 64);
+    const int groups = (a.Cin + a.group - 1) / a.group;
+    const int gcp = ((a.Cin < a.group ? a.Cin : a.group) + 31) & ~31;
+    const size_t lds = (size_t)gcp * DG_WPITCH * 2 + sizeof(float) * 6 * gcp;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
+    // two resident blocks per CU in total; at least one pixel tile per wave
+    long bx = (512 + groups - 1) / groups; const long maxbx = ((long)a.P + 32 * DG_WAVES - 1) / (32 * DG_WAVES);
+    if (bx > maxbx) bx = maxbx; if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(dense_dgrad_kernel, dim3((unsigned)bx, groups), dim3(DG_WAVES * 64), lds, st, a);
+    SAUNET_CHECK_LAUNCH("dense_dgrad");
+    return SAUNET_OK;
+}
+
+}  // namespace saunet

@@ -1,0 +1,60 @@
+"""GPU parity of the DenseNet block (forward + the "linear" BatchNorm backward with its fused dgrad epilogues) against a
+float64 torch restatement of torchvision's _DenseBlock (/root/reference/models/models.py:271,306-313 use it unchanged):
+    for each layer:  new = conv2(relu(norm2(conv1(relu(norm1(cat(features)))))));  features.append(new)
+float32 storage: 2e-4 of each tensor's scale.  bf16 storage (dense_dgrad.hip / tile kernels with bf16 operands): outputs within
+1e-2; gradients are compared in the relative L2 norm with a loose bound, because every pre-activation that bf16 rounding moves
+across zero flips a ReLU mask and changes that element's gradient by O(1) (~0.4 % of the elements -> 5-10 % in L2; the same
+holds for any bf16 activation storage).  scripts/dense_ab.py prints the figures for the dedicated and the generic dgrad kernel."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_block(block, x):
+    d = torch.float64
+    prm = {k: v.detach().to(d).requires_grad_(True) for k, v in block.named_parameters()}
+    xr = x.detach().to(d).requires_grad_(True)
+    feats = [xr]
+    for name, layer in block.items():
+        cat = torch.cat(feats, 1)
+        a = F.relu(F.batch_norm(cat, None, None, prm[name + ".norm1.weight"], prm[name + ".norm1.bias"], True, 0.0, layer.norm1.eps))
+        z1 = F.conv2d(a, prm[name + ".conv1.weight"])
+        b = F.relu(F.batch_norm(z1, None, None, prm[name + ".norm2.weight"], prm[name + ".norm2.bias"], True, 0.0, layer.norm2.eps))
+        feats.append(F.conv2d(b, prm[name + ".conv2.weight"], padding=1))
+    return torch.cat(feats, 1), xr, prm
+
+
+def rel(a, b):
+    b = b.to(torch.float64)
+    return float((a.detach().to(torch.float64) - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rel_l2(a, b):
+    b = b.to(torch.float64)
+    return float((a.detach().to(torch.float64) - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("layers,cin,shape", [(3, 64, (2, 32, 32)), (2, 96, (1, 16, 48)), (4, 40, (3, 16, 16))])
+def test_dense_block_fwd_bwd(dtype, tol, layers, cin, shape):
+    import saunet_amd as S
+    torch.manual_seed(layers * 100 + cin)
+    n, h, w = shape
+    block = S.modules._DenseBlock(layers, cin).cuda().train()
+    with torch.no_grad():
+        for m in block.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+    x = torch.randn(n, cin, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = block(x)
+    cot = torch.randn(y.shape, device="cuda").to(dtype)
+    (y.float() * cot.float()).sum().backward()
+    ry, xr, prm = ref_block(block, x)
+    (ry * cot.double()).sum().backward()
+    assert rel(y, ry) < tol, rel(y, ry)
+    err, gtol = (rel, tol) if dtype == torch.float32 else (rel_l2, 0.2)
+    assert err(x.grad, xr.grad) < gtol, err(x.grad, xr.grad)
+    for k, v in block.named_parameters():
+        assert err(v.grad, prm[k].grad) < gtol, (k, err(v.grad, prm[k].grad))
