@@ -48,22 +48,25 @@ def parse():
 
 
 def kernel_roofline(S, dtype, batch, size):
-    """Time the dominant kernel family on its own with HIP events on the launch stream.
+    """Time the dominant kernel of the step on its own with HIP events on the launch stream.
 
-    Dominant kernel of the step (profiles/): the DenseNet 3x3 implicit-GEMM convolution (128 -> 32 channels,
-    58 instances/forward; here block-1 geometry: B x 128 x 128 pixels).  Algorithmic bytes per launch =
-    input [P,128] + output [P,32] elements x itemsize (+ weights 36,864 elements); algorithmic FLOPs = 2*P*1152*32."""
+    Dominant kernel (profiles/r01_f_step_kernel_stats.txt): dense_dgrad_kernel -- the DenseNet conv1 data gradient with the
+    fused BatchNorm-backward epilogue (58 launches per step, one per dense layer; csrc/dense_dgrad.hip).  Probe geometry:
+    dense block 1, layer 5 (Cin = 192 earlier channels) at B x (size/2)^2 pixels.  Algorithmic bytes per launch:
+    g [P,128] read + x [P,Cin] read + dbuf [P,Cin] read and written = (128 + 3*Cin) * itemsize per pixel (+ 128*Cin weights);
+    algorithmic FLOPs = 2*P*128*Cin."""
     HF = S.functional
     h = size // 2
-    n, cin, cout = batch, 128, 32
-    x = torch.randn(n, cin, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
-    w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device="cuda") * 0.03)
-    scale = torch.rand(cin, device="cuda") + 0.5
-    shift = torch.randn(cin, device="cuda") * 0.1
-    out = HF.new_act(n, cout, h, h, dtype, "cuda")
-    stats = torch.zeros(HF.STAT_R, 2, cout, dtype=torch.float64, device="cuda")
+    n, k, cin, ctot = batch, 128, 192, 256
+    buf = torch.randn(n, ctot, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)    # concat buffer (x)
+    dbuf = torch.randn(n, ctot, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)   # gradient buffer (y)
+    g = torch.randn(n, k, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.randn(k, cin, 1, 1, device="cuda") * 0.05)
+    p = HF.BNParams(cin, "cuda")
+    p.buf[0].uniform_(0.5, 1.5); p.buf[1].normal_(0, 0.3); p.buf[2].normal_(0, 0.3); p.buf[3].uniform_(0.5, 1.5)
+    sums = torch.zeros(HF.STAT_R, 2, cin, dtype=torch.float64, device="cuda")
     def run():
-        HF.conv_forward_raw(x, w, None, 1, 1, pro=(scale, shift, True), out=out, stats=stats)
+        HF.conv_dgrad_raw(g, w, (n, cin, h, h), 1, 0, out=dbuf[:, :cin], bn_epi=(buf[:, :cin], p, True, sums, True))
     for _ in range(5):
         run()
     torch.cuda.synchronize()
@@ -75,20 +78,21 @@ def kernel_roofline(S, dtype, batch, size):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     P = n * h * h
-    flops = 2.0 * P * (cin * 9) * cout
-    nbytes = (P * cin + P * cout + cout * cin * 9) * x.element_size()
+    flops = 2.0 * P * k * cin
+    nbytes = (P * (k + 3 * cin) + k * cin) * g.element_size()
     tflops = flops / (ms * 1e-3) / 1e12
     gbs = nbytes / (ms * 1e-3) / 1e9
     ai = flops / nbytes
     peak_tf = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
+    label = "dense_dgrad 1x1 128->%d +BN-bwd epilogue @%dx%d B%d" % (cin, h, h, n)
     # the bound that applies: min(MFMA peak, AI x HBM peak)
     hbm_bound_tf = ai * HBM_PEAK_GBS / 1e3
     if hbm_bound_tf < peak_tf:
         return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": None, "kernel": "conv_igemm_fwd 3x3 128->32 @%dx%d B%d" % (h, h, n), "ms": round(ms, 4),
+                "traffic": None, "kernel": label, "ms": round(ms, 4), "algorithmic_bytes": int(nbytes),
                 "tflops": round(tflops, 1), "flop_per_byte": round(ai, 1)}
     return {"bound": "mfma", "achieved": round(tflops, 1), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(tflops / peak_tf, 4),
-            "traffic": None, "kernel": "conv_igemm_fwd 3x3 128->32 @%dx%d B%d" % (h, h, n), "ms": round(ms, 4),
+            "traffic": None, "kernel": label, "ms": round(ms, 4), "algorithmic_bytes": int(nbytes),
             "gbs": round(gbs, 1), "flop_per_byte": round(ai, 1)}
 
 
