@@ -96,6 +96,20 @@ def kernel_roofline(S, dtype, batch, size):
             "gbs": round(gbs, 1), "flop_per_byte": round(ai, 1)}
 
 
+def config_name(args, world):
+    """which BASELINE.json config the command line corresponds to"""
+    key = (args.size, args.batch, args.dtype)
+    if key == (256, 32, "bf16"):
+        return "configs[1]" if world == 1 else "configs[2]"
+    if key == (256, 64, "bf16"):
+        return "configs[3]"
+    if key == (512, 8, "f32"):
+        return "configs[4]"
+    if key == (128, 2, "f32"):
+        return "configs[0] geometry"
+    return "custom geometry (not a BASELINE config)"
+
+
 def pmc_traffic(kernel_label):
     """HBM bytes per launch of the probe kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json), or None."""
     path = os.path.join(ROOT, "profiles", "roofline_pmc.json")
@@ -247,7 +261,7 @@ def main():
             "value": round(slices, 2), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic (ellipse phantom, z-scored; random-init weights)",
-            "config": {"workload": "ACDC %dx%d batch=%d/GPU SAUNet %s, configs[%d]" % (args.size, args.size, args.batch, args.dtype, 1 if world == 1 else 2),
+            "config": {"workload": "ACDC %dx%d batch=%d/GPU SAUNet %s, %s" % (args.size, args.size, args.batch, args.dtype, config_name(args, world)),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "mode": mode, "optimizer": args.optimizer,
                        "loss": round(final_loss, 5)},
             "achieved_tflops_algorithmic": round(slices * TRAIN_GFLOP_PER_SLICE_256 * scale / 1e3, 2),

@@ -15,6 +15,8 @@ int set_error(int code, const char* fmt, ...)
 
 bool dense_dgrad_supported(const saunet_conv_desc* d, const float* bias, const float* ps, const saunet_bn_epilogue* epi);
 int dense_dgrad_forward(const saunet_conv_desc* d, const void* x, const void* w, void* y, const saunet_bn_epilogue* epi, hipStream_t st);
+bool dense_dgrad3_supported(const saunet_conv_desc* d, const float* bias, const float* ps, const saunet_bn_epilogue* epi);
+int dense_dgrad3_forward(const saunet_conv_desc* d, const void* x, const void* w, void* y, const saunet_bn_epilogue* epi, hipStream_t st);
 bool igemm_supported(const saunet_conv_desc* d);
 int igemm_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps, const float* psh,
                   void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st);
@@ -469,6 +471,7 @@ int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const voi
     if ((ps == nullptr) != (psh == nullptr)) return set_error(SAUNET_BAD_SHAPE, "conv: prologue needs scale and shift");
     static const bool use_dense_dgrad = !(getenv("SAUNET_DENSE_DGRAD") && getenv("SAUNET_DENSE_DGRAD")[0] == '0');   // A/B switch for profiling
     if (use_dense_dgrad && ssum == nullptr && dense_dgrad_supported(d, bias, ps, epi)) return dense_dgrad_forward(d, x, w, y, epi, st);
+    if (use_dense_dgrad && ssum == nullptr && dense_dgrad3_supported(d, bias, ps, epi)) return dense_dgrad3_forward(d, x, w, y, epi, st);
     if (igemm_supported(d)) {
         if (epi && (((uintptr_t)epi->bn_x & 15) || epi->ld_bn_x % (d->dtype == SAUNET_BF16 ? 8 : 4)))
             return set_error(SAUNET_BAD_ALIGN, "conv: bn epilogue tensor must be 16-byte aligned");

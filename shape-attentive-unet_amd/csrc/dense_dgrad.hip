@@ -178,6 +178,154 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgra
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// DenseNet conv2 (3x3, 128 -> 32) data gradient with the BatchNorm-backward reduction epilogue of norm2: the same
+// wave-independent transposed-MFMA structure.  As a forward-view conv: 32 input channels (the layer's gradient chunk of the
+// block buffer), 9 taps, 128 output channels:
+//     G[p][n] = sum_{tap,k} W[n][tap][k] * g[p + tap][k]          K = 9 * 32 = 288
+//     G       = G * [z1[p][n]*scale[n] + shift[n] > 0] ;  sums[n] += G ,  sums[128+n] += G * xhat ;  out[p][n] = G
+// The B fragments are 16-byte pieces of the g rows of the 9 shifted pixels, loaded straight from global memory (64-byte rows,
+// L1/L2 hits for the 9-fold reuse; out-of-image taps are zero); the 128 x 288 weight rows live in LDS (296-element pitch);
+// a wave keeps its 18 g fragments (72 VGPRs) for the four 32-channel MFMA tiles; epilogue exactly as above (permlane32 swap,
+// 16-byte row pieces of z1 / out, one 128-byte line per 64-channel step stored together).
+// Traffic: (32 + 128 + 128) * 2 B per pixel; 128 flop/B -> HBM bound.
+struct DenseDgrad3Args {
+    const u16* g; int ldg; const u16* w; const u16* z; int ldz; u16* y; int ldy;
+    const float* scale; const float* shift; const float* mean; const float* invstd;
+    double* sums; int reps, rstride;
+    int N, H, W; unsigned P; int relu;
+    FastDiv dW, dHW;
+};
+constexpr int D3_WPITCH = 296;
+
+__global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgrad3Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char d_smem[];
+    u16* s_w = (u16*)d_smem;                                        // [128][D3_WPITCH]
+    float* s_par = (float*)(d_smem + (size_t)128 * D3_WPITCH * 2);  // [4][128]
+    float* s_sum = s_par + 4 * 128;                                 // [2][128]
+    constexpr int NT = DG_WAVES * 64;
+    for (int i = threadIdx.x; i < 128 * 36; i += NT) {
+        const int r = i / 36, ch = i - r * 36;
+        *(u32x4*)(s_w + r * D3_WPITCH + ch * 8) = *(const u32x4*)(a.w + (size_t)r * 288 + ch * 8);
+    }
+    for (int i = threadIdx.x; i < 128; i += NT) {
+        const float is = a.invstd[i];
+        s_par[i] = a.scale[i]; s_par[128 + i] = a.shift[i]; s_par[256 + i] = is; s_par[384 + i] = -a.mean[i] * is;
+        s_sum[i] = 0.f; s_sum[128 + i] = 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
+    const unsigned ntp = (a.P + 31) / 32;
+    for (unsigned tp = blockIdx.x * DG_WAVES + wave; tp < ntp; tp += gridDim.x * DG_WAVES) {
+        const unsigned p = tp * 32u + lr;
+        const bool live = p < a.P;
+        const unsigned pc = live ? p : a.P - 1;
+        const unsigned n = a.dHW.div(pc), rem = pc - n * (unsigned)(a.H * a.W);
+        const int py = (int)a.dW.div(rem), px = (int)(rem - (unsigned)py * a.W);
+        // B fragments: [tap][k half]  (k = 16*h + 8*lh .. +8 of the 32 gradient channels)
+        u32x4 gf[18];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+            const bool ok = live && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            const u16* row = a.g + ((size_t)n * a.H * a.W + (size_t)(ok ? yy : py) * a.W + (ok ? xx : px)) * a.ldg + lh * 8;
+            const u32x4 v0 = *(const u32x4*)row, v1 = *(const u32x4*)(row + 16);
+            gf[2 * tap] = ok ? v0 : u32x4{0u, 0u, 0u, 0u};
+            gf[2 * tap + 1] = ok ? v1 : u32x4{0u, 0u, 0u, 0u};
+        }
+        const u16* zrow = a.z + (size_t)pc * a.ldz + 8 * lh;
+        u16* yrow = a.y + (size_t)pc * a.ldy + 8 * lh;
+#pragma unroll 1
+        for (int step = 0; step < 2; ++step) {
+            u32x4 zv[4], outv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) zv[i] = *(const u32x4*)(zrow + step * 64 + 16 * i);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ct = step * 64 + 32 * t;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                const u16* wrow = s_w + (ct + lr) * D3_WPITCH + lh * 8;
+#pragma unroll
+                for (int ks = 0; ks < 18; ++ks) {
+                    const u32x4 wf = *(const u32x4*)(wrow + ks * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, gf[ks]), acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    float G[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * r + q]), __float_as_uint(acc[8 * r + 4 + q]), false, false);
+                        G[q] = __uint_as_float(sw[0]); G[4 + q] = __uint_as_float(sw[1]);
+                    }
+                    const int cl = ct + 16 * r + 8 * lh;
+                    float zf[8], o[8];
+                    Vec16<u16>::unpack(zv[2 * t + r], zf);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 sc = *(const f32x4*)(s_par + cl + 4 * h), sh = *(const f32x4*)(s_par + 128 + cl + 4 * h);
+                        const f32x4 a1 = *(const f32x4*)(s_par + 256 + cl + 4 * h), a0 = *(const f32x4*)(s_par + 384 + cl + 4 * h);
+                        float e1[4], e2[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int e = 4 * h + q;
+                            const bool keep = live && (!a.relu || fmaf(zf[e], sc[q], sh[q]) > 0.f);
+                            const float Gv = keep ? G[e] : 0.f;
+                            e1[q] = half_wave_sum(Gv); e2[q] = half_wave_sum(Gv * fmaf(zf[e], a1[q], a0[q]));
+                            o[e] = Gv;
+                        }
+                        if (lr == 31) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { atomicAdd(&s_sum[cl + 4 * h + q], e1[q]); atomicAdd(&s_sum[128 + cl + 4 * h + q], e2[q]); }
+                        }
+                    }
+                    outv[2 * t + r] = Vec16<u16>::pack(o);
+                }
+            }
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(u32x4*)(yrow + step * 64 + 16 * i) = outv[i];
+            }
+        }
+    }
+    __syncthreads();
+    const size_t ro = (size_t)(blockIdx.x % a.reps) * a.rstride;
+    for (int i = threadIdx.x; i < 128; i += NT) {
+        atomicAdd(&a.sums[ro + i], (double)s_sum[i]);
+        atomicAdd(&a.sums[ro + 128 + i], (double)s_sum[128 + i]);
+    }
+}
+
+bool dense_dgrad3_supported(const saunet_conv_desc* d, const float* bias, const float* ps, const saunet_bn_epilogue* epi)
+{
+    return epi != nullptr && epi->bn_x != nullptr && !epi->accumulate && d->dtype == SAUNET_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 1 &&
+           d->pad == 1 && !d->transposed && d->Cin == 32 && d->Cout == 128 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && epi->ld_bn_x % 8 == 0 &&
+           bias == nullptr && ps == nullptr && (long)d->N * d->H * d->W < (1L << 31);
+}
+
+int dense_dgrad3_forward(const saunet_conv_desc* d, const void* x, const void* w, void* y, const saunet_bn_epilogue* epi, hipStream_t st)
+{
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)epi->bn_x) & 15)
+        return set_error(SAUNET_BAD_ALIGN, "dense 3x3 dgrad: operands must be 16-byte aligned");
+    DenseDgrad3Args a;
+    a.g = (const u16*)x; a.ldg = d->ldx; a.w = (const u16*)w; a.z = (const u16*)epi->bn_x; a.ldz = epi->ld_bn_x; a.y = (u16*)y; a.ldy = d->ldy;
+    a.scale = epi->scale; a.shift = epi->shift; a.mean = epi->mean; a.invstd = epi->invstd;
+    a.sums = epi->sums; a.reps = epi->sums_replicas > 1 ? epi->sums_replicas : 1; a.rstride = epi->sums_rstride;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.P = (unsigned)((long)d->N * d->H * d->W); a.relu = epi->relu;
+    a.dW = FastDiv::make((unsigned)d->W); a.dHW = FastDiv::make((unsigned)(d->H * d->W));
+    const size_t lds = (size_t)128 * D3_WPITCH * 2 + sizeof(float) * 6 * 128;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
+    long bx = 512; const long maxbx = ((long)a.P + 32 * DG_WAVES - 1) / (32 * DG_WAVES);
+    if (bx > maxbx) bx = maxbx; if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(dense_dgrad3_kernel, dim3((unsigned)bx), dim3(DG_WAVES * 64), lds, st, a);
+    SAUNET_CHECK_LAUNCH("dense_dgrad3");
+    return SAUNET_OK;
+}
+
 bool dense_dgrad_supported(const saunet_conv_desc* d, const float* bias, const float* ps, const saunet_bn_epilogue* epi)
 {
     return epi != nullptr && epi->bn_x != nullptr && d->dtype == SAUNET_BF16 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 &&
