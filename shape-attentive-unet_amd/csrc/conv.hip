@@ -91,7 +91,7 @@ template <typename T> __global__ void pack_weight_multi_kernel(saunet_pack_list 
 struct PwArgs {
     const void* x; const void* w; void* y; const float* bias; const float* ps; const float* psh;
     double* ssum; double* ssq;
-    long P; int Cin, Cout, ldx, ldy, pro_relu; int srep, srstride;
+    long P; int Cin, Cout, ldx, ldy, pro_relu; int srep, srstride; int vec_out;
 };
 
 // Each block owns ITEMS = 256*PW_IT consecutive (pixel, cout) items; thread t handles items t, t+256, ...
@@ -178,7 +178,7 @@ template <typename T, int CIN_PAD> __global__ __launch_bounds__(256) void pointw
             xv[c] = (c < a.Cin) ? v : 0.f;
         }
         T* yr = (T*)a.y + (live ? p : 0) * a.ldy;
-        for (int co = 0; co < a.Cout; ++co) {
+        auto dot = [&](int co) {
             const float* wr = sw + co * CIN_PAD;
             float acc = 0.f;
 #pragma unroll
@@ -192,7 +192,21 @@ template <typename T, int CIN_PAD> __global__ __launch_bounds__(256) void pointw
                 float s = wave_sum(v), q = wave_sum(v * v);
                 if (lane == 0) { atomicAdd(&ssum[co], s); atomicAdd(&ssum[a.Cout + co], q); }
             }
-            if (live) Elem<T>::store(yr + co, acc + sb[co]);
+            return acc + sb[co];
+        };
+        constexpr int EPC = 16 / sizeof(T);
+        if (a.vec_out) {            // Cout % EPC == 0, 16-byte aligned output rows: one vector store per EPC channels
+            for (int co = 0; co < a.Cout; co += EPC) {
+                float o[EPC];
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) o[j] = dot(co + j);
+                if (live) *(u32x4*)(yr + co) = Vec16<T>::pack(o);
+            }
+        } else {
+            for (int co = 0; co < a.Cout; ++co) {
+                const float v = dot(co);
+                if (live) Elem<T>::store(yr + co, v);
+            }
         }
     }
     if (stats) {
@@ -485,7 +499,11 @@ int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const voi
     if (!is_pointwise(d)) return set_error(SAUNET_UNSUPPORTED, "conv: %dx%d s%d Cin=%d Cout=%d has no kernel", d->KH, d->KW, d->stride, d->Cin, d->Cout);
     if (ssum != nullptr && d->Cout > 64) return set_error(SAUNET_UNSUPPORTED, "pointwise stats need Cout <= 64");
     PwArgs a{x, w, y, bias, ps, psh, ssum, ssq, (long)d->N * d->H * d->W, d->Cin, d->Cout, d->ldx, d->ldy, d->pro_relu,
-             d->stat_replicas > 1 ? d->stat_replicas : 1, d->stat_rstride};
+             d->stat_replicas > 1 ? d->stat_replicas : 1, d->stat_rstride, 0};
+    {
+        const int epc = d->dtype == SAUNET_BF16 ? 8 : 4;
+        a.vec_out = d->Cout % epc == 0 && d->ldy % epc == 0 && !((uintptr_t)y & 15);
+    }
     if (d->Cin <= 64 && d->Cout <= 64) {
         const int cpad = d->Cin <= 4 ? 4 : d->Cin <= 8 ? 8 : d->Cin <= 16 ? 16 : d->Cin <= 36 ? 36 : 64;
         long blocks = (a.P + 255) / 256; if (blocks > 2048) blocks = 2048;

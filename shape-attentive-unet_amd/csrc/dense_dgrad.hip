@@ -72,9 +72,18 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgra
     float* s_par = (float*)(d_smem + (size_t)GCP * DG_WPITCH * 2);   // [4][GCP] scale, shift, invstd, -mean*invstd
     float* s_sum = s_par + 4 * GCP;                      // [2][GCP]
     constexpr int NT = DG_WAVES * 64;
-    for (int i = threadIdx.x; i < GCP * 16; i += NT) {
-        const int r = i >> 4, ch = i & 15;
-        *(u32x4*)(s_w + r * DG_WPITCH + ch * 8) = *(const u32x4*)(a.w + (size_t)min(g0 + r, a.Cin - 1) * 128 + ch * 8);
+    for (int i0 = threadIdx.x; i0 < GCP * 16; i0 += NT * 8) {     // 8 loads in flight per thread: the copy costs ~2 memory latencies
+        u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * NT, r = i >> 4, ch = i & 15;
+            if (i < GCP * 16) v[u] = *(const u32x4*)(a.w + (size_t)min(g0 + r, a.Cin - 1) * 128 + ch * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * NT, r = i >> 4, ch = i & 15;
+            if (i < GCP * 16) *(u32x4*)(s_w + r * DG_WPITCH + ch * 8) = v[u];
+        }
     }
     for (int i = threadIdx.x; i < GCP; i += NT) {
         const bool ok = i < GC;
@@ -205,9 +214,18 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgr
     float* s_par = (float*)(d_smem + (size_t)128 * D3_WPITCH * 2);  // [4][128]
     float* s_sum = s_par + 4 * 128;                                 // [2][128]
     constexpr int NT = DG_WAVES * 64;
-    for (int i = threadIdx.x; i < 128 * 36; i += NT) {
-        const int r = i / 36, ch = i - r * 36;
-        *(u32x4*)(s_w + r * D3_WPITCH + ch * 8) = *(const u32x4*)(a.w + (size_t)r * 288 + ch * 8);
+    for (int i0 = threadIdx.x; i0 < 128 * 36; i0 += NT * 9) {     // 9 loads in flight per thread
+        u32x4 v[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int i = i0 + u * NT;
+            if (i < 128 * 36) v[u] = *(const u32x4*)(a.w + (size_t)i * 8);      // rows are contiguous in the packed weights
+        }
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int i = i0 + u * NT, r = i / 36, ch = i - r * 36;
+            if (i < 128 * 36) *(u32x4*)(s_w + r * D3_WPITCH + ch * 8) = v[u];
+        }
     }
     for (int i = threadIdx.x; i < 128; i += NT) {
         const float is = a.invstd[i];

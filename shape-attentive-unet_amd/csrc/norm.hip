@@ -209,15 +209,18 @@ __device__ __forceinline__ double rep_sum(const double* __restrict__ s, int reps
 
 template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a)
 {
+    // the two per-channel sums, replicas added ONCE per block (cooperatively, into LDS) -- not once per thread and channel
+    extern __shared__ float s_c12[];       // [2][C]: sum g / count , sum g*xhat / count
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) {
+        const double v = rep_sum(a.sums, a.sreps, a.srstride, i);
+        s_c12[i] = a.training ? (float)(v / a.count) : 0.f;
+        if (blockIdx.x == 0 && a.dgamma) { if (i < a.C) a.dbeta[i] = (float)v; else a.dgamma[i - a.C] = (float)v; }
+    }
+    __syncthreads();
     const long p0 = blockIdx.x * a.rpb, p1 = min(p0 + a.rpb, a.P);
     const int CH = a.C / V;
     const T* dy = (const T*)a.dy; const T* x = (const T*)a.x; const T* res = (const T*)a.res;
     T* dx = (T*)a.dx; T* dres = (T*)a.dres;
-    if (blockIdx.x == 0 && a.dgamma) {
-        for (int c = threadIdx.x; c < a.C; c += 256) {
-            a.dbeta[c] = (float)rep_sum(a.sums, a.sreps, a.srstride, c); a.dgamma[c] = (float)rep_sum(a.sums, a.sreps, a.srstride, a.C + c);
-        }
-    }
     for (int cb = 0; cb < CH; cb += 256) {
         const int cw = min(256, CH - cb), rl = 256 / cw;
         const int ch = cb + threadIdx.x % cw, r0 = threadIdx.x / cw;
@@ -227,8 +230,7 @@ template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_apply
         for (int j = 0; j < V; ++j) {
             const int c = ch * V + j;
             s[j] = a.scale[c]; t[j] = a.shift[c]; mu[j] = a.mean[c]; is[j] = a.invstd[c];
-            c1[j] = a.training ? (float)(rep_sum(a.sums, a.sreps, a.srstride, c) / a.count) : 0.f;
-            c2[j] = a.training ? (float)(rep_sum(a.sums, a.sreps, a.srstride, a.C + c) / a.count) : 0.f;
+            c1[j] = s_c12[c]; c2[j] = s_c12[a.C + c];
         }
         for (long p = p0 + r0; p < p1; p += rl) {
             float g[V], xv[V], r[V], o[V];
@@ -430,7 +432,7 @@ int saunet_bn_backward_apply(int dtype, const void* dy, int lddy, const void* x,
     a.P = pixels; a.C = C;
     int blocks; const int V = vec ? (dtype == SAUNET_BF16 ? 8 : 4) : 1;
     a.rpb = rows_per_block(pixels, C, V, &blocks);
-#define CALL(TT, VV) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, VV>), dim3(blocks), dim3(256), 0, st, a)
+#define CALL(TT, VV) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, VV>), dim3(blocks), dim3(256), sizeof(float) * 2 * C, st, a)
     DISPATCH_TV(dtype, vec, CALL);
 #undef CALL
     SAUNET_CHECK_LAUNCH("bn_backward_apply");

@@ -15,14 +15,28 @@ __global__ __launch_bounds__(256) void sgd_kernel(saunet_tensor_list tl, const f
     const long n = tl.numel[t];
     const float lr = hyper[0], mom = hyper[1], wd = hyper[2], gs = hyper[4];
     const bool first = hyper[3] != 0.f;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        float d = g[i] * gs;
-        if (wd != 0.f) d = fmaf(wd, p[i], d);
-        if (mom != 0.f) {
-            float b = first ? d : fmaf(mom, m[i], d);
-            m[i] = b; d = b;
-        }
-        p[i] = fmaf(-lr, d, p[i]);
+    auto upd = [&](float pv, float gv, float mv, float& po, float& mo) {
+        float d = gv * gs;
+        if (wd != 0.f) d = fmaf(wd, pv, d);
+        if (mom != 0.f) { const float b = first ? d : fmaf(mom, mv, d); mo = b; d = b; }
+        po = fmaf(-lr, d, pv);
+    };
+    // 16-byte main loop when all three arrays allow it, scalar tail / fallback
+    const bool vec = !(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m) & 15);
+    const long n4 = vec ? n / 4 : 0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 pv = ((const f32x4*)p)[i], gv = ((const f32x4*)g)[i], mv = (mom != 0.f && !first) ? ((const f32x4*)m)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 po, mo = mv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { float a, b = mv[j]; upd(pv[j], gv[j], mv[j], a, b); po[j] = a; mo[j] = b; }
+        if (mom != 0.f) ((f32x4*)m)[i] = mo;
+        ((f32x4*)p)[i] = po;
+    }
+    for (long i = n4 * 4 + blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float a, b = (mom != 0.f && !first) ? m[i] : 0.f;
+        upd(p[i], g[i], b, a, b);
+        if (mom != 0.f) m[i] = b;
+        p[i] = a;
     }
 }
 
@@ -66,7 +80,10 @@ extern "C" {
 int saunet_sgd_step(const saunet_tensor_list* tl, const float* hyper, void* stream)
 {
     if (tl->count <= 0 || tl->count > 96) return set_error(SAUNET_BAD_SHAPE, "sgd: %d tensors", tl->count);
-    hipLaunchKernelGGL(sgd_kernel, dim3(128, tl->count), dim3(256), 0, (hipStream_t)stream, *tl, hyper);
+    long biggest = 1;
+    for (int t = 0; t < tl->count; ++t) if (tl->numel[t] > biggest) biggest = tl->numel[t];
+    long bx = (biggest / 4 + 511) / 512; if (bx > 2048) bx = 2048; if (bx < 1) bx = 1;      // ~2 vectors per thread for the largest tensor
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)bx, tl->count), dim3(256), 0, (hipStream_t)stream, *tl, hyper);
     SAUNET_CHECK_LAUNCH("sgd_step");
     return SAUNET_OK;
 }

@@ -452,9 +452,9 @@ def bn_backward(dy, x, p, relu, count, training, residual=None, dx=None, accumul
         L.call("saunet_bn_backward_reduce", dt, dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), rp, rl, p.scale.data_ptr(),
                p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), 1 if relu else 0, st.data_ptr(), st.shape[0], st.stride(0),
                P, c, L.stream())
-    # one tiny launch folds the replicas: every apply thread re-adding 16 copies costs far more than that launch
-    sums, sreps, srstr = collapse_stats(st), 1, 0
+    sums, sreps, srstr = st, st.shape[0], st.stride(0)       # the apply kernel adds the replicas itself (once per block, via LDS)
     if sync_group is not None and training:
+        sums, sreps, srstr = collapse_stats(st), 1, 0
         torch.distributed.all_reduce(sums, group=sync_group)
     if dx is None:
         dx = new_act(n, c, h, w, x.dtype, dev)
