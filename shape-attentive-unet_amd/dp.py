@@ -26,6 +26,9 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SAUNET_SHARE_GPU") == "1" and torch.cuda.is_available():
+        local %= torch.cuda.device_count()          # test rig: several ranks on one GPU (needs SAUNET_DIST_BACKEND=gloo)
+    backend = backend or os.environ.get("SAUNET_DIST_BACKEND") or None
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

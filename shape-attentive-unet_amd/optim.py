@@ -70,6 +70,19 @@ class _FusedBase(torch.optim.Optimizer):
             group["_hyper"] = h
         return h
 
+    def _upload(self, group, values):
+        """Hyper-parameters go to the device array with an ASYNCHRONOUS copy from pinned memory, and only when they changed:
+        a pageable-memory copy_ blocks the host until the stream has drained, i.e. once per step in eager mode."""
+        values = tuple(float(v) for v in values)
+        h = self._hyper(group)
+        if group.get("_hyper_vals") == values and group.get("_hyper_dev") == h.data_ptr():
+            return
+        host = torch.tensor(values, dtype=torch.float32)
+        if h.is_cuda:
+            host = host.pin_memory()          # the caching host allocator keeps the block alive until the copy has run
+        h.copy_(host, non_blocking=True)
+        group["_hyper_vals"], group["_hyper_dev"] = values, h.data_ptr()
+
     def _live(self, group):
         HF.WGRAD_SIDE.join()      # weight gradients are produced on a side stream
         ps = [p for p in group["params"] if p.grad is not None]
@@ -90,8 +103,7 @@ class FusedSGD(_FusedBase):
     def upload_hyper(self):
         for g in self.param_groups:
             first = 0.0 if g.get("_stepped", False) else 1.0
-            vals = torch.tensor([g["lr"], g["momentum"], g["weight_decay"], first, self.grad_scale, 0, 0, 0], dtype=torch.float32)
-            self._hyper(g).copy_(vals, non_blocking=False)
+            self._upload(g, [g["lr"], g["momentum"], g["weight_decay"], first, self.grad_scale, 0, 0, 0])
 
     @torch.no_grad()
     def step(self, closure=None, upload=True):
@@ -136,9 +148,7 @@ class FusedRAdam(_FusedBase):
             step = g.get("_step", 0) + 1
             b1, b2 = g["betas"]
             n_sma, step_size = self.schedule(step, g["lr"], b1, b2)
-            vals = torch.tensor([b1, b2, g["eps"], g["weight_decay"] * g["lr"], step_size, 1.0 if n_sma >= 5 else 0.0,
-                                 self.grad_scale, 0], dtype=torch.float32)
-            self._hyper(g).copy_(vals, non_blocking=False)
+            self._upload(g, [b1, b2, g["eps"], g["weight_decay"] * g["lr"], step_size, 1.0 if n_sma >= 5 else 0.0, self.grad_scale, 0])
 
     @torch.no_grad()
     def step(self, closure=None, upload=True):
