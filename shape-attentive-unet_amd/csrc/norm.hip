@@ -74,6 +74,22 @@ __global__ void sum_replicas_kernel(double* __restrict__ base, int n, int reps, 
     base[i] = s;
 }
 
+// sum over the replicated accumulators (saunet_bn_epilogue.sums_replicas): 8 loads in flight at a time -- these kernels are
+// pure latency chains (one thread per channel), a one-load-per-iteration loop costs 16 memory round trips
+__device__ __forceinline__ double rep_sum(const double* __restrict__ s, int reps, int rstride, int i)
+{
+    double v = 0.0;
+    int r = 0;
+    for (; r + 8 <= reps; r += 8) {
+        double t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = s[(size_t)(r + j) * rstride + i];
+        v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    for (; r < reps; ++r) v += s[(size_t)r * rstride + i];
+    return v;
+}
+
 __global__ void bn_finalize_kernel(int C, const double* __restrict__ sum, const double* __restrict__ sq, int reps, int rstride, double count,
                                    const float* __restrict__ cbias, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
@@ -84,8 +100,7 @@ __global__ void bn_finalize_kernel(int C, const double* __restrict__ sum, const 
     if (c >= C) return;
     float mean, invstd;
     if (training) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int r = 0; r < reps; ++r) { s1 += sum[(size_t)r * rstride + c]; s2 += sq[(size_t)r * rstride + c]; }
+        const double s1 = rep_sum(sum, reps, rstride, c), s2 = rep_sum(sq, reps, rstride, c);
         double m = s1 / count;
         double var = s2 / count - m * m;
         if (var < 0.0) var = 0.0;
@@ -197,14 +212,6 @@ template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_reduc
     __syncthreads();
     const size_t ro = (size_t)(blockIdx.x % a.sreps) * a.srstride;
     for (int c = threadIdx.x; c < 2 * a.C; c += 256) atomicAdd(&a.sums[ro + c], s_red[c]);
-}
-
-// sum over the replicated accumulators (saunet_bn_epilogue.sums_replicas)
-__device__ __forceinline__ double rep_sum(const double* __restrict__ s, int reps, int rstride, int i)
-{
-    double v = 0.0;
-    for (int r = 0; r < reps; ++r) v += s[(size_t)r * rstride + i];
-    return v;
 }
 
 template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a)
