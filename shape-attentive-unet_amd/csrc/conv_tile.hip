@@ -622,7 +622,7 @@ template <typename T> static int dispatch_res_fwd(const TileArgs& a, hipStream_t
     const int bn = a.Cout <= 32 ? 32 : (a.Cout <= 64 ? 64 : 128);
     const long halo_b = (long)NPIX * pitch, epi_b = 256L * bn * sizeof(T);
     long lds = (halo_b > epi_b ? halo_b : epi_b) + (long)ncb * 9 * bn * pitch + 2 * bn * 4;
-    *handled = lds <= 154 * 1024 && (a.tiles_x * a.tiles_y * a.N) >= 256;
+    *handled = lds <= 154 * 1024 && (a.tiles_x * a.tiles_y * a.N) >= 32;   // even at one tile per block a single bulk weight load beats nine dependent per-tap loads
     if (!*handled) return SAUNET_OK;
 #define RES(BN_, WM_, WN_, CPR_) (a.epi.bn_x ? launch_res_fwd_i<T, BN_, WM_, WN_, CPR_, true>(a, st) : launch_res_fwd_i<T, BN_, WM_, WN_, CPR_, false>(a, st))
     if (bn == 32) return narrow ? RES(32, 64, 32, 4) : RES(32, 64, 32, 8);
