@@ -99,15 +99,13 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgra
     const int nsteps = (GCP + 63) / 64;                  // 64-channel steps in the group
 
     // x / y pieces of one 64-channel step: piece i (tile t = i >> 1, run r = i & 1) = channels step*64 + 32t + 16r + 8*lh .. +8
-    struct XY { u32x4 x[4], y[4]; };
-    auto request = [&](size_t pp, int step, XY& o) {
+    struct XP { u32x4 x[4]; };
+    auto request_x = [&](size_t pp, int step, XP& o) {
         const u16* xr = a.x + pp * a.ldx + g0 + step * 64 + 8 * lh;
-        const u16* yr = a.y + pp * a.ldy + g0 + step * 64 + 8 * lh;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = step * 64 + 16 * i + 8 * lh < GC;
             o.x[i] = ok ? *(const u32x4*)(xr + 16 * i) : u32x4{0u, 0u, 0u, 0u};
-            o.y[i] = (ok && a.accumulate) ? *(const u32x4*)(yr + 16 * i) : u32x4{0u, 0u, 0u, 0u};
         }
     };
     for (unsigned tp = blockIdx.x * DG_WAVES + wave; tp < ntp; tp += stride) {
@@ -120,11 +118,17 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgra
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) gf[ks] = live ? *(const u32x4*)(grow + ks * 16) : u32x4{0u, 0u, 0u, 0u};
         }
-        XY cur, nxt;
-        request(pp, 0, cur);
+        XP cur, nxt;                  // x (needed first, for the mask) is requested one step ahead; y at the start of its own step
+        request_x(pp, 0, cur);
         u16* yrow = a.y + pp * a.ldy + g0 + 8 * lh;
         for (int step = 0; step < nsteps; ++step) {
-            if (step + 1 < nsteps) request(pp, step + 1, nxt);
+            u32x4 yv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = a.accumulate && step * 64 + 16 * i + 8 * lh < GC;
+                yv[i] = ok ? *(const u32x4*)(yrow + step * 64 + 16 * i) : u32x4{0u, 0u, 0u, 0u};
+            }
+            if (step + 1 < nsteps) request_x(pp, step + 1, nxt);
             u32x4 outv[4];          // the step's four 16-byte output pieces leave together: the L2 sees whole 128-byte lines
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgra
                     const int cl = ct + 16 * r + 8 * lh;
                     const bool ok = live && cl < GC;
                     float xf[8], yf[8], o[8];
-                    Vec16<u16>::unpack(cur.x[2 * t + r], xf); Vec16<u16>::unpack(cur.y[2 * t + r], yf);
+                    Vec16<u16>::unpack(cur.x[2 * t + r], xf); Vec16<u16>::unpack(yv[2 * t + r], yf);
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const f32x4 sc = *(const f32x4*)(s_par + cl + 4 * h), sh = *(const f32x4*)(s_par + GCP + cl + 4 * h);
