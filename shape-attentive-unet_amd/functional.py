@@ -281,6 +281,7 @@ class SideStream:
 
     def __init__(self):
         self.enabled = os.environ.get("SAUNET_WGRAD_SIDE_STREAM", "0") == "1"   # measured neutral on MI355X: off by default
+        self.max_pixels = int(os.environ.get("SAUNET_WGRAD_SIDE_MAXPIX", "0"))  # > 0: only launches with at most this many pixels
         self.streams = {}
         self.dirty = False
 
@@ -322,7 +323,8 @@ class _ShapeOnly:
 
 def conv_wgrad_raw(x, dy, weight, stride, pad, transposed=False, pro=None):
     x = nhwc(x); dy = nhwc(dy)
-    if WGRAD_SIDE.enabled and x.is_cuda and isinstance(weight, torch.nn.Parameter):   # leaf weights only: nothing in the
+    if (WGRAD_SIDE.enabled and x.is_cuda and isinstance(weight, torch.nn.Parameter)   # leaf weights only: nothing in the
+            and (WGRAD_SIDE.max_pixels <= 0 or x.shape[0] * x.shape[2] * x.shape[3] <= WGRAD_SIDE.max_pixels)):
         main = torch.cuda.current_stream(x.device)                                     # autograd graph reads their gradient
         side = WGRAD_SIDE.get(x.device)
         side.wait_stream(main)
@@ -453,8 +455,12 @@ def bn_backward(dy, x, p, relu, count, training, residual=None, dx=None, accumul
                p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), 1 if relu else 0, st.data_ptr(), st.shape[0], st.stride(0),
                P, c, L.stream())
     sums, sreps, srstr = st, st.shape[0], st.stride(0)       # the apply kernel adds the replicas itself (once per block, via LDS)
+    local = None
     if sync_group is not None and training:
         sums, sreps, srstr = collapse_stats(st), 1, 0
+        # dx needs the GLOBAL sums (the shared statistics couple the ranks); dgamma / dbeta are gradients of the LOCAL loss and
+        # are averaged with all other parameter gradients afterwards, so they must come from the local sums
+        local = sums.clone()
         torch.distributed.all_reduce(sums, group=sync_group)
     if dx is None:
         dx = new_act(n, c, h, w, x.dtype, dev)
@@ -464,6 +470,8 @@ def bn_backward(dy, x, p, relu, count, training, residual=None, dx=None, accumul
            p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), 1 if relu else 0, sums.data_ptr(), sreps, srstr, float(count),
            1 if training else 0, 1 if accumulate else 0, dx.data_ptr(), ld_of(dx), L.ptr(dres),
            ld_of(dres) if dres is not None else 0, dgb[0].data_ptr(), dgb[1].data_ptr(), P, c, L.stream())
+    if local is not None:
+        return dx, dres, local[c:].float(), local[:c].float()
     return dx, dres, dgb[0], dgb[1]
 
 
