@@ -107,6 +107,33 @@ def test_other_shapes_against_oracle(B, H, W, seed):
         assert err < 1e-3 * gmax, (k, err, gmax)
 
 
+def test_fix_bn_training_step_against_oracle():
+    """train.py --fix_bn (train.py:85 `segmentation_module.train(not args.fix_bn)`): BatchNorm in eval mode (running statistics, no
+    batch terms in its backward) while gradients flow -- loss and every parameter gradient against the oracle."""
+    seed = 21
+    S, spec, sd, net, sm = make_net(seed)
+    img, seg, edge = Wt.synthetic_batch(2, 64, 96, seed=140)
+    sdo = {k: v.clone() for k, v in sd.items()}
+    keys = Wt.trainable_keys(spec)
+    for k in keys:
+        sdo[k].requires_grad_(True)
+    loss_o, acc_o, lg_o, eo_o = R.segmentation_step(sdo, img, seg, edge, False)
+    loss_o.backward()
+    sm.eval()
+    loss, (acc, jac) = sm({"image": img.cuda(), "mask": (seg.cuda(), edge.cuda())}, 1)
+    loss.backward()
+    assert abs(float(loss) - float(loss_o)) < 1e-4 * max(1.0, float(loss_o))
+    pd = dict(net.named_parameters())
+    gmax = max(float(sdo[k].grad.abs().max()) for k in keys)
+    for k in keys:
+        err = float((pd[k].grad.cpu() - sdo[k].grad).abs().max())
+        assert err < 1e-3 * gmax, (k, err, gmax)
+    # running statistics untouched
+    for k, v in net.state_dict().items():
+        if k.endswith("running_mean") and "_tmp" not in k and k in sd:
+            assert torch.equal(v.cpu(), sd[k]), k
+
+
 def test_bf16_storage_tracks_fp32_oracle():
     """bf16 activations/weights, fp32 accumulate/statistics/loss: loss within 2% and Dice-style metrics close."""
     seed = 3
