@@ -134,6 +134,22 @@ def test_fix_bn_training_step_against_oracle():
             assert torch.equal(v.cpu(), sd[k]), k
 
 
+def test_attention_maps_branch_against_oracle():
+    """SegmentationModule test branch (segSize=True, models/models.py:96-103): softmax + the 7 attention / gate maps."""
+    S, spec, sd, net, sm = make_net(17)
+    img, seg, edge = Wt.synthetic_batch(2, 64, 64, seed=41)
+    sm.eval()
+    with torch.no_grad():
+        pred, maps = sm({"image": img.cuda(), "mask": (seg.cuda(), edge.cuda())}, epoch=0, segSize=True)
+        lg_o, eo_o, maps_o = R.saunet_forward({k: v.clone() for k, v in sd.items()}, img, False, return_att=True)
+    assert len(maps) == 7 and len(maps_o) == 7
+    ref = torch.softmax(lg_o, 1)
+    assert float((pred.float().cpu() - ref).abs().max()) < 1e-4
+    for i, (m, mo) in enumerate(zip(maps, maps_o)):
+        assert tuple(m.shape) == tuple(mo.shape) == (2, 1, 64, 64), (i, m.shape, mo.shape)
+        assert float((m.float().cpu() - mo).abs().max()) < 1e-4 * max(1.0, float(mo.abs().max())), i
+
+
 def test_bf16_storage_tracks_fp32_oracle():
     """bf16 activations/weights, fp32 accumulate/statistics/loss: loss within 2% and Dice-style metrics close."""
     seed = 3
