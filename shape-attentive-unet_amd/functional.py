@@ -858,6 +858,8 @@ class _ExpandBNAct(torch.autograd.Function):
     def forward(ctx, a, w, b, gamma, beta, rmean, rvar, momentum, eps, training, relu, out_dtype):
         a = nhwc(a)
         _check_dev(a)
+        if not a.is_contiguous():          # the kernels index the one-channel map as a dense [P] vector
+            a = a.contiguous()
         n, _, h, wd = a.shape
         P, dev, c = n * h * wd, a.device, w.shape[0]
         stats = bn_stats(a) if training else None
