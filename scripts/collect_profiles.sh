@@ -7,6 +7,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/round_prof
 rm -rf $O; mkdir -p $O
+[ -x $R/scripts/probes/rowpiece_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/scripts/probes/rowpiece_probe.hip -o $R/scripts/probes/rowpiece_probe
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/rf_stats -o p -- python $R/bench.py --roofline-only > $O/rf_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/rf_fetch -o p -- python $R/bench.py --roofline-only > $O/rf_fetch.log 2>&1
