@@ -317,7 +317,11 @@ template <typename T> static int dispatch_tile_fwd(const TileArgs& a, hipStream_
     constexpr int EPC = 16 / sizeof(T);
     const bool narrow = a.Cin <= 4 * EPC;
     if (a.Cout <= 32) return narrow ? launch_tile_fwd<T, 32, 64, 32, 4>(a, st) : launch_tile_fwd<T, 32, 64, 32, 8>(a, st);
-    if (a.Cout <= 64) return narrow ? launch_tile_fwd<T, 64, 64, 64, 4>(a, st) : launch_tile_fwd<T, 64, 64, 64, 8>(a, st);
+    // low-resolution maps with many channels (center, dec5: 32 pixel tiles): 64-channel output tiles double the number of
+    // workgroups instead of leaving half of the CUs idle; the halo re-reads come from the L2
+    const long blocks128 = (long)a.tiles_x * a.tiles_y * a.N * ((a.Cout + 127) / 128);
+    if (a.Cout <= 64 || (blocks128 < 256 && !a.epi.bn_x))
+        return narrow ? launch_tile_fwd<T, 64, 64, 64, 4>(a, st) : launch_tile_fwd<T, 64, 64, 64, 8>(a, st);
     return narrow ? launch_tile_fwd<T, 128, 128, 64, 4>(a, st) : launch_tile_fwd<T, 128, 128, 64, 8>(a, st);
 }
 
