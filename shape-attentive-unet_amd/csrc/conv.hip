@@ -91,7 +91,7 @@ template <typename T> __global__ void pack_weight_multi_kernel(saunet_pack_list 
 struct PwArgs {
     const void* x; const void* w; void* y; const float* bias; const float* ps; const float* psh;
     double* ssum; double* ssq;
-    long P; int Cin, Cout, ldx, ldy, pro_relu; int srep, srstride; int vec_out;
+    long P; int Cin, Cout, ldx, ldy, pro_relu; int srep, srstride; int vec_out, vec_in;
 };
 
 // Each block owns ITEMS = 256*PW_IT consecutive (pixel, cout) items; thread t handles items t, t+256, ...
@@ -171,9 +171,22 @@ template <typename T, int CIN_PAD> __global__ __launch_bounds__(256) void pointw
         const bool live = p < a.P;
         float xv[CIN_PAD];
         const T* xr = (const T*)a.x + (live ? p : 0) * a.ldx;
+        constexpr int EPI = 16 / sizeof(T);
+        if (a.vec_in) {             // Cin % EPI == 0 and 16-byte aligned rows: whole vectors instead of element loads
+#pragma unroll
+            for (int c0 = 0; c0 < CIN_PAD; c0 += EPI) {
+                float f[EPI];
+                if (c0 < a.Cin) Vec16<T>::unpack(*(const u32x4*)(xr + c0), f);
+#pragma unroll
+                for (int j = 0; j < EPI; ++j) if (c0 + j < CIN_PAD) xv[c0 + j] = (c0 < a.Cin) ? f[j] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CIN_PAD; ++c) xv[c] = (c < a.Cin) ? Elem<T>::load(xr + c) : 0.f;
+        }
 #pragma unroll
         for (int c = 0; c < CIN_PAD; ++c) {
-            float v = (c < a.Cin) ? Elem<T>::load(xr + c) : 0.f;
+            float v = xv[c];
             if (has_pro) v = fmaxf(fmaf(v, sps[c], sps[CIN_PAD + c]), relu_lo);
             xv[c] = (c < a.Cin) ? v : 0.f;
         }
@@ -499,10 +512,11 @@ int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const voi
     if (!is_pointwise(d)) return set_error(SAUNET_UNSUPPORTED, "conv: %dx%d s%d Cin=%d Cout=%d has no kernel", d->KH, d->KW, d->stride, d->Cin, d->Cout);
     if (ssum != nullptr && d->Cout > 64) return set_error(SAUNET_UNSUPPORTED, "pointwise stats need Cout <= 64");
     PwArgs a{x, w, y, bias, ps, psh, ssum, ssq, (long)d->N * d->H * d->W, d->Cin, d->Cout, d->ldx, d->ldy, d->pro_relu,
-             d->stat_replicas > 1 ? d->stat_replicas : 1, d->stat_rstride, 0};
+             d->stat_replicas > 1 ? d->stat_replicas : 1, d->stat_rstride, 0, 0};
     {
         const int epc = d->dtype == SAUNET_BF16 ? 8 : 4;
         a.vec_out = d->Cout % epc == 0 && d->ldy % epc == 0 && !((uintptr_t)y & 15);
+        a.vec_in = d->Cin % epc == 0 && d->ldx % epc == 0 && !((uintptr_t)x & 15);
     }
     if (d->Cin <= 64 && d->Cout <= 64) {
         const int cpad = d->Cin <= 4 ? 4 : d->Cin <= 8 ? 8 : d->Cin <= 16 ? 16 : d->Cin <= 36 ? 36 : 64;
