@@ -309,6 +309,7 @@ class SideStream:
 
 
 WGRAD_SIDE = SideStream()
+DENSE_WGRAD_DEFER = os.environ.get("SAUNET_DENSE_WGRAD_DEFER", "")
 
 
 class _ShapeOnly:
@@ -1141,6 +1142,12 @@ class _DenseBlock(torch.autograd.Function):
                        AB[1, lo:hi].data_ptr(), xh[0, lo:hi].data_ptr(), xh[1, lo:hi].data_ptr(), P, hi - lo, L.stream())
 
         grads = [None] * (6 * nl)
+        # Eager execution (no hipGraph capture; the N > 1 data-parallel default): the weight gradients of the whole block are issued
+        # AFTER its data-gradient chain, on the side stream -- two long independent branches with one fork / join per block, so the
+        # small launches of the low-resolution blocks overlap (measured 38.3 -> 36.6 ms/step eager).  A captured graph replays its
+        # branches serially on this ROCm, so during capture the kernels stay interleaved on one stream.  SAUNET_DENSE_WGRAD_DEFER=0/1 forces.
+        defer = buf.is_cuda and (DENSE_WGRAD_DEFER == "1" or (DENSE_WGRAD_DEFER != "0" and not torch.cuda.is_current_stream_capturing()))
+        deferred = []
         for l in reversed(range(nl)):
             n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
             z1, p1b, p2b = saved[3 * l:3 * l + 3]
@@ -1150,17 +1157,34 @@ class _DenseBlock(torch.autograd.Function):
             xin = buf[:, :cin]
             correct(cin, cin + growth)
             dz2 = dbuf[:, cin:cin + growth]
-            dw2 = conv_wgrad_raw(z1, dz2, c2w, 1, 1, pro=(p2.scale, p2.shift, True))
+            if not defer:
+                dw2 = conv_wgrad_raw(z1, dz2, c2w, 1, 1, pro=(p2.scale, p2.shift, True))
             s2 = new_stats(z1.shape[1], dev)
             da2 = conv_dgrad_raw(dz2, c2w, z1.shape, 1, 1, bn_epi=(z1, p2, True, s2))
             dz1, _, dg2, db2 = bn_backward(da2, z1, p2, True, count, training, dx=da2, presums=s2)
-            dw1 = conv_wgrad_raw(xin, dz1, c1w, 1, 0, pro=(p1.scale, p1.shift, True))
+            if not defer:
+                dw1 = conv_wgrad_raw(xin, dz1, c1w, 1, 0, pro=(p1.scale, p1.shift, True))
+            else:
+                dw1 = dw2 = None
+                deferred.append((l, z1, dz2, dz1, xin, p1, p2, c1w, c2w))
             s1 = new_stats(cin, dev)
             conv_dgrad_raw(dz1, c1w, (n, cin, h, w), 1, 0, out=dbuf[:, :cin], bn_epi=(xin, p1, True, s1, True))
             dgb = torch.empty(2, cin, dtype=torch.float32, device=dev)
             L.call("saunet_bn_backward_coeff", cin, s1.data_ptr(), s1.shape[0], s1.stride(0), float(count), p1.scale.data_ptr(), AB[0].data_ptr(), AB[1].data_ptr(),
                    dgb[0].data_ptr(), dgb[1].data_ptr(), 1 if training else 0, L.stream())
             grads[6 * l:6 * l + 6] = [dgb[0], dgb[1], dw1, dg2, db2, dw2]
+        if defer:
+            main = torch.cuda.current_stream(dev)
+            side = WGRAD_SIDE.get(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for (l, z1, dz2, dz1, xin, p1, p2, c1w, c2w) in deferred:
+                    grads[6 * l + 5] = _conv_wgrad_impl(z1, dz2, c2w, 1, 1, pro=(p2.scale, p2.shift, True))
+                    grads[6 * l + 2] = _conv_wgrad_impl(xin, dz1, c1w, 1, 0, pro=(p1.scale, p1.shift, True))
+                    for t in (z1, dz1, grads[6 * l + 5], grads[6 * l + 2], p1.buf, p2.buf):
+                        t.record_stream(side)
+            buf.record_stream(side); dbuf.record_stream(side)
+            WGRAD_SIDE.mark()
         correct(0, c0)
         dx0 = dbuf[:, :c0] if ctx.needs_input_grad[0] else None
         return (dx0, None, None) + tuple(grads) + (None,) * (4 * nl)
