@@ -1,0 +1,32 @@
+"""Does a captured hipGraph run independent branches concurrently on this ROCm?  Two chains of small kernels (each far from filling
+256 CUs): one stream / two streams eager / two streams captured."""
+import torch, time
+torch.cuda.init()
+n = 1 << 16                                  # 64K elements: 64 workgroups of 1024 -> quarter of the CUs
+a = torch.randn(n, device="cuda"); b = torch.randn(n, device="cuda")
+def chain(x, k=300):
+    for _ in range(k):
+        x = torch.sin(x) * 1.0001            # two tiny kernels per iteration
+    return x
+def two_streams():
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    s1.wait_stream(cur); s2.wait_stream(cur)
+    with torch.cuda.stream(s1): r1 = chain(a)
+    with torch.cuda.stream(s2): r2 = chain(b)
+    cur.wait_stream(s1); cur.wait_stream(s2)
+    return r1, r2
+def timeit(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize()
+    return (time.time() - t) / reps * 1e3
+print("one stream, eager      : %.2f ms" % timeit(lambda: (chain(a), chain(b))))
+print("two streams, eager     : %.2f ms" % timeit(two_streams))
+g1 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g1): chain(a); chain(b)
+print("one stream, graph      : %.2f ms" % timeit(g1.replay))
+g2 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g2): two_streams()
+print("two branches, graph    : %.2f ms" % timeit(g2.replay))
