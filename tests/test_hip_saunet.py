@@ -167,6 +167,33 @@ def test_bf16_storage_tracks_fp32_oracle():
         S.set_compute_dtype(torch.float32)
 
 
+def test_bf16_training_tracks_fp32_training():
+    """40 fused-SGD steps on one fixed batch in bf16 storage (fused gate / expand / dense-block kernels) against the same run
+    in float32 storage: both must fit the batch, and the loss curves must stay close (they are not bit-comparable: bf16
+    rounding flips ReLU masks, see tests/test_hip_dense.py)."""
+    curves = {}
+    for dt in (torch.float32, torch.bfloat16):
+        S, spec, sd, net, sm = make_net(29, dt)
+        try:
+            img, seg, edge = Wt.synthetic_batch(4, 128, 128, seed=77)
+            feed = {"image": img.cuda(), "mask": (seg.cuda(), edge.cuda())}
+            opt = S.optim.create_optimizers(net, "sgd", lr=2e-3, momentum=0.9, weight_decay=1e-4)[0]
+            sm.train()
+            c = []
+            for it in range(40):
+                sm.zero_grad(set_to_none=True)
+                loss, _ = sm(feed, 1)
+                loss.backward(); opt.step(); c.append(float(loss))
+            curves[dt] = c
+        finally:
+            S.set_compute_dtype(torch.float32)
+    f, b = np.array(curves[torch.float32]), np.array(curves[torch.bfloat16])
+    assert np.isfinite(b).all()
+    assert f[-1] < 0.6 * f[0] and b[-1] < 0.6 * b[0], (f[0], f[-1], b[0], b[-1])
+    assert abs(b[0] - f[0]) < 0.02 * f[0]
+    assert np.abs(b - f).max() < 0.12 * f[0], (list(f[::8]), list(b[::8]))
+
+
 def test_properties_at_bench_size():
     """256x256 (BASELINE config 2 geometry, small batch): size-independent checks."""
     S, spec, sd, net, sm = make_net(11)
