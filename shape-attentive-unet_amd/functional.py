@@ -1142,11 +1142,12 @@ class _DenseBlock(torch.autograd.Function):
                        AB[1, lo:hi].data_ptr(), xh[0, lo:hi].data_ptr(), xh[1, lo:hi].data_ptr(), P, hi - lo, L.stream())
 
         grads = [None] * (6 * nl)
-        # Eager execution (no hipGraph capture; the N > 1 data-parallel default): the weight gradients of the whole block are issued
-        # AFTER its data-gradient chain, on the side stream -- two long independent branches with one fork / join per block, so the
-        # small launches of the low-resolution blocks overlap (measured 38.3 -> 36.6 ms/step eager).  A captured graph replays its
-        # branches serially on this ROCm, so during capture the kernels stay interleaved on one stream.  SAUNET_DENSE_WGRAD_DEFER=0/1 forces.
-        defer = buf.is_cuda and (DENSE_WGRAD_DEFER == "1" or (DENSE_WGRAD_DEFER != "0" and not torch.cuda.is_current_stream_capturing()))
+        # SAUNET_DENSE_WGRAD_DEFER=1 (opt-in): the weight gradients of the whole block are issued AFTER its data-gradient chain, on
+        # the side stream -- two long independent branches with one fork / join per block, so the small launches of the low-resolution
+        # blocks overlap: 38.3 -> 36.9 ms/step in single-process eager mode.  Off by default: a captured graph replays its branches
+        # serially on this ROCm (no gain), and two ranks sharing one GPU (the gloo test rig) ran 6x SLOWER with the extra compute
+        # queue per process, which could not be re-checked against RCCL with one GPU per rank.
+        defer = buf.is_cuda and DENSE_WGRAD_DEFER == "1" and not torch.cuda.is_current_stream_capturing()
         deferred = []
         for l in reversed(range(nl)):
             n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
