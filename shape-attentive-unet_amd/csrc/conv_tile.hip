@@ -629,8 +629,9 @@ template <typename T> static int dispatch_res_fwd(const TileArgs& a, hipStream_t
     *handled = lds <= 154 * 1024 && (a.tiles_x * a.tiles_y * a.N) >= 32;   // even at one tile per block a single bulk weight load beats nine dependent per-tap loads
     if (!*handled) return SAUNET_OK;
 #define RES(BN_, WM_, WN_, CPR_) (a.epi.bn_x ? launch_res_fwd_i<T, BN_, WM_, WN_, CPR_, true>(a, st) : launch_res_fwd_i<T, BN_, WM_, WN_, CPR_, false>(a, st))
-    if (bn == 32) return narrow ? RES(32, 64, 32, 4) : RES(32, 64, 32, 8);
-    if (bn == 64) return narrow ? RES(64, 64, 64, 4) : RES(64, 64, 64, 8);
+    // 8 waves per block (one resident block per CU: the weights + one halo fill the LDS): twice the waves to hide the halo latency
+    if (bn == 32) return narrow ? RES(32, 64, 32, 4) : RES(32, 32, 32, 8);
+    if (bn == 64) return narrow ? RES(64, 64, 64, 4) : RES(64, 64, 32, 8);
     return narrow ? RES(128, 128, 64, 4) : RES(128, 128, 64, 8);
 #undef RES
 }
