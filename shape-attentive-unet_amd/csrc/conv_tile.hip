@@ -900,6 +900,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 static int tile_wgrad_groups(int ntiles, int nchan_tiles)
 {
     int groups = 512 / nchan_tiles; if (groups < 1) groups = 1; if (groups > ntiles) groups = ntiles;
+    // every group writes a full partial gradient: on small maps (few pixel tiles) let a block take at least two tiles as long as
+    // 256 blocks remain
+    if (groups > ntiles / 2 && (ntiles / 2) * nchan_tiles >= 256) groups = ntiles / 2;
     return groups;
 }
 
