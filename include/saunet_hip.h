@@ -47,6 +47,7 @@ typedef struct saunet_conv_desc {
      * base + replica*stat_rstride (elements).  Thousands of workgroups hitting the same 2*C float64 addresses serialise
      * in the cross-XCD atomic path (+40 us on a 4096-block launch); 16 replicas remove that.  0/1 = single copy. */
     int32_t stat_replicas, stat_rstride;
+    int32_t epi_relu;              /* epilogue: y = max(conv + bias, 0) -- inference with BatchNorm folded into weights and bias */
 } saunet_conv_desc;
 
 const char* saunet_last_error(void);

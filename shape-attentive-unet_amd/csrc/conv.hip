@@ -91,7 +91,7 @@ template <typename T> __global__ void pack_weight_multi_kernel(saunet_pack_list 
 struct PwArgs {
     const void* x; const void* w; void* y; const float* bias; const float* ps; const float* psh;
     double* ssum; double* ssq;
-    long P; int Cin, Cout, ldx, ldy, pro_relu; int srep, srstride; int vec_out, vec_in;
+    long P; int Cin, Cout, ldx, ldy, pro_relu; int srep, srstride; int vec_out, vec_in, act_relu;
 };
 
 // Each block owns ITEMS = 256*PW_IT consecutive (pixel, cout) items; thread t handles items t, t+256, ...
@@ -129,7 +129,7 @@ template <typename T> __global__ __launch_bounds__(256) void pointwise_fwd_kerne
             if (fixed_co) { rs += acc; rq = fmaf(acc, acc, rq); co_last = co; }
             else { atomicAdd(&s_sum[co], acc); atomicAdd(&s_sq[co], acc * acc); }
         }
-        Elem<T>::store((T*)a.y + p * a.ldy + co, acc + (a.bias ? a.bias[co] : 0.f));
+        { const float o = acc + (a.bias ? a.bias[co] : 0.f); Elem<T>::store((T*)a.y + p * a.ldy + co, a.act_relu ? fmaxf(o, 0.f) : o); }
     }
     if (stats) {
         if (fixed_co) { atomicAdd(&s_sum[co_last], rs); atomicAdd(&s_sq[co_last], rq); }
@@ -205,7 +205,7 @@ template <typename T, int CIN_PAD> __global__ __launch_bounds__(256) void pointw
                 float s = wave_sum(v), q = wave_sum(v * v);
                 if (lane == 0) { atomicAdd(&ssum[co], s); atomicAdd(&ssum[a.Cout + co], q); }
             }
-            return acc + sb[co];
+            return a.act_relu ? fmaxf(acc + sb[co], 0.f) : acc + sb[co];
         };
         constexpr int EPC = 16 / sizeof(T);
         if (a.vec_out) {            // Cout % EPC == 0, 16-byte aligned output rows: one vector store per EPC channels
@@ -249,7 +249,7 @@ template <typename T> __global__ __launch_bounds__(256) void pointwise_dot_kerne
             acc = fmaf(v, Elem<T>::load(wr + c), acc);
         }
         acc = wave_sum(acc);
-        if (lane == 0) Elem<T>::store((T*)a.y + p * a.ldy + co, acc + (a.bias ? a.bias[co] : 0.f));
+        if (lane == 0) { const float o = acc + (a.bias ? a.bias[co] : 0.f); Elem<T>::store((T*)a.y + p * a.ldy + co, a.act_relu ? fmaxf(o, 0.f) : o); }
     }
 }
 
@@ -262,7 +262,7 @@ template <typename T> __global__ __launch_bounds__(256) void pointwise_cin1_kern
         const unsigned p = i / (unsigned)a.Cout, co = i - p * (unsigned)a.Cout;
         float v = Elem<T>::load((const T*)a.x + (size_t)p * a.ldx);
         if (a.ps) v = fmaxf(fmaf(v, a.ps[0], a.psh[0]), relu_lo);
-        Elem<T>::store((T*)a.y + (size_t)p * a.ldy + co, fmaf(v, Elem<T>::load((const T*)a.w + co), a.bias ? a.bias[co] : 0.f));
+        { const float o = fmaf(v, Elem<T>::load((const T*)a.w + co), a.bias ? a.bias[co] : 0.f); Elem<T>::store((T*)a.y + (size_t)p * a.ldy + co, a.act_relu ? fmaxf(o, 0.f) : o); }
     }
 }
 
@@ -512,7 +512,7 @@ int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const voi
     if (!is_pointwise(d)) return set_error(SAUNET_UNSUPPORTED, "conv: %dx%d s%d Cin=%d Cout=%d has no kernel", d->KH, d->KW, d->stride, d->Cin, d->Cout);
     if (ssum != nullptr && d->Cout > 64) return set_error(SAUNET_UNSUPPORTED, "pointwise stats need Cout <= 64");
     PwArgs a{x, w, y, bias, ps, psh, ssum, ssq, (long)d->N * d->H * d->W, d->Cin, d->Cout, d->ldx, d->ldy, d->pro_relu,
-             d->stat_replicas > 1 ? d->stat_replicas : 1, d->stat_rstride, 0, 0};
+             d->stat_replicas > 1 ? d->stat_replicas : 1, d->stat_rstride, 0, 0, d->epi_relu};
     {
         const int epc = d->dtype == SAUNET_BF16 ? 8 : 4;
         a.vec_out = d->Cout % epc == 0 && d->ldy % epc == 0 && !((uintptr_t)y & 15);

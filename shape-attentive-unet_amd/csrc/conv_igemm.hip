@@ -23,7 +23,7 @@ struct IgemmArgs {
     int N, H, W, Cin, ldx;
     int Ho, Wo, Cout, ldy;
     int KH, KW, stride, pad;
-    int transposed, pro_relu;
+    int transposed, pro_relu, act_relu;
     int M;            // GEMM rows per launch (per phase when transposed)
     int Mh, Mw;       // row decode: m -> (n, q, r) with q < Mh, r < Mw
     int kpt;          // K-steps per tap = ceil(Cin / KC)
@@ -230,7 +230,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void conv_igemm_fwd_
                 float v = acc[i][j][r];
                 s += v; ss += v * v;
                 int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                Elem<T>::store(so + row * BN + col, v + bv);
+                Elem<T>::store(so + row * BN + col, a.act_relu ? fmaxf(v + bv, 0.f) : v + bv);
             }
         if (do_stats) {
             s += __shfl_xor(s, 32, 64); ss += __shfl_xor(ss, 32, 64);
@@ -381,7 +381,7 @@ int igemm_forward(const saunet_conv_desc* d, const void* x, const void* w, const
     a.stat_replicas = d->stat_replicas > 1 ? d->stat_replicas : 1; a.stat_rstride = d->stat_rstride;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
     a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.ldy = d->ldy;
-    a.stride = d->stride; a.pad = d->pad; a.transposed = d->transposed; a.pro_relu = d->pro_relu;
+    a.stride = d->stride; a.pad = d->pad; a.transposed = d->transposed; a.pro_relu = d->pro_relu; a.act_relu = d->epi_relu;
     int phases = 1;
     if (d->transposed) {
         if (d->KH != 4 || d->KW != 4 || d->stride != 2 || d->pad != 1 || d->Ho != 2 * d->H || d->Wo != 2 * d->W)

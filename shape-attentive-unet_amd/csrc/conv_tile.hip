@@ -19,7 +19,7 @@ struct TileArgs {
     const float* bias; const float* pro_scale; const float* pro_shift;
     double* stat_sum; double* stat_sumsq; int stat_replicas, stat_rstride;
     int N, H, W, Cin, ldx, Cout, ldy;
-    int pro_relu;
+    int pro_relu, act_relu;
     int tiles_x, tiles_y;   // H/16, W/16
     saunet_bn_epilogue epi;
     int lds_acc_off;        // resident kernel: byte offset of the block-lifetime accumulators in LDS
@@ -211,7 +211,7 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64, BNEPI ? 1 : 2) void co
                 float v = acc[i][j][r];
                 s += v; ss += v * v;
                 int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                Elem<T>::store(so + row * BN + col, v + bv);
+                Elem<T>::store(so + row * BN + col, a.act_relu ? fmaxf(v + bv, 0.f) : v + bv);
             }
         if (do_stats) {
             s += __shfl_xor(s, 32, 64); ss += __shfl_xor(ss, 32, 64);
@@ -525,7 +525,7 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
                     float v = acc[i][j][r];
                     s1 += v; s2 += v * v;
                     int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    Elem<T>::store(so + row * BN + col, v + bv);
+                    Elem<T>::store(so + row * BN + col, a.act_relu ? fmaxf(v + bv, 0.f) : v + bv);
                 }
             if (do_stats) {
                 s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
@@ -650,7 +650,7 @@ int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const 
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.pro_scale = ps; a.pro_shift = psh; a.stat_sum = ssum; a.stat_sumsq = ssq;
     a.stat_replicas = d->stat_replicas > 1 ? d->stat_replicas : 1; a.stat_rstride = d->stat_rstride;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Cout = d->Cout; a.ldy = d->ldy;
-    a.pro_relu = d->pro_relu; a.tiles_y = d->H / TILE; a.tiles_x = d->W / TILE;
+    a.pro_relu = d->pro_relu; a.act_relu = d->epi_relu; a.tiles_y = d->H / TILE; a.tiles_x = d->W / TILE;
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return set_error(SAUNET_BAD_ALIGN, "conv: pointers must be 16-byte aligned");
     bool handled = false;
     if (d->dtype == SAUNET_BF16) { int rc = dispatch_res_fwd<u16>(a, st, &handled); if (handled) return rc; return dispatch_tile_fwd<u16>(a, st); }

@@ -210,7 +210,7 @@ def conv_out_hw(h, w, kh, kw, stride, pad, transposed):
     return (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
 
 
-def conv_forward_raw(x, weight, bias, stride, pad, transposed=False, pro=None, out=None, stats=None):
+def conv_forward_raw(x, weight, bias, stride, pad, transposed=False, pro=None, out=None, stats=None, act_relu=False):
     """y = conv(prologue(x), weight) + bias.  pro = (scale, shift, relu) or None.
     out: optional pre-allocated (channel-slice) destination.  stats = [R, 2, Cout] float64 accumulators (may be a
     channel slice of a wider [R, 2, Ctot] buffer)."""
@@ -229,6 +229,7 @@ def conv_forward_raw(x, weight, bias, stride, pad, transposed=False, pro=None, o
     d = _desc(x, cout, ld_of(out), ho, wo, kh, kw, stride, pad, transposed, bool(pro and pro[2]))
     if stats is not None:
         d.stat_replicas, d.stat_rstride = stats.shape[0], stats.stride(0)
+    d.epi_relu = 1 if act_relu else 0
     L.call("saunet_conv2d_forward", C.byref(d), x.data_ptr(), wp.data_ptr(), L.ptr(bias),
            L.ptr(pro[0]) if pro else None, L.ptr(pro[1]) if pro else None, out.data_ptr(),
            stats[0, 0].data_ptr() if stats is not None else None, stats[0, 1].data_ptr() if stats is not None else None, L.stream())
@@ -565,6 +566,13 @@ def conv_bn_act(x, weight, bias, bn, relu=True, residual=None, stride=1, padding
     _bump(bn)
     if transposed:
         stride, padding = 2, 1  # the only transposed geometry on the path: ConvTranspose2d(k=4, s=2, p=1)
+    if not bn.training and not torch.is_grad_enabled() and residual is None and x.is_cuda:
+        # inference: BatchNorm folded into the convolution -- w' = w * gamma/sqrt(var+eps) per output channel, b' = the BN shift
+        # (incl. the conv bias), ReLU in the conv epilogue: one kernel, no normalisation pass
+        p = bn_finalize(None, 1, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, False)
+        wf = weight * (p.scale.view(1, -1, 1, 1) if transposed else p.scale.view(-1, 1, 1, 1))
+        bf = p.shift if bias is None else torch.addcmul(p.shift, bias, p.scale)
+        return conv_forward_raw(x, wf, bf, stride, padding, transposed, act_relu=relu)
     group = None
     if getattr(bn, "sync", False) and bn.training and torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size() > 1:

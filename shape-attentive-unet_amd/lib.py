@@ -18,7 +18,7 @@ PACK_FWD, PACK_DGRAD, PACK_CONVT_FWD, PACK_CONVT_DGRAD = 0, 1, 2, 3
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dtype", "N", "H", "W", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "KH", "KW", "stride", "pad",
-        "transposed", "pro_relu", "stat_replicas", "stat_rstride")]
+        "transposed", "pro_relu", "stat_replicas", "stat_rstride", "epi_relu")]
 
 
 class BnEpilogue(C.Structure):
