@@ -211,17 +211,18 @@ def main():
     graph = None
     if use_graph:
         try:
+            from saunet_amd.graph import GraphedStep
             opt.upload_hyper()
-            graph = torch.cuda.CUDAGraph()
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                fwd_bwd()
-            torch.cuda.current_stream().wait_stream(s)
-            with torch.cuda.graph(graph):
-                static_loss = fwd_bwd()
+
+            def captured():
+                loss = fwd_bwd()
                 if world == 1:
                     tail()
+                return loss
+
+            # weight re-packing is recorded INSIDE the graph (functional.PackedWeights.prepack under capture), so every replay trains
+            # on the weights its predecessor's optimiser step produced
+            graph = GraphedStep(captured, warmup=1)
             mode = "hipgraph(fwd+bwd+opt)" if world == 1 else "hipgraph(fwd+bwd)+eager(allreduce+opt)"
             graph.replay(); torch.cuda.synchronize()
         except Exception as e:  # capture unsupported -> measured eagerly, and said so in the JSON
@@ -232,10 +233,10 @@ def main():
     def step():
         if graph is None:
             return eager_step()
-        graph.replay()
+        loss = graph.replay()
         if world > 1:
             tail()
-        return static_loss
+        return loss
 
     for _ in range(2):
         step()

@@ -113,6 +113,15 @@ int saunet_bn_finalize(int C, const double* sum, const double* sumsq, int replic
                        const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, float* scale, float* shift,
                        float* mean, float* invstd, int training, void* stream);
+/* SynchronizedBatchNorm2d across data-parallel replicas (lib/nn/modules/batchnorm.py:118-139, _compute_mean_std):
+ * (sum, sumsq, count) are the GLOBAL (all-reduced) statistics; inv_std = clamp(biased var, eps)^-1/2; the moving average is
+ * the reference's accumulator pair  tmp = tmp*(1-momentum) + stat,  iter = iter*(1-momentum) + 1,  running = tmp / iter
+ * (unbiased variance).  tmp_running_mean == NULL skips the running-statistic update. */
+int saunet_syncbn_finalize(int C, const double* sum, const double* sumsq, int replicas, int rstride, double count,
+                           const float* gamma, const float* beta, float eps, float momentum,
+                           float* tmp_running_mean, float* tmp_running_var, float* running_iter,
+                           float* running_mean, float* running_var, float* scale, float* shift,
+                           float* mean, float* invstd, void* stream);
 /* y = act(x*scale+shift (+residual)) */
 int saunet_affine_act(int dtype, const void* x, int ldx, const float* scale, const float* shift,
                       const void* residual, int ldr, int relu, void* y, int ldy, int64_t pixels, int C, void* stream);

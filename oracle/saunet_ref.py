@@ -37,10 +37,66 @@ CE_WEIGHT = (1.0, 4.0, 5.0, 1.0)  # loss.py:130
 
 
 # ----------------------------------------------------------------------------- primitives
+# Data-parallel emulation (/root/reference/train.py:272-277, lib/nn/modules/batchnorm.py:98-139): when
+# _DP_SHARDS = K > 1 the batch dimension holds K equal shards back to back (one per replica).  Convolutions, pooling, resampling
+# and the SE pool are per-sample, so running them on the concatenation IS running them per replica; only batch normalisation and
+# the loss see the shard structure:
+#   * the 144 nn.BatchNorm2d layers normalise every shard with ITS OWN batch statistics (what nn.DataParallel replicas do);
+#     the running statistics that survive are replica 0's (replica 0 shares the module's buffers, the others are discarded);
+#   * the 6 SynchronizedBatchNorm2d layers (momentum == SYNCBN_MOM) use the statistics of the whole global batch, computed
+#     and accumulated exactly like _compute_mean_std (clamp(var, eps)^-1/2, _tmp_running_* / _running_iter);
+#   * the loss is evaluated per shard and averaged (train.py:96 `loss.mean()`).
+_DP_SHARDS = 1
+
+
+class dp_shards:
+    """context manager: interpret the batch as K per-replica shards"""
+
+    def __init__(self, k):
+        self.k = int(k)
+
+    def __enter__(self):
+        global _DP_SHARDS
+        self.prev, _DP_SHARDS = _DP_SHARDS, self.k
+        return self
+
+    def __exit__(self, *exc):
+        global _DP_SHARDS
+        _DP_SHARDS = self.prev
+
+
+def _sync_bn_train(sd, pre, x, momentum):
+    """_SynchronizedBatchNorm.forward, parallel branch (lib/nn/modules/batchnorm.py:63-84, 118-139)."""
+    n = x.numel() // x.shape[1]
+    s1 = x.sum((0, 2, 3)); s2 = (x * x).sum((0, 2, 3))
+    mean = s1 / n
+    sumvar = s2 - s1 * mean
+    unbias_var, bias_var = sumvar / (n - 1), sumvar / n
+    keep = 1.0 - momentum
+    with torch.no_grad():
+        tm = sd[pre + "._tmp_running_mean"] * keep + mean.detach()
+        tv = sd[pre + "._tmp_running_var"] * keep + unbias_var.detach()
+        it = sd[pre + "._running_iter"] * keep + 1
+        sd[pre + "._tmp_running_mean"], sd[pre + "._tmp_running_var"], sd[pre + "._running_iter"] = tm, tv, it
+        sd[pre + ".running_mean"], sd[pre + ".running_var"] = tm / it, tv / it
+    inv_std = bias_var.clamp(BN_EPS) ** -0.5
+    return (x - mean[None, :, None, None]) * (inv_std * sd[pre + ".weight"])[None, :, None, None] + sd[pre + ".bias"][None, :, None, None]
+
+
 def _bn(sd, pre, x, training, momentum=BN_MOM):
     rm, rv = sd[pre + ".running_mean"], sd[pre + ".running_var"]
     if training and (pre + ".num_batches_tracked") in sd:
         sd[pre + ".num_batches_tracked"] += 1
+    k = _DP_SHARDS
+    if k > 1 and training:
+        if momentum == SYNCBN_MOM and (pre + "._running_iter") in sd:
+            return _sync_bn_train(sd, pre, x, momentum)
+        b = x.shape[0] // k
+        outs = []
+        for r in range(k):       # replica r: local statistics; only replica 0's running-statistic update survives
+            outs.append(F.batch_norm(x[r * b:(r + 1) * b], rm if r == 0 else rm.clone(), rv if r == 0 else rv.clone(),
+                                     sd[pre + ".weight"], sd[pre + ".bias"], True, momentum, BN_EPS))
+        return torch.cat(outs, 0)
     return F.batch_norm(x, rm, rv, sd[pre + ".weight"], sd[pre + ".bias"], training, momentum, BN_EPS)
 
 
@@ -200,6 +256,28 @@ def segmentation_step(sd, image, seg_t, edge_t, training=True, canny=None):
     loss = dual_loss(logits, edge, seg_t, edge_t)
     acc = pixel_acc(logits.detach(), seg_t)
     return loss, acc, logits, edge
+
+
+def dp_emulate_step(sd, shards, training=True):
+    """K-replica data-parallel step on the CPU: `shards` = [(image, seg, edge)] * K with identical
+    weights `sd`; returns (mean of the per-shard losses, [per-shard loss], logits, edge) -- backpropagating the mean loss
+    yields the average of the K replica gradients, which is what the all-reduce delivers to every rank."""
+    k = len(shards)
+    b = shards[0][0].shape[0]
+    assert all(s[0].shape[0] == b for s in shards), "equal shards (drop_last=True, train.py:252)"
+    image = torch.cat([s[0] for s in shards]); seg_t = torch.cat([s[1] for s in shards]); edge_t = torch.cat([s[2] for s in shards])
+    # SyncBN bookkeeping buffers as the reference constructor leaves them (batchnorm.py:50-54), if the state dict lacks them
+    for key in list(sd.keys()):
+        if key.endswith(".running_mean") and key.split(".")[0] in ("res1", "res2", "res3"):
+            pre = key[:-len(".running_mean")]
+            sd.setdefault(pre + "._running_iter", torch.ones(1))
+            sd.setdefault(pre + "._tmp_running_mean", sd[key].clone() * sd[pre + "._running_iter"])
+            sd.setdefault(pre + "._tmp_running_var", sd[pre + ".running_var"].clone() * sd[pre + "._running_iter"])
+    with dp_shards(k):
+        logits, edge = saunet_forward(sd, image, training)
+    losses = [dual_loss(logits[r * b:(r + 1) * b], edge[r * b:(r + 1) * b], seg_t[r * b:(r + 1) * b], edge_t[r * b:(r + 1) * b])
+              for r in range(k)]
+    return torch.stack(losses).mean(), losses, logits, edge
 
 
 def intersection_and_union(pred, lab, num_class):

@@ -123,6 +123,40 @@ __global__ void bn_finalize_kernel(int C, const double* __restrict__ sum, const 
     if (invstd_o) invstd_o[c] = invstd;
 }
 
+// SynchronizedBatchNorm2d in its multi-replica form (lib/nn/modules/batchnorm.py:118-139): statistics from the GLOBAL
+// (all-reduced) sums, inv_std = clamp(biased var, eps)^-1/2, and the moving average kept as the pair
+// (_tmp_running_* , _running_iter): tmp = tmp*(1-m) + stat; iter = iter*(1-m) + 1; running = tmp / iter.
+__global__ void syncbn_finalize_kernel(int C, const double* __restrict__ sum, const double* __restrict__ sq, int reps, int rstride, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                       float* __restrict__ tmp_mean, float* __restrict__ tmp_var, float* __restrict__ iter,
+                                       float* __restrict__ rmean, float* __restrict__ rvar,
+                                       float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o, float* __restrict__ invstd_o)
+{
+    const float keep = 1.f - momentum;
+    const float it_new = iter ? iter[0] * keep + 1.f : 1.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double s1 = rep_sum(sum, reps, rstride, c), s2 = rep_sum(sq, reps, rstride, c);
+        const double m = s1 / count;
+        double sumvar = s2 - s1 * m;
+        if (sumvar < 0.0) sumvar = 0.0;
+        const double bias_var = sumvar / count, unb = sumvar / (count - 1.0);
+        const float mean = (float)m;
+        const float invstd = (float)(1.0 / sqrt(bias_var < (double)eps ? (double)eps : bias_var));
+        if (tmp_mean) {
+            const float tm = tmp_mean[c] * keep + mean, tv = tmp_var[c] * keep + (float)unb;
+            tmp_mean[c] = tm; tmp_var[c] = tv;
+            rmean[c] = tm / it_new; rvar[c] = tv / it_new;
+        }
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        const float s = g * invstd;
+        scale[c] = s; shift[c] = b - mean * s;
+        if (mean_o) mean_o[c] = mean;
+        if (invstd_o) invstd_o[c] = invstd;
+    }
+    __syncthreads();              // every thread has read iter[0]
+    if (iter && threadIdx.x == 0) iter[0] = it_new;
+}
+
 template <typename T, int V>
 __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const T* __restrict__ res, int ldr, int relu,
@@ -365,6 +399,22 @@ int saunet_bn_finalize(int C, const double* sum, const double* sumsq, int replic
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, sum, sumsq, replicas < 1 ? 1 : replicas, rstride, count, conv_bias,
                        gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd, training);
     SAUNET_CHECK_LAUNCH("bn_finalize");
+    return SAUNET_OK;
+}
+
+int saunet_syncbn_finalize(int C, const double* sum, const double* sumsq, int replicas, int rstride, double count,
+                           const float* gamma, const float* beta, float eps, float momentum,
+                           float* tmp_running_mean, float* tmp_running_var, float* running_iter,
+                           float* running_mean, float* running_var, float* scale, float* shift,
+                           float* mean, float* invstd, void* stream)
+{
+    if (!sum || !sumsq || count <= 1.0) return set_error(SAUNET_BAD_SHAPE, "syncbn_finalize: needs sums and a global count > 1");
+    if (tmp_running_mean && (!tmp_running_var || !running_iter || !running_mean || !running_var))
+        return set_error(SAUNET_BAD_SHAPE, "syncbn_finalize: incomplete running-statistic buffers");
+    hipLaunchKernelGGL(syncbn_finalize_kernel, dim3(1), dim3(C < 256 ? 64 * ((C + 63) / 64) : 256), 0, (hipStream_t)stream, C, sum, sumsq, replicas < 1 ? 1 : replicas,
+                       rstride, count, gamma, beta, eps, momentum, tmp_running_mean, tmp_running_var, running_iter, running_mean, running_var,
+                       scale, shift, mean, invstd);
+    SAUNET_CHECK_LAUNCH("syncbn_finalize");
     return SAUNET_OK;
 }
 

@@ -86,17 +86,31 @@ def _copy(tl_cols, pack, scale):
 
 
 class GradientBuckets:
-    """Bucketed, backward-overlapped gradient averaging."""
+    """Bucketed, backward-overlapped gradient averaging.
+
+    Parameters that never receive a gradient (``encoder.classifier``: registered like in the reference, off the compute path)
+    are detected on the first step and dropped from the buckets: their ``.grad`` stays None on every rank -- exactly as in a
+    single-process run, where the optimiser skips them -- and no bucket waits for a gradient that never comes."""
 
     def __init__(self, params, bucket_mb=32.0, group=None, overlap=True):
         self.group = group
         self.params = [p for p in params if p.requires_grad]
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        cap = int(bucket_mb * 1024 * 1024 / 4)
+        self.cap = int(bucket_mb * 1024 * 1024 / 4)
+        self.overlap = overlap
+        self.hooks = []
+        self.first_step_done = False
+        self.exposed_events = None        # (start, end) HIP events around the wait+unpack of finish(), if timing is enabled
+        self.time_finish = False
+        self._build(self.params)
+
+    def _build(self, params):
         # reverse registration order ~ order in which backward produces gradients (final ... conv0)
+        self.remove_hooks()
+        self.params = list(params)
         self.buckets, cur, cur_n = [], [], 0
         for p in reversed(self.params):
-            if cur and cur_n + p.numel() > cap:
+            if cur and cur_n + p.numel() > self.cap:
                 self.buckets.append(cur); cur, cur_n = [], 0
             cur.append(p); cur_n += p.numel()
         if cur:
@@ -106,10 +120,7 @@ class GradientBuckets:
         for b, ps in enumerate(self.buckets):
             for p in ps:
                 self.bucket_of[id(p)] = b
-        self.pending = [0] * len(self.buckets)
-        self.handles = [None] * len(self.buckets)
-        self.hooks = []
-        if overlap and self.world > 1:
+        if self.overlap and self.world > 1:
             for p in self.params:
                 self.hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.reset()
@@ -128,14 +139,20 @@ class GradientBuckets:
             views.append(self.flat[b][o:o + p.numel()]); o += p.numel()
         return views
 
+    def _present(self, b):
+        """(gradients, flat views) of the bucket's parameters that have a gradient"""
+        views = self._views(b)
+        pairs = [(p.grad, v) for p, v in zip(self.buckets[b], views) if p.grad is not None]
+        return [g for g, _ in pairs], [v for _, v in pairs]
+
     def _launch(self, b):
         from . import functional as HF
         HF.WGRAD_SIDE.join()          # weight gradients are written on a side stream
-        ps = self.buckets[b]
-        for p in ps:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-        _copy(([p.grad for p in ps], self._views(b)), True, 1.0)
+        grads, views = self._present(b)
+        if len(grads) != len(self.buckets[b]):
+            self.flat[b].zero_()      # first step only: slots of gradient-less parameters travel as zeros (every rank agrees)
+        if grads:
+            _copy((grads, views), True, 1.0)
         self.handles[b] = dist.all_reduce(self.flat[b], group=self.group, async_op=True)
 
     def _on_grad(self, p):
@@ -151,9 +168,24 @@ class GradientBuckets:
         for b in range(len(self.buckets)):
             if self.handles[b] is None:
                 self._launch(b)
-        for b, ps in enumerate(self.buckets):
+        ev = None
+        if self.time_finish and self.flat[0].is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        for b in range(len(self.buckets)):
             self.handles[b].wait()
-            _copy(([p.grad for p in ps], self._views(b)), False, 1.0 / self.world)
+            grads, views = self._present(b)
+            if grads:
+                _copy((grads, views), False, 1.0 / self.world)
+        if ev is not None:
+            ev[1].record()
+            self.exposed_events = ev
+        if not self.first_step_done:
+            self.first_step_done = True
+            used = [p for p in self.params if p.grad is not None]
+            if len(used) != len(self.params):
+                self._build(used)
+                return
         self.reset()
 
     def remove_hooks(self):

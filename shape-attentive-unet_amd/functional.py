@@ -103,10 +103,24 @@ def collapse_stats(st):
     return st[0].reshape(2 * c)
 
 
+def capturing():
+    """True while the current HIP stream is being captured into a hipGraph."""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def begin_step():
     """Called at the start of every SAUNet forward: new scratch arenas, all weight packings refreshed in bulk."""
     STATS.reset(); GRADS.reset()
     PACKS.prepack()
+
+
+def notify_params_changed():
+    """Parameters / running statistics were changed through raw pointers without the host seeing it -- i.e. a captured
+    hipGraph containing an optimiser step or a training-mode BatchNorm was replayed.  Marks every weight packing dirty and
+    drops the eval-mode BatchNorm coefficient cache.  (Eager fused optimiser steps and training-mode finalizes do this
+    themselves; only ``graph.replay()`` needs the explicit call -- saunet_amd.graph.GraphedStep makes it.)"""
+    PACKS.invalidate()
+    _EVAL_BN.clear()
 
 
 class PackedWeights:
@@ -131,7 +145,9 @@ class PackedWeights:
         return co, ci, kh, kw
 
     def prepack(self):
-        if not self.dirty:
+        # under stream capture the re-pack launches must become part of the graph: a replayed optimiser step changes the master
+        # weights through raw pointers, so every replay has to refresh the packings itself (in place, addresses are stable)
+        if not self.dirty and not capturing():
             return
         live = []
         for key, ent in list(self.cache.items()):
@@ -423,7 +439,9 @@ def bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum, eps, training,
     if training and rmean is not None:
         PACKS.generation += 1                  # running statistics are about to change through a raw pointer
     key = None
-    if not training and stats is None and conv_bias is None and rmean is not None:
+    # never read or fill the cache while a hipGraph is being captured: the captured forward must contain its own finalize
+    # launches (gamma / beta / running statistics change between replays) and must not reference cache-owned buffers
+    if not training and stats is None and conv_bias is None and rmean is not None and not capturing():
         key = (id(rmean), id(gamma))
         vers = (gamma._version, beta._version, rmean._version, rvar._version, float(eps), PACKS.generation, gamma.device)
         ent = _EVAL_BN.get(key)
@@ -545,17 +563,30 @@ class _ConvBNAct(torch.autograd.Function):
     """y = act(BN(conv(x)) [+ residual]) with the batch statistics taken in the conv epilogue."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, rmean, rvar, residual, stride, pad, transposed, relu, momentum, eps, training, group):
+    def forward(ctx, x, weight, bias, gamma, beta, rmean, rvar, residual, stride, pad, transposed, relu, momentum, eps, training, group,
+                sync_bufs=None):
         x = nhwc(x)
         cout = weight.shape[1] if transposed else weight.shape[0]
         stats = new_stats(cout, x.device) if training else None
         z = conv_forward_raw(x, weight, bias, stride, pad, transposed, stats=stats)
         count = z.shape[0] * z.shape[2] * z.shape[3]
         if group is not None and training:
-            # SynchronizedBatchNorm: global batch statistics = all-reduce of (sum, sumsq); count scales with the world
-            torch.distributed.all_reduce(stats, group=group)
+            # SynchronizedBatchNorm across replicas (lib/nn/modules/batchnorm.py:98-139): global batch statistics = all-reduce of
+            # (sum, sumsq), count scales with the world, inv_std = clamp(var, eps)^-1/2, running statistics through the reference's
+            # (_tmp_running_*, _running_iter) accumulator
+            if bias is not None:
+                raise RuntimeError("synchronised batch norm behind a biased convolution is not on the SAUNet path")
+            flat = collapse_stats(stats)
+            torch.distributed.all_reduce(flat, group=group)
             count *= torch.distributed.get_world_size(group)
-        p = bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum, eps, training, conv_bias=bias)
+            p = BNParams(cout, x.device)
+            tm, tv, it = sync_bufs if sync_bufs is not None else (None, None, None)
+            PACKS.generation += 1
+            L.call("saunet_syncbn_finalize", cout, flat[:cout].data_ptr(), flat[cout:].data_ptr(), 1, 0, float(count), gamma.data_ptr(),
+                   beta.data_ptr(), float(eps), float(momentum), L.ptr(tm), L.ptr(tv), L.ptr(it), L.ptr(rmean), L.ptr(rvar),
+                   p.scale.data_ptr(), p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), L.stream())
+        else:
+            p = bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum, eps, training, conv_bias=bias)
         y = affine_act(z, p.scale, p.shift, relu, residual)
         ctx.save_for_backward(x, weight, z, p.buf, residual if residual is not None else z.new_empty(0))
         ctx.cfg = (stride, pad, transposed, relu, training, count, bias is not None, residual is not None, group)
@@ -576,7 +607,7 @@ class _ConvBNAct(torch.autograd.Function):
             # a bias in front of a training-mode BatchNorm has an exactly zero gradient (sum of dz over the batch is 0)
             cout = dz.shape[1]
             db = torch.zeros(cout, dtype=torch.float32, device=dz.device) if training else channel_sum(dz)
-        return dx, dw, db, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, weight, bias, bn, relu=True, residual=None, stride=1, padding=0, transposed=False):
@@ -593,12 +624,13 @@ def conv_bn_act(x, weight, bias, bn, relu=True, residual=None, stride=1, padding
         wf = weight * (p.scale.view(1, -1, 1, 1) if transposed else p.scale.view(-1, 1, 1, 1))
         bf = p.shift if bias is None else torch.addcmul(p.shift, bias, p.scale)
         return conv_forward_raw(x, wf, bf, stride, padding, transposed, act_relu=relu)
-    group = None
+    group, sync_bufs = None, None
     if getattr(bn, "sync", False) and bn.training and torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size() > 1:
         group = torch.distributed.group.WORLD
+        sync_bufs = (bn._tmp_running_mean, bn._tmp_running_var, bn._running_iter)
     return _ConvBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, stride, padding,
-                            transposed, relu, bn.momentum, bn.eps, bn.training, group)
+                            transposed, relu, bn.momentum, bn.eps, bn.training, group, sync_bufs)
 
 
 class _BNAct(torch.autograd.Function):

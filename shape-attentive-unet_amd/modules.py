@@ -349,6 +349,11 @@ class SAUNet(nn.Module):
         self.dec0 = conv3x3_bn_relu(num_filters * 2, num_filters)
         self.final = nn.Conv2d(num_filters, self.num_classes, kernel_size=1)
 
+    def train(self, mode=True):
+        if mode != self.training:
+            HF._EVAL_BN.clear()       # eval-mode BatchNorm coefficients are cached per module: drop them on every mode switch
+        return super().train(mode)
+
     def _prep_input(self, x):
         """float image [B,3,H,W] (any layout) -> NHWC, 8 channels (5 zero), compute dtype."""
         n, c, h, w = x.shape

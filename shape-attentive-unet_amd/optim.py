@@ -61,13 +61,23 @@ def _tensor_lists(cols):
 
 
 class _FusedBase(torch.optim.Optimizer):
+    """Private bookkeeping (device hyper-parameter arrays, last uploaded values) lives in ``self._priv`` keyed by the
+    group index -- never in ``param_groups`` -- so ``state_dict()`` holds only what torch.optim would put there."""
     grad_scale = 1.0
 
+    def _p(self, group):
+        priv = self.__dict__.setdefault("_priv", {})
+        for i, g in enumerate(self.param_groups):
+            if g is group:
+                return priv.setdefault(i, {})
+        raise KeyError("unknown param group")
+
     def _hyper(self, group, n=8):
-        h = group.get("_hyper")
+        pv = self._p(group)
+        h = pv.get("hyper")
         if h is None or h.device != group["params"][0].device:
             h = torch.zeros(n, dtype=torch.float32, device=group["params"][0].device)
-            group["_hyper"] = h
+            pv["hyper"] = h
         return h
 
     def _upload(self, group, values):
@@ -75,13 +85,14 @@ class _FusedBase(torch.optim.Optimizer):
         a pageable-memory copy_ blocks the host until the stream has drained, i.e. once per step in eager mode."""
         values = tuple(float(v) for v in values)
         h = self._hyper(group)
-        if group.get("_hyper_vals") == values and group.get("_hyper_dev") == h.data_ptr():
+        pv = self._p(group)
+        if pv.get("vals") == values and pv.get("dev") == h.data_ptr():
             return
         host = torch.tensor(values, dtype=torch.float32)
         if h.is_cuda:
             host = host.pin_memory()          # the caching host allocator keeps the block alive until the copy has run
         h.copy_(host, non_blocking=True)
-        group["_hyper_vals"], group["_hyper_dev"] = values, h.data_ptr()
+        pv["vals"], pv["dev"] = values, h.data_ptr()
 
     def _live(self, group):
         HF.WGRAD_SIDE.join()      # weight gradients are produced on a side stream
@@ -102,7 +113,8 @@ class FusedSGD(_FusedBase):
 
     def upload_hyper(self):
         for g in self.param_groups:
-            first = 0.0 if g.get("_stepped", False) else 1.0
+            # first step <=> no momentum buffer exists yet (also right after load_state_dict of a fresh or a resumed optimiser)
+            first = 0.0 if any("momentum_buffer" in self.state.get(p, {}) for p in g["params"]) else 1.0
             self._upload(g, [g["lr"], g["momentum"], g["weight_decay"], first, self.grad_scale, 0, 0, 0])
 
     @torch.no_grad()
@@ -121,7 +133,6 @@ class FusedSGD(_FusedBase):
                 bufs.append(st["momentum_buffer"])
             for tl in _tensor_lists([ps, [p.grad for p in ps], bufs]):
                 L.call("saunet_sgd_step", C.byref(tl), self._hyper(g).data_ptr(), L.stream())
-            g["_stepped"] = True
         HF.PACKS.invalidate()
 
 
@@ -143,9 +154,17 @@ class FusedRAdam(_FusedBase):
             step_size = lr / (1 - beta1 ** step)
         return n_sma, step_size
 
+    def _group_step(self, g):
+        """steps taken so far = the per-parameter counter of any parameter with state (all move together)"""
+        for p in g["params"]:
+            st = self.state.get(p)
+            if st and "step" in st:
+                return int(st["step"])
+        return 0
+
     def upload_hyper(self):
         for g in self.param_groups:
-            step = g.get("_step", 0) + 1
+            step = self._group_step(g) + 1
             b1, b2 = g["betas"]
             n_sma, step_size = self.schedule(step, g["lr"], b1, b2)
             self._upload(g, [b1, b2, g["eps"], g["weight_decay"] * g["lr"], step_size, 1.0 if n_sma >= 5 else 0.0, self.grad_scale, 0])
@@ -162,12 +181,14 @@ class FusedRAdam(_FusedBase):
             for p in ps:
                 st = self.state[p]
                 if "exp_avg" not in st:
+                    st["step"] = 0               # radam.py:38 keeps the step count per parameter
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 ea.append(st["exp_avg"]); es.append(st["exp_avg_sq"])
             for tl in _tensor_lists([ps, [p.grad for p in ps], ea, es]):
                 L.call("saunet_radam_step", C.byref(tl), self._hyper(g).data_ptr(), L.stream())
-            g["_step"] = g.get("_step", 0) + 1
+            for p in ps:
+                self.state[p]["step"] += 1
         HF.PACKS.invalidate()
 
 

@@ -148,18 +148,18 @@ def checkpoint(unet, history, args, epoch):
 
 
 def should_checkpoint(epoch, iou, best, num_epoch):
-    """train.py:294-329: new best per-class / mean IoU after epoch 15, every 50 epochs, and the last epoch."""
-    save = False
+    """train.py:294-329: the per-class / mean best IoUs are tracked from the FIRST epoch; a new best saves unless
+    ``epoch < 15``; every 50th epoch and the last epoch always save."""
+    improved = False
     mean = float(np.mean(iou))
-    if epoch > 15:
-        for c in range(len(iou)):
-            if iou[c] > best["class"][c]:
-                best["class"][c] = float(iou[c]); save = True
-        if mean > best["mean"]:
-            best["mean"] = mean; save = True
+    for c in range(len(iou)):
+        if iou[c] > best["class"][c]:
+            best["class"][c] = float(iou[c]); improved = True
+    if mean > best["mean"]:
+        best["mean"] = mean; improved = True
     if epoch % 50 == 0 or epoch == num_epoch:
-        save = True
-    return save
+        return True
+    return improved and epoch >= 15
 
 
 def build_parser():

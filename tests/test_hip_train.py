@@ -54,3 +54,64 @@ def test_fused_radam_matches_reference_formula():
         n_sma, step_size = FusedRAdam.schedule(step, 1e-2, 0.9, 0.999)
         ref = ref - step_size * m / (v.sqrt() + 1e-8) if n_sma >= 5 else ref - step_size * m
         assert float((p.detach().double() - ref).abs().max()) < 1e-5, step
+
+
+def _make_training(dtype, seed=19, B=2, H=64):
+    import saunet_amd as S
+    from oracle import saunet_ref as R, weights as Wt
+    S.set_compute_dtype(dtype)
+    net = S.SAUNet(num_classes=4).cuda()
+    net.load_state_dict(Wt.make_state_dict(R.state_dict_spec(), seed), strict=False)
+    S.functional.notify_params_changed()
+    sm = S.SegmentationModule(S.DualLoss(mode="train"), net, 4).train()
+    opt = S.optim.create_optimizers(net, "sgd", lr=5e-3, momentum=0.9, weight_decay=1e-4)[0]
+    img, seg, edge = Wt.synthetic_batch(B, H, H, seed=61)
+    feed = {"image": img.cuda(), "mask": (seg.cuda(), edge.cuda())}
+    return S, net, sm, opt, feed
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_graph_replays_follow_the_eager_trajectory(dtype):
+    """A captured fwd+bwd+SGD step must re-pack the weights inside the graph: N replays reproduce the eager loss curve (a graph that
+    trained against frozen packed weights would print the SAME loss on every replay), and an eager eval after the replays sees the
+    replayed weights (host-side pack / eval-BN caches are invalidated by GraphedStep.replay)."""
+    import saunet_amd as S
+    from saunet_amd.graph import GraphedStep
+    try:
+        S_, net, sm, opt, feed = _make_training(dtype)
+        eager = []
+        for _ in range(6):
+            sm.zero_grad(set_to_none=True)
+            loss, _ = sm(feed, 1)
+            loss.backward(); opt.step(); eager.append(float(loss))
+        w_eager = net.final.weight.detach().clone()
+        sm.eval()
+        with torch.no_grad():
+            ref_eval = net(feed["image"])[0].float().clone()
+
+        S_, net, sm, opt, feed = _make_training(dtype)
+        opt.upload_hyper()
+
+        def step():
+            sm.zero_grad(set_to_none=True)
+            loss, _ = sm(feed, 1)
+            loss.backward()
+            opt.step(upload=False)
+            return loss.detach()
+
+        g = GraphedStep(step, warmup=1)          # the warm-up call is training step 0
+        replayed = []
+        for _ in range(5):
+            replayed.append(float(g.replay()))
+        torch.cuda.synchronize()
+        tol = 2e-4 if dtype == torch.float32 else 3e-2
+        assert max(abs(a - b) for a, b in zip(eager[1:], replayed)) < tol * max(eager), (eager, replayed)
+        assert abs(replayed[0] - replayed[-1]) > 1e-3, replayed            # the curve moves: weights are not frozen
+        assert float((net.final.weight.detach() - w_eager).abs().max()) < (1e-5 if dtype == torch.float32 else 2e-3)
+        sm.eval()
+        with torch.no_grad():
+            got = net(feed["image"])[0].float()
+        scale = float(ref_eval.abs().max())
+        assert float((got - ref_eval).abs().max()) < (1e-3 if dtype == torch.float32 else 6e-2) * scale
+    finally:
+        S.set_compute_dtype(torch.float32)

@@ -183,3 +183,38 @@ def test_saunet_sgd_trajectory_and_eval_branch():
     # after training the eval-mode net (running stats 10 steps old, SyncBN momentum 0.001) is chaotic: loose
     assert close(l_eval, g["eval_loss"], 1e-2, 0)[0]
     assert close(pred[:, :, ::8, ::8], g["eval_pred_s8"], 0.1, 0)[0]
+
+
+def test_dp_emulation_invariants():
+    """oracle.dp_emulate_step: K identical shards reproduce the single-replica loss / gradients (local statistics of
+    identical shards are identical; the 6 SyncBN layers see the same mean/var), different shards do not, and only replica 0's
+    running statistics survive in the 144 local BatchNorm layers."""
+    from oracle import saunet_ref as R, weights as Wt
+    spec = R.state_dict_spec()
+    sd = Wt.make_state_dict(spec, 3)
+    keys = Wt.trainable_keys(spec)
+    a = Wt.synthetic_batch(1, 64, 64, seed=5)
+    b = Wt.synthetic_batch(1, 64, 64, seed=9)
+
+    def run(fn):
+        s = {k: v.clone() for k, v in sd.items()}
+        for k in keys:
+            s[k].requires_grad_(True)
+        loss = fn(s)
+        loss.backward()
+        return float(loss), s
+
+    l1, s1 = run(lambda s: R.segmentation_step(s, *a, True)[0])
+    l2, s2 = run(lambda s: R.dp_emulate_step(s, [a, a], True)[0])
+    assert abs(l1 - l2) < 2e-5
+    gmax = max(float(s1[k].grad.abs().max()) for k in keys)
+    assert max(float((s1[k].grad - s2[k].grad).abs().max()) for k in keys) < 2e-4 * gmax
+    l3, s3 = run(lambda s: R.dp_emulate_step(s, [a, b], True)[0])
+    la, _ = run(lambda s: R.segmentation_step(s, *a, True)[0])
+    assert abs(l3 - l1) > 1e-4
+    # local BN: replica 0's update only == the single-replica run on shard a
+    k = "encoder.features.denseblock2.denselayer3.norm1.running_mean"
+    assert torch.allclose(s3[k], s1[k], atol=1e-6)
+    # SyncBN: global statistics + accumulator form (running = tmp / iter, iter = 1*(1-m)+1)
+    assert abs(float(s3["res1.bn1._running_iter"]) - 1.999) < 1e-6
+    assert not torch.allclose(s3["res1.bn1.running_mean"], s1["res1.bn1.running_mean"], atol=1e-3)

@@ -50,15 +50,22 @@ def test_intersection_and_union_and_dice():
 
 
 def test_checkpoint_policy():
+    """/root/reference/train.py:294-329: bests are tracked from epoch 1, a new best saves from epoch 15 on, every 50th epoch and the
+    last epoch always save."""
     import saunet_amd
     from saunet_amd import train
     best = {"class": [0.0, 0.0, 0.0], "mean": 0.0}
-    assert not train.should_checkpoint(10, [0.9, 0.9, 0.9], best, 120)      # nothing before epoch 16 ...
-    assert train.should_checkpoint(50, [0.1, 0.1, 0.1], best, 120)           # ... except every 50 epochs
-    assert train.should_checkpoint(16, [0.5, 0.4, 0.3], best, 120)           # new best
+    assert not train.should_checkpoint(10, [0.3, 0.3, 0.3], best, 120)      # improvement before epoch 15: tracked, not saved
+    assert best["class"] == [0.3, 0.3, 0.3] and abs(best["mean"] - 0.3) < 1e-12
+    assert not train.should_checkpoint(14, [0.35, 0.3, 0.3], best, 120)
+    assert train.should_checkpoint(15, [0.5, 0.4, 0.3], best, 120)           # epoch 15 may save (only `epoch < 15` is suppressed)
+    assert not train.should_checkpoint(16, [0.5, 0.4, 0.3], best, 120)      # ties are not improvements
     assert not train.should_checkpoint(17, [0.4, 0.3, 0.2], best, 120)
     assert train.should_checkpoint(18, [0.4, 0.45, 0.2], best, 120)          # one class improved
+    assert train.should_checkpoint(50, [0.1, 0.1, 0.1], best, 120)           # every 50 epochs
     assert train.should_checkpoint(120, [0.0, 0.0, 0.0], best, 120)          # last epoch
+    best2 = {"class": [0.0, 0.0, 0.0], "mean": 0.0}
+    assert train.should_checkpoint(100, [0.2, 0.2, 0.2], best2, 120) and best2["mean"] > 0.19   # bests updated on forced saves too
 
 
 def test_synthetic_dataset_format():
