@@ -171,6 +171,17 @@ int saunet_gate_mul_forward(int dtype, const void* x, int ldx, const void* alpha
 int saunet_gate_mul_backward(int dtype, const void* x, int ldx, const void* alpha, const void* dy, int lddy,
                              void* dx, int lddx, void* dalpha, int64_t pixels, int C, void* stream);
 
+/* ---- selectable global pooling (models/adaptive_avgmax_pool.py:19-40 adaptive_avgmax_pool2d, :43-74 AdaptiveAvgMaxPool2d; and
+ * nn.AdaptiveAvgPool2d(1) of SEModule, models/attention_blocks.py:32) --------------------------------------------------------------
+ * mode: 0 'avg', 1 'max', 2 'avgmax' = 0.5*(avg+max), 3 'avgmaxc' = [avg | max] (2C values per image).  One pass over x [N, HW, C]
+ * (NHWC, row stride ldx); out is float32 [N, C] (or [N, 2C]); argmax (optional, int32 [N, C]) receives the FIRST pixel index of every
+ * channel maximum (what F.max_pool2d's backward routes the gradient to).  Workspace: saunet_global_pool_workspace(N, HW, C) bytes.
+ * backward: dx[n,p,c] = davg/HW + [p == argmax[n,c]] * dmax with (davg, dmax) read from dy according to the mode. */
+int64_t saunet_global_pool_workspace(int N, int HW, int C);
+int saunet_global_pool_forward(int dtype, int mode, const void* x, int N, int HW, int C, int ldx, float* out, int* argmax,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+int saunet_global_pool_backward(int dtype, int mode, const float* dy, const int* argmax, int N, int HW, int C, void* dx, int lddx, void* stream);
+
 /* ---- fused GatedSpatialConv2d (models/GSConv.py:16-57; call sites models/models.py:341-352) ----------------------
  * Replaces  cat -> BN(C+1) -> conv1x1(C+1,C+1) -> relu -> conv1x1(C+1,1) -> BN(1) -> sigmoid -> x*(alpha+1) -> conv1x1(C,C)
  * for C = 8/16/32 feature channels + 1 gating channel, bf16 storage, training-mode batch norm.  One thread owns one
@@ -255,9 +266,12 @@ typedef struct saunet_tensor_list { int32_t count; const void* ptrs[4][96]; int6
 /* hyper-parameters live in a DEVICE float array so a captured hipGraph can be replayed after the host
  * rewrites the learning rate:
  *   SGD   hyper = {lr, momentum, weight_decay, first_step(0/1), grad_scale}
- *   RAdam hyper = {beta1, beta2, eps, weight_decay*lr, step_size, rectified(0/1), grad_scale}  (radam.py:52-75) */
+ *   RAdam hyper = {beta1, beta2, eps, weight_decay*lr, step_size, rectified(0/1), grad_scale}  (radam.py:52-75)
+ *   Adam  hyper = {beta1, beta2, eps, weight_decay, lr/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale}  (torch.optim.Adam as built at
+ *                 train.py:197-201: amsgrad off, L2 weight decay) */
 int saunet_sgd_step(const saunet_tensor_list* tl /*0:param 1:grad 2:momentum*/, const float* hyper, void* stream);
 int saunet_radam_step(const saunet_tensor_list* tl /*0:param 1:grad 2:exp_avg 3:exp_avg_sq*/, const float* hyper, void* stream);
+int saunet_adam_step(const saunet_tensor_list* tl /*0:param 1:grad 2:exp_avg 3:exp_avg_sq*/, const float* hyper, void* stream);
 /* flat[offset_i : offset_i+n_i] = grad_i (pack=1) or grad_i = flat[...]*scale (pack=0): all-reduce buckets */
 int saunet_bucket_copy(const saunet_tensor_list* tl /*0:tensor 1:flat+offset*/, int pack, float scale, void* stream);
 

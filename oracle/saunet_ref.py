@@ -48,6 +48,58 @@ CE_WEIGHT = (1.0, 4.0, 5.0, 1.0)  # loss.py:130
 #   * the loss is evaluated per shard and averaged (train.py:96 `loss.mean()`).
 _DP_SHARDS = 1
 
+# bf16-storage emulation (test infrastructure for the bf16 parity tests): with _BF16_EMU set, every tensor an op hands to the next op
+# -- activations on the way forward, their gradients on the way back -- and every convolution weight operand is rounded to bfloat16,
+# while all arithmetic stays float32.  This is what ANY implementation that keeps activations / gradients / MFMA operands in bf16
+# (the HIP path in its bench configuration, or the reference under bf16 autocast) computes, up to where exactly it rounds; the one- and
+# two-channel edge head and the loss stay float32 like in the HIP path.  It separates "error inherent to bf16 storage" from
+# "error of the implementation" in tests/test_hip_parity_bf16.py.
+_BF16_EMU = False
+
+
+class bf16_storage:
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _BF16_EMU
+        self.prev, _BF16_EMU = _BF16_EMU, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _BF16_EMU
+        _BF16_EMU = self.prev
+
+
+class _RoundBoth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _RoundFwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _q(x):
+    """stored activation: value and gradient live in bf16"""
+    return _RoundBoth.apply(x) if _BF16_EMU else x
+
+
+def _qw(w):
+    """weight operand: rounded for the multiply, gradient kept in float32 (master weights are float32)"""
+    return _RoundFwd.apply(w) if _BF16_EMU else w
+
 
 class dp_shards:
     """context manager: interpret the batch as K per-replica shards"""
@@ -90,26 +142,26 @@ def _bn(sd, pre, x, training, momentum=BN_MOM):
     k = _DP_SHARDS
     if k > 1 and training:
         if momentum == SYNCBN_MOM and (pre + "._running_iter") in sd:
-            return _sync_bn_train(sd, pre, x, momentum)
+            return _q(_sync_bn_train(sd, pre, x, momentum))
         b = x.shape[0] // k
         outs = []
         for r in range(k):       # replica r: local statistics; only replica 0's running-statistic update survives
             outs.append(F.batch_norm(x[r * b:(r + 1) * b], rm if r == 0 else rm.clone(), rv if r == 0 else rv.clone(),
                                      sd[pre + ".weight"], sd[pre + ".bias"], True, momentum, BN_EPS))
-        return torch.cat(outs, 0)
-    return F.batch_norm(x, rm, rv, sd[pre + ".weight"], sd[pre + ".bias"], training, momentum, BN_EPS)
+        return _q(torch.cat(outs, 0))
+    return _q(F.batch_norm(x, rm, rv, sd[pre + ".weight"], sd[pre + ".bias"], training, momentum, BN_EPS))
 
 
 def _conv(sd, pre, x, stride=1, padding=0):
-    return F.conv2d(x, sd[pre + ".weight"], sd.get(pre + ".bias"), stride, padding)
+    return _q(F.conv2d(x, _qw(sd[pre + ".weight"]), sd.get(pre + ".bias"), stride, padding))
 
 
 def _convT(sd, pre, x):
-    return F.conv_transpose2d(x, sd[pre + ".weight"], sd.get(pre + ".bias"), stride=2, padding=1)
+    return _q(F.conv_transpose2d(x, _qw(sd[pre + ".weight"]), sd.get(pre + ".bias"), stride=2, padding=1))
 
 
 def _up(x, size=None, scale=None):
-    return F.interpolate(x, size=size, scale_factor=scale, mode="bilinear", align_corners=True)
+    return _q(F.interpolate(x, size=size, scale_factor=scale, mode="bilinear", align_corners=True))
 
 
 # ----------------------------------------------------------------------------- encoder
@@ -124,7 +176,7 @@ def dense_block(sd, pre, x, nlayers, training):
 
 
 def transition(sd, pre, x, training):
-    return F.avg_pool2d(_conv(sd, pre + ".conv", F.relu(_bn(sd, pre + ".norm", x, training))), 2, 2)
+    return _q(F.avg_pool2d(_conv(sd, pre + ".conv", F.relu(_bn(sd, pre + ".norm", x, training))), 2, 2))
 
 
 def encoder(sd, x, training, pre="encoder.features"):
@@ -140,7 +192,7 @@ def encoder(sd, x, training, pre="encoder.features"):
 def basic_block(sd, pre, x, training):
     y = F.relu(_bn(sd, pre + ".bn1", _conv(sd, pre + ".conv1", x, padding=1), training, SYNCBN_MOM))
     y = _bn(sd, pre + ".bn2", _conv(sd, pre + ".conv2", y, padding=1), training, SYNCBN_MOM)
-    return F.relu(y + x)
+    return _q(F.relu(y + x))
 
 
 def gated_conv(sd, pre, feat, gate, training):
@@ -148,7 +200,7 @@ def gated_conv(sd, pre, feat, gate, training):
     a = _bn(sd, g + ".0", torch.cat([feat, gate], 1), training)
     a = F.relu(_conv(sd, g + ".1", a))
     a = torch.sigmoid(_bn(sd, g + ".4", _conv(sd, g + ".3", a), training))
-    return F.conv2d(feat * (a + 1), sd[pre + ".weight"], sd.get(pre + ".bias")), a
+    return _q(F.conv2d(_q(feat * (a + 1)), _qw(sd[pre + ".weight"]), sd.get(pre + ".bias"))), a
 
 
 def conv3x3_bn_relu(sd, pre, x, training):
@@ -171,7 +223,7 @@ def dual_att_block(sd, pre, low, skip, training):
     fused = conv3x3_bn_relu(sd, pre + ".c3x3rb", torch.cat([skip, up], 1), training)
     spatial = spatial_attention(sd, pre + ".spatialAttn", fused, training)
     channel = se_module(sd, pre + ".channelAttn", fused)
-    return (spatial + 1) * channel, spatial
+    return _q((spatial + 1) * channel), spatial
 
 
 def decoder_block(sd, pre, x, training):
@@ -203,11 +255,13 @@ def saunet_forward(sd, x, training=True, return_att=False, canny=None):
 
     if canny is None:
         canny = canny_branch(x)
-    acts = torch.sigmoid(_conv(sd, "cw", torch.cat([edge_out, canny.to(edge_out.dtype)], 1)))
-    edge = F.relu(_bn(sd, "expand.1", _conv(sd, "expand.0", acts), training))
+    with bf16_storage(False):        # the one/two-channel edge head is float32 in every storage mode (saunet_amd/modules.py: SAUNet.forward)
+        acts = torch.sigmoid(_conv(sd, "cw", torch.cat([edge_out, canny.to(edge_out.dtype)], 1)))
+        edge = _bn(sd, "expand.1", _conv(sd, "expand.0", acts), training)
+    edge = _q(F.relu(edge))
 
     conv2u, conv3u, conv4u = _up(conv2, scale=2), _up(conv3, scale=2), _up(conv4, scale=2)
-    center = conv3x3_bn_relu(sd, "center", F.max_pool2d(conv5, 2, 2), training)
+    center = conv3x3_bn_relu(sd, "center", _q(F.max_pool2d(conv5, 2, 2)), training)
     dec5, att5 = dual_att_block(sd, "dec5", center, conv5, training)
     dec4, att4 = dual_att_block(sd, "dec4", dec5, conv4u, training)
     dec3, att3 = dual_att_block(sd, "dec3", dec4, conv3u, training)
@@ -266,13 +320,14 @@ def dp_emulate_step(sd, shards, training=True):
     b = shards[0][0].shape[0]
     assert all(s[0].shape[0] == b for s in shards), "equal shards (drop_last=True, train.py:252)"
     image = torch.cat([s[0] for s in shards]); seg_t = torch.cat([s[1] for s in shards]); edge_t = torch.cat([s[2] for s in shards])
-    # SyncBN bookkeeping buffers as the reference constructor leaves them (batchnorm.py:50-54), if the state dict lacks them
+    # SyncBN bookkeeping buffers as the reference CONSTRUCTOR leaves them (batchnorm.py:50-54: running_mean = 0, running_var = 1,
+    # iter = 1 at that point) when the state dict lacks them -- what load_state_dict(strict=False) of such a checkpoint gives
     for key in list(sd.keys()):
         if key.endswith(".running_mean") and key.split(".")[0] in ("res1", "res2", "res3"):
             pre = key[:-len(".running_mean")]
             sd.setdefault(pre + "._running_iter", torch.ones(1))
-            sd.setdefault(pre + "._tmp_running_mean", sd[key].clone() * sd[pre + "._running_iter"])
-            sd.setdefault(pre + "._tmp_running_var", sd[pre + ".running_var"].clone() * sd[pre + "._running_iter"])
+            sd.setdefault(pre + "._tmp_running_mean", torch.zeros_like(sd[key]))
+            sd.setdefault(pre + "._tmp_running_var", torch.ones_like(sd[key]))
     with dp_shards(k):
         logits, edge = saunet_forward(sd, image, training)
     losses = [dual_loss(logits[r * b:(r + 1) * b], edge[r * b:(r + 1) * b], seg_t[r * b:(r + 1) * b], edge_t[r * b:(r + 1) * b])

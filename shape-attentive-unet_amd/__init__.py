@@ -9,8 +9,10 @@ from . import functional  # noqa: F401
 from .modules import (  # noqa: F401
     SAUNet, SegmentationModule, SegmentationModuleBase, ModelBuilder, DualLoss, DualAttBlock, SEModule,
     SpatialAttentionBlock, GatedSpatialConv2d, BasicBlock, DecoderBlock, conv3x3_bn_relu, ConvBNReLU, Norm2d,
-    SynchronizedBatchNorm2d, DenseNet121, densenet121, set_compute_dtype, get_compute_dtype)
+    SynchronizedBatchNorm2d, DenseNet121, densenet121, set_compute_dtype, get_compute_dtype, AdaptiveAvgMaxPool2d,
+    adaptive_avgmax_pool2d, pooling_factor)
 from . import optim  # noqa: F401
 from . import dp  # noqa: F401
+from . import graph  # noqa: F401
 
 __version__ = "0.1.0"

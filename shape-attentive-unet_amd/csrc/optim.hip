@@ -61,6 +61,26 @@ __global__ __launch_bounds__(256) void radam_kernel(saunet_tensor_list tl, const
     }
 }
 
+// hyper (Adam):  [0] beta1 [1] beta2 [2] eps [3] weight_decay (L2, added to the gradient) [4] lr / (1 - beta1^t) [5] 1 / sqrt(1 - beta2^t)
+//                [6] grad_scale     -- torch.optim.Adam (amsgrad=False) as /root/reference/train.py:197-201 builds it
+__global__ __launch_bounds__(256) void adam_kernel(saunet_tensor_list tl, const float* __restrict__ hyper)
+{
+    const int t = blockIdx.y;
+    float* p = (float*)tl.ptrs[0][t]; const float* g = (const float*)tl.ptrs[1][t];
+    float* ea = (float*)tl.ptrs[2][t]; float* es = (float*)tl.ptrs[3][t];
+    const long n = tl.numel[t];
+    const float b1 = hyper[0], b2 = hyper[1], eps = hyper[2], wd = hyper[3], step = hyper[4], rbc2 = hyper[5], gs = hyper[6];
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float w = p[i];
+        float gr = g[i] * gs;
+        if (wd != 0.f) gr = fmaf(wd, w, gr);
+        const float m = b1 * ea[i] + (1.f - b1) * gr;
+        const float v = b2 * es[i] + (1.f - b2) * gr * gr;
+        ea[i] = m; es[i] = v;
+        p[i] = w - step * m / (sqrtf(v) * rbc2 + eps);
+    }
+}
+
 __global__ __launch_bounds__(256) void bucket_copy_kernel(saunet_tensor_list tl, int pack, float scale)
 {
     const int t = blockIdx.y;
@@ -93,6 +113,14 @@ int saunet_radam_step(const saunet_tensor_list* tl, const float* hyper, void* st
     if (tl->count <= 0 || tl->count > 96) return set_error(SAUNET_BAD_SHAPE, "radam: %d tensors", tl->count);
     hipLaunchKernelGGL(radam_kernel, dim3(128, tl->count), dim3(256), 0, (hipStream_t)stream, *tl, hyper);
     SAUNET_CHECK_LAUNCH("radam_step");
+    return SAUNET_OK;
+}
+
+int saunet_adam_step(const saunet_tensor_list* tl, const float* hyper, void* stream)
+{
+    if (tl->count <= 0 || tl->count > 96) return set_error(SAUNET_BAD_SHAPE, "adam: %d tensors", tl->count);
+    hipLaunchKernelGGL(adam_kernel, dim3(128, tl->count), dim3(256), 0, (hipStream_t)stream, *tl, hyper);
+    SAUNET_CHECK_LAUNCH("adam_step");
     return SAUNET_OK;
 }
 

@@ -1016,6 +1016,48 @@ def dual_att_tail(F, S, fc1, fc2):
     return _DualAttTail.apply(F, S, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
 
 
+POOL_MODES = {"avg": 0, "max": 1, "avgmax": 2, "avgmaxc": 3}
+
+
+class _GlobalPool(torch.autograd.Function):
+    """adaptive_avgmax_pool2d (models/adaptive_avgmax_pool.py:19-40): global avg / max / avgmax / avgmaxc in one pass."""
+
+    @staticmethod
+    def forward(ctx, x, mode):
+        x = nhwc(x)
+        _check_dev(x)
+        n, c, h, w = x.shape
+        dev = x.device
+        out = torch.empty(n, c * (2 if mode == 3 else 1), dtype=torch.float32, device=dev)
+        arg = torch.empty(n, c, dtype=torch.int32, device=dev) if mode != 0 else None
+        need = L.load().saunet_global_pool_workspace(n, h * w, c)
+        ws = torch.empty(max(need, 4) // 4, dtype=torch.float32, device=dev)
+        L.call("saunet_global_pool_forward", L.dtype_code(x), mode, x.data_ptr(), n, h * w, c, ld_of(x), out.data_ptr(), L.ptr(arg),
+               ws.data_ptr(), need, L.stream())
+        ctx.save_for_backward(arg if arg is not None else out.new_empty(0))
+        ctx.cfg = (mode, n, c, h, w, x.dtype)
+        return out.view(n, -1, 1, 1).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        mode, n, c, h, w, dtype = ctx.cfg
+        dy = dy.reshape(n, -1).to(torch.float32).contiguous()
+        dx = new_act(n, c, h, w, dtype, dy.device)
+        L.call("saunet_global_pool_backward", L.dtype_code(dx), mode, dy.data_ptr(), arg.data_ptr() if mode != 0 else None, n, h * w, c,
+               dx.data_ptr(), ld_of(dx), L.stream())
+        return dx, None
+
+
+def adaptive_avgmax_pool2d(x, pool_type="avg"):
+    """[N,C,H,W] -> [N,C,1,1] ('avg', 'max', 'avgmax') or [N,2C,1,1] ('avgmaxc'); an unknown pool_type falls back to 'avg' with the
+    reference's message (adaptive_avgmax_pool.py:35-37)."""
+    if pool_type not in POOL_MODES:
+        print("Invalid pool type %s specified. Defaulting to average pooling." % pool_type)
+        pool_type = "avg"
+    return _GlobalPool.apply(x, POOL_MODES[pool_type])
+
+
 def _as_f32(t):
     t = nhwc(t)
     if t.dtype == torch.float32:

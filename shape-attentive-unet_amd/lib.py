@@ -76,6 +76,9 @@ _SIGS = {
     "saunet_expand_forward": [i32, vp, i64, i32, vp, vp, i32, i32, vp],
     "saunet_expand_backward": [i32, vp, i32, vp, i64, i32, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "saunet_global_avgpool": [i32, vp, i32, i32, i32, i32, vp, vp],
+    "saunet_global_pool_workspace": [i32, i32, i32],
+    "saunet_global_pool_forward": [i32, i32, vp, i32, i32, i32, i32, vp, vp, vp, i64, vp],
+    "saunet_global_pool_backward": [i32, i32, vp, vp, i32, i32, i32, vp, i32, vp],
     "saunet_se_excite": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "saunet_se_excite_backward": [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "saunet_att_combine_forward": [i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp],
@@ -88,6 +91,7 @@ _SIGS = {
     "saunet_mask_to_edges": [vp, i32, i32, i32, i32, vp, vp],
     "saunet_sgd_step": [C.POINTER(TensorList), vp, vp],
     "saunet_radam_step": [C.POINTER(TensorList), vp, vp],
+    "saunet_adam_step": [C.POINTER(TensorList), vp, vp],
     "saunet_bucket_copy": [C.POINTER(TensorList), i32, f32, vp],
 }
 EXPORTS = sorted(list(_SIGS) + ["saunet_last_error", "saunet_version"])

@@ -216,6 +216,39 @@ class DecoderBlock(nn.Module):
         return HF.conv_bn_act(b[0](x), b[1].weight, b[1].bias, b[2], relu=True, transposed=True)
 
 
+# ------------------------------------------------------------------------------------------------ selectable global pooling
+def pooling_factor(pool_type="avg"):
+    return 2 if pool_type == "avgmaxc" else 1
+
+
+def adaptive_avgmax_pool2d(x, pool_type="avg", padding=0, count_include_pad=False):
+    """models/adaptive_avgmax_pool.py:19-40 (global pooling: the kernel is the whole map, so padding must be 0)."""
+    if padding != 0:
+        raise NotImplementedError("global pooling over the whole map: padding=0")
+    return HF.adaptive_avgmax_pool2d(x, pool_type)
+
+
+class AdaptiveAvgMaxPool2d(nn.Module):
+    """models/adaptive_avgmax_pool.py:43-74 with output_size=1."""
+
+    def __init__(self, output_size=1, pool_type="avg"):
+        super().__init__()
+        if output_size not in (1, (1, 1)):
+            raise NotImplementedError("AdaptiveAvgMaxPool2d: output_size=1 (global pooling)")
+        self.output_size, self.pool_type = output_size, pool_type
+        if pool_type not in HF.POOL_MODES:
+            print("Invalid pool type %s specified. Defaulting to average pooling." % pool_type)
+
+    def forward(self, x):
+        return HF.adaptive_avgmax_pool2d(x, self.pool_type if self.pool_type in HF.POOL_MODES else "avg")
+
+    def factor(self):
+        return pooling_factor(self.pool_type)
+
+    def __repr__(self):
+        return self.__class__.__name__ + " (output_size=" + str(self.output_size) + ", pool_type=" + self.pool_type + ")"
+
+
 # ------------------------------------------------------------------------------------------------ DenseNet-121 encoder
 class _DenseLayer(nn.Module):
     def __init__(self, cin, growth, bn_size):

@@ -192,12 +192,52 @@ class FusedRAdam(_FusedBase):
         HF.PACKS.invalidate()
 
 
+class FusedAdam(_FusedBase):
+    """torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False) as /root/reference/train.py:197-201 builds it."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    _group_step = FusedRAdam._group_step
+
+    def upload_hyper(self):
+        for g in self.param_groups:
+            step = self._group_step(g) + 1
+            b1, b2 = g["betas"]
+            self._upload(g, [b1, b2, g["eps"], g["weight_decay"], g["lr"] / (1.0 - b1 ** step), 1.0 / math.sqrt(1.0 - b2 ** step),
+                             self.grad_scale, 0])
+
+    @torch.no_grad()
+    def step(self, closure=None, upload=True):
+        if upload:
+            self.upload_hyper()
+        for g in self.param_groups:
+            ps = self._live(g)
+            if not ps:
+                continue
+            ea, es = [], []
+            for p in ps:
+                st = self.state[p]
+                if "exp_avg" not in st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                ea.append(st["exp_avg"]); es.append(st["exp_avg_sq"])
+            for tl in _tensor_lists([ps, [p.grad for p in ps], ea, es]):
+                L.call("saunet_adam_step", C.byref(tl), self._hyper(g).data_ptr(), L.stream())
+            for p in ps:
+                self.state[p]["step"] += 1
+        HF.PACKS.invalidate()
+
+
 def create_optimizers(unet, optimizer="sgd", lr=5e-4, momentum=0.9, weight_decay=1e-4):
     """train.py:187-207 (defaults = train.py's argparse defaults)."""
     groups = group_weight(unet)
     name = optimizer.lower()
     if name == "sgd":
         return [FusedSGD(groups, lr=lr, momentum=momentum, weight_decay=weight_decay)]
+    if name == "adam":
+        return [FusedAdam(groups, lr=lr, betas=(0.9, 0.999))]
     if name == "radam":
         return [FusedRAdam(groups, lr=lr, betas=(0.9, 0.999))]
-    raise ValueError("optimizer %s: the fused path provides sgd and radam" % optimizer)
+    raise ValueError("optimizer %s: train.py:187-207 knows sgd, adam and radam" % optimizer)

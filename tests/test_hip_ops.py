@@ -320,3 +320,32 @@ def test_mask_to_edges_on_device_matches_loader_and_reference_fixture():
     rnd_seg = torch.from_numpy(r.integers(0, 4, (2, 40, 56)))
     want = np.stack([R.mask_to_edges(s.numpy()) for s in rnd_seg])
     assert (hf.mask_to_edges(rnd_seg.cuda()).cpu().numpy() == want).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("pool_type", ["avg", "max", "avgmax", "avgmaxc"])
+@pytest.mark.parametrize("shape", [(2, 16, 8, 8), (3, 24, 16, 48), (2, 7, 5, 9)])
+def test_adaptive_avgmax_pool_kat(dtype, pool_type, shape):
+    """models/adaptive_avgmax_pool.py:19-40 restated with torch CPU ops (the reference file is never imported by its own training path;
+    SURVEY 8 A16): forward values and the gradient, including max ties (first occurrence wins, like F.max_pool2d)."""
+    import torch.nn.functional as F
+    import saunet_amd as S
+    torch.manual_seed(sum(shape))
+    x = torch.randn(*shape).to(dtype).float()
+    x[0, 0, 0, 0] = x[0, 0].max() + 1.0; x[0, 0, -1, -1] = x[0, 0, 0, 0]          # an exact tie for the maximum
+    xr = x.clone().requires_grad_(True)
+    k = (shape[2], shape[3])
+    avg, mx = F.avg_pool2d(xr, k), F.max_pool2d(xr, k)
+    want = {"avg": avg, "max": mx, "avgmax": 0.5 * (avg + mx), "avgmaxc": torch.cat([avg, mx], 1)}[pool_type]
+    cot = torch.randn_like(want)
+    (want * cot).sum().backward()
+    xh = x.to(dtype).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    got = S.adaptive_avgmax_pool2d(xh, pool_type)
+    assert got.shape == want.shape
+    (got.float() * cot.cuda()).sum().backward()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert float((got.float().cpu() - want).abs().max()) < tol * max(1.0, float(want.abs().max()))
+    assert float((xh.grad.float().cpu() - xr.grad).abs().max()) < tol * max(1.0, float(xr.grad.abs().max()))
+    m = S.AdaptiveAvgMaxPool2d(1, pool_type)
+    assert m.factor() == (2 if pool_type == "avgmaxc" else 1)
+    assert torch.equal(m(xh.detach()), got.detach())

@@ -115,3 +115,43 @@ def test_graph_replays_follow_the_eager_trajectory(dtype):
         assert float((got - ref_eval).abs().max()) < (1e-3 if dtype == torch.float32 else 6e-2) * scale
     finally:
         S.set_compute_dtype(torch.float32)
+
+
+def test_fused_adam_matches_torch_adam():
+    """fused Adam kernel against torch.optim.Adam on the CPU (float64), 8 steps, the construction of train.py:197-201 (no weight decay)
+    plus one run with L2 weight decay."""
+    from saunet_amd.optim import FusedAdam
+    for wd in (0.0, 1e-2):
+        torch.manual_seed(1)
+        p = torch.nn.Parameter(torch.randn(1537, device="cuda"))
+        q = torch.nn.Parameter(p.detach().cpu().double())
+        opt = FusedAdam([p], lr=1e-2, weight_decay=wd)
+        ref = torch.optim.Adam([q], lr=1e-2, betas=(0.9, 0.999), weight_decay=wd)
+        for step in range(8):
+            g = torch.randn(1537, device="cuda")
+            p.grad = g.clone(); q.grad = g.cpu().double()
+            opt.step(); ref.step()
+            assert float((p.detach().cpu().double() - q.detach()).abs().max()) < 2e-6, (wd, step)
+    sd = opt.state_dict()
+    assert set(sd["param_groups"][0].keys()) >= {"lr", "betas", "eps", "weight_decay", "params"}
+    assert not any(k.startswith("_") for k in sd["param_groups"][0])          # no private bookkeeping leaks into checkpoints
+
+
+def test_fused_sgd_state_dict_roundtrip_keeps_momentum():
+    """optimizer.state_dict() holds only torch-style entries; a resumed FusedSGD continues with the loaded momentum buffers."""
+    from saunet_amd.optim import FusedSGD
+    torch.manual_seed(2)
+    p = torch.nn.Parameter(torch.randn(300, device="cuda"))
+    q = torch.nn.Parameter(p.detach().clone())
+    a = FusedSGD([p], lr=0.1, momentum=0.9)
+    ref = torch.optim.SGD([q], lr=0.1, momentum=0.9)
+    gs = [torch.randn(300, device="cuda") for _ in range(4)]
+    for g in gs[:2]:
+        p.grad = g.clone(); q.grad = g.clone(); a.step(); ref.step()
+    sd = a.state_dict()
+    assert not any(k.startswith("_") for k in sd["param_groups"][0])
+    b = FusedSGD([p], lr=0.1, momentum=0.9)
+    b.load_state_dict(sd)
+    for g in gs[2:]:
+        p.grad = g.clone(); q.grad = g.clone(); b.step(); ref.step()
+    assert float((p.detach() - q.detach()).abs().max()) < 1e-5
