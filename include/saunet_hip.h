@@ -125,6 +125,10 @@ int saunet_syncbn_finalize(int C, const double* sum, const double* sumsq, int re
 /* y = act(x*scale+shift (+residual)) */
 int saunet_affine_act(int dtype, const void* x, int ldx, const float* scale, const float* shift,
                       const void* residual, int ldr, int relu, void* y, int ldy, int64_t pixels, int C, void* stream);
+/* y = act(x*scale+shift) AND pooled[n][c] = mean over the image's H*W pixels of y (the SE squeeze, attention_blocks.py:32,50) in the
+ * same pass; pooled [pixels/HW][C] float32 is zeroed here.  Vector path only (C, strides multiples of 8 bf16 / 4 f32 elements). */
+int saunet_affine_act_pool(int dtype, const void* x, int ldx, const float* scale, const float* shift, int relu, void* y, int ldy,
+                           int64_t pixels, int C, float* pooled, int HW, void* stream);
 /* g = dy * [out>0] where out = x*scale+shift(+residual) (if relu);  sums[0:C] += sum g,
  * sums[C:2C] += sum g*xhat  with xhat = (x-mean)*invstd   (float64 atomics, zeroed by caller) */
 int saunet_bn_backward_reduce(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,

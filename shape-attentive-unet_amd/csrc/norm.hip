@@ -186,6 +186,58 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x
     }
 }
 
+// affine_act with the SE squeeze fused in: while the normalised + activated tensor F = act(x*scale+shift) is written, its global
+// average pool over H x W (nn.AdaptiveAvgPool2d(1) of SEModule, /root/reference/models/attention_blocks.py:32,50) is accumulated:
+// per-thread sums -> LDS (two images at most per block: rpb <= HW) -> one float atomic per (image, channel) per block into the zeroed
+// pooled[N][C], already scaled by 1/HW.  F is never re-read for the pool.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void affine_act_pool_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int relu, T* __restrict__ y, int ldy, long P, int C,
+                                                              long rpb, float* __restrict__ pooled, int HW)
+{
+    extern __shared__ float s_pool[];   // [2][C]
+    for (int i = threadIdx.x; i < 2 * C; i += 256) s_pool[i] = 0.f;
+    __syncthreads();
+    const long p0 = blockIdx.x * rpb, p1 = min(p0 + rpb, P);
+    const long n0 = p0 / HW, boundary = (n0 + 1) * (long)HW;
+    const int CH = C / V;
+    for (int cb = 0; cb < CH; cb += 256) {
+        const int cw = min(256, CH - cb), rl = 256 / cw;
+        const int ch = cb + threadIdx.x % cw, r0 = threadIdx.x / cw;
+        if (r0 >= rl) continue;
+        float s[V], t[V], a0[V], a1[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { s[j] = scale[ch * V + j]; t[j] = shift[ch * V + j]; a0[j] = a1[j] = 0.f; }
+        for (long p = p0 + r0; p < p1; p += rl) {
+            float f[V];
+            ChunkIO<T, V>::load(x + p * ldx + ch * V, f);
+            const bool first = p < boundary;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float v = fmaf(f[j], s[j], t[j]);
+                v = relu ? fmaxf(v, 0.f) : v;
+                f[j] = v;
+            }
+            if constexpr (sizeof(T) == 2) {      // pool what the consumers will read: the bf16-rounded values
+                const u32x4 q = Vec16<T>::pack(f);
+                *(u32x4*)(y + p * ldy + ch * V) = q;
+                Vec16<T>::unpack(q, f);
+            } else ChunkIO<T, V>::store(y + p * ldy + ch * V, f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { if (first) a0[j] += f[j]; else a1[j] += f[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) { atomicAdd(&s_pool[ch * V + j], a0[j]); atomicAdd(&s_pool[C + ch * V + j], a1[j]); }
+    }
+    __syncthreads();
+    const float inv = 1.f / (float)HW;
+    const bool two = p1 > boundary;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomicAdd(&pooled[n0 * C + c], s_pool[c] * inv);
+        if (two) atomicAdd(&pooled[(n0 + 1) * C + c], s_pool[C + c] * inv);
+    }
+}
+
 struct BnBwdArgs {
     const void* dy; int lddy; const void* x; int ldx; const void* res; int ldr;
     const float* scale; const float* shift; const float* mean; const float* invstd; int relu;
@@ -429,6 +481,26 @@ int saunet_affine_act(int dtype, const void* x, int ldx, const float* scale, con
     DISPATCH_TV(dtype, vec, CALL);
 #undef CALL
     SAUNET_CHECK_LAUNCH("affine_act");
+    return SAUNET_OK;
+}
+
+int saunet_affine_act_pool(int dtype, const void* x, int ldx, const float* scale, const float* shift, int relu, void* y, int ldy,
+                           int64_t pixels, int C, float* pooled, int HW, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!scale || !shift || !pooled || HW <= 0 || pixels % HW) return set_error(SAUNET_BAD_SHAPE, "affine_act_pool: needs scale/shift/pooled and pixels %% HW == 0");
+    const int epc = dtype == SAUNET_BF16 ? 8 : 4;
+    if (!vec_ok(dtype, C, {ldx, ldy}, {x, y})) return set_error(SAUNET_BAD_ALIGN, "affine_act_pool: C, strides multiples of %d and 16-byte aligned views", epc);
+    int blocks;
+    long rpb = rows_per_block(pixels, C, epc, &blocks);
+    if (rpb > HW) rpb = HW;                       // a block touches two images at most
+    blocks = (int)((pixels + rpb - 1) / rpb);
+    if (hipMemsetAsync(pooled, 0, sizeof(float) * (size_t)(pixels / HW) * C, st) != hipSuccess) return set_error(SAUNET_LAUNCH_FAILED, "affine_act_pool memset");
+    const size_t lds = sizeof(float) * 2 * C;
+    if (dtype == SAUNET_BF16) hipLaunchKernelGGL((affine_act_pool_kernel<u16, 8>), dim3(blocks), dim3(256), lds, st, (const u16*)x, ldx, scale, shift, relu, (u16*)y, ldy, (long)pixels, C, rpb, pooled, HW);
+    else if (dtype == SAUNET_F32) hipLaunchKernelGGL((affine_act_pool_kernel<float, 4>), dim3(blocks), dim3(256), lds, st, (const float*)x, ldx, scale, shift, relu, (float*)y, ldy, (long)pixels, C, rpb, pooled, HW);
+    else return set_error(SAUNET_BAD_DTYPE, "dtype %d", dtype);
+    SAUNET_CHECK_LAUNCH("affine_act_pool");
     return SAUNET_OK;
 }
 

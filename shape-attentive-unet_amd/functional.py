@@ -460,11 +460,21 @@ def bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum, eps, training,
     return p
 
 
-def affine_act(x, scale, shift, relu, residual=None, out=None):
+def affine_act(x, scale, shift, relu, residual=None, out=None, pool=None):
+    """pool: optional float32 [N, C] tensor that receives the global average pool of the OUTPUT (SE squeeze fused into this pass)"""
     x = nhwc(x)
     n, c, h, w = x.shape
     if out is None:
         out = new_act(n, c, h, w, x.dtype, x.device)
+    if pool is not None:
+        epc = 8 if x.dtype == torch.bfloat16 else 4
+        if residual is None and c % epc == 0 and ld_of(x) % epc == 0 and ld_of(out) % epc == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0:
+            L.call("saunet_affine_act_pool", L.dtype_code(x), x.data_ptr(), ld_of(x), scale.data_ptr(), shift.data_ptr(), 1 if relu else 0,
+                   out.data_ptr(), ld_of(out), n * h * w, c, pool.data_ptr(), h * w, L.stream())
+            return out
+        out = affine_act(x, scale, shift, relu, residual, out)
+        L.call("saunet_global_avgpool", L.dtype_code(out), out.data_ptr(), n, h * w, c, ld_of(out), pool.data_ptr(), L.stream())
+        return out
     if residual is not None:
         residual = nhwc(residual)
     L.call("saunet_affine_act", L.dtype_code(x), x.data_ptr(), ld_of(x), L.ptr(scale), L.ptr(shift), L.ptr(residual),
@@ -564,7 +574,7 @@ class _ConvBNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, rmean, rvar, residual, stride, pad, transposed, relu, momentum, eps, training, group,
-                sync_bufs=None):
+                sync_bufs=None, out=None, pool=None):
         x = nhwc(x)
         cout = weight.shape[1] if transposed else weight.shape[0]
         stats = new_stats(cout, x.device) if training else None
@@ -587,7 +597,7 @@ class _ConvBNAct(torch.autograd.Function):
                    p.scale.data_ptr(), p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), L.stream())
         else:
             p = bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum, eps, training, conv_bias=bias)
-        y = affine_act(z, p.scale, p.shift, relu, residual)
+        y = affine_act(z, p.scale, p.shift, relu, residual, out=out, pool=pool)
         ctx.save_for_backward(x, weight, z, p.buf, residual if residual is not None else z.new_empty(0))
         ctx.cfg = (stride, pad, transposed, relu, training, count, bias is not None, residual is not None, group)
         return y
@@ -607,11 +617,13 @@ class _ConvBNAct(torch.autograd.Function):
             # a bias in front of a training-mode BatchNorm has an exactly zero gradient (sum of dz over the batch is 0)
             cout = dz.shape[1]
             db = torch.zeros(cout, dtype=torch.float32, device=dz.device) if training else channel_sum(dz)
-        return dx, dw, db, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
-def conv_bn_act(x, weight, bias, bn, relu=True, residual=None, stride=1, padding=0, transposed=False):
+def conv_bn_act(x, weight, bias, bn, relu=True, residual=None, stride=1, padding=0, transposed=False, out=None, pool=None):
     """bn: an nn.BatchNorm2d-like module (weight, bias, running_mean, running_var, momentum, eps, training).
+    out: optional destination (a channel slice of a concat buffer -- see cat_alias).
+    pool: optional float32 [N, Cout] tensor that receives the global average pool of the result (the SE squeeze rides on the BN-apply pass).
     A bn with a truthy ``sync`` attribute (SynchronizedBatchNorm2d) reduces its statistics over the default
     process group when one with more than one rank exists."""
     _bump(bn)
@@ -623,28 +635,31 @@ def conv_bn_act(x, weight, bias, bn, relu=True, residual=None, stride=1, padding
         p = bn_finalize(None, 1, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, False)
         wf = weight * (p.scale.view(1, -1, 1, 1) if transposed else p.scale.view(-1, 1, 1, 1))
         bf = p.shift if bias is None else torch.addcmul(p.shift, bias, p.scale)
-        return conv_forward_raw(x, wf, bf, stride, padding, transposed, act_relu=relu)
+        y = conv_forward_raw(x, wf, bf, stride, padding, transposed, act_relu=relu, out=out)
+        if pool is not None:
+            L.call("saunet_global_avgpool", L.dtype_code(y), y.data_ptr(), y.shape[0], y.shape[2] * y.shape[3], y.shape[1], ld_of(y), pool.data_ptr(), L.stream())
+        return y
     group, sync_bufs = None, None
     if getattr(bn, "sync", False) and bn.training and torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size() > 1:
         group = torch.distributed.group.WORLD
         sync_bufs = (bn._tmp_running_mean, bn._tmp_running_var, bn._running_iter)
     return _ConvBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, stride, padding,
-                            transposed, relu, bn.momentum, bn.eps, bn.training, group, sync_bufs)
+                            transposed, relu, bn.momentum, bn.eps, bn.training, group, sync_bufs, out, pool)
 
 
 class _BNAct(torch.autograd.Function):
     """Stand-alone BatchNorm (+ReLU) over a materialised tensor; optional precomputed statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, stats, relu, momentum, eps, training):
+    def forward(ctx, x, gamma, beta, rmean, rvar, stats, relu, momentum, eps, training, out=None):
         x = nhwc(x)
         n, c, h, w = x.shape
         count = n * h * w
         if training and stats is None:
             stats = bn_stats(x)
         p = bn_finalize(stats if training else None, count, gamma, beta, rmean, rvar, momentum, eps, training)
-        y = affine_act(x, p.scale, p.shift, relu)
+        y = affine_act(x, p.scale, p.shift, relu, out=out)
         ctx.save_for_backward(x, p.buf)
         ctx.cfg = (relu, training, count)
         return y
@@ -655,20 +670,20 @@ class _BNAct(torch.autograd.Function):
         relu, training, count = ctx.cfg
         p = BNParams.__new__(BNParams); p.buf = pbuf
         dx, _, dgamma, dbeta = bn_backward(dy, x, p, relu, count, training)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
-def batch_norm_act(x, bn, relu=False, stats=None):
+def batch_norm_act(x, bn, relu=False, stats=None, out=None):
     _bump(bn)
-    return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, stats, relu, bn.momentum, bn.eps, bn.training)
+    return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, stats, relu, bn.momentum, bn.eps, bn.training, out)
 
 
 class _Bilinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, ho, wo):
+    def forward(ctx, x, ho, wo, out=None):
         x = nhwc(x)
         n, c, h, w = x.shape
-        y = new_act(n, c, ho, wo, x.dtype, x.device)
+        y = out if out is not None else new_act(n, c, ho, wo, x.dtype, x.device)
         L.call("saunet_bilinear_forward", L.dtype_code(x), x.data_ptr(), n, h, w, c, ld_of(x), y.data_ptr(), ho, wo, ld_of(y), L.stream())
         ctx.shape = (n, c, h, w)
         return y
@@ -680,14 +695,14 @@ class _Bilinear(torch.autograd.Function):
         dx = new_act(n, c, h, w, dy.dtype, dy.device)
         L.call("saunet_bilinear_backward", L.dtype_code(dy), dy.data_ptr(), n, dy.shape[2], dy.shape[3], c, ld_of(dy), dx.data_ptr(),
                h, w, ld_of(dx), 0, L.stream())
-        return dx, None, None
+        return dx, None, None, None
 
 
-def interpolate_bilinear(x, size=None, scale_factor=None):
-    """F.interpolate(mode='bilinear', align_corners=True)."""
+def interpolate_bilinear(x, size=None, scale_factor=None, out=None):
+    """F.interpolate(mode='bilinear', align_corners=True).  out: optional destination (channel slice of a concat buffer)."""
     if size is None:
         size = (int(x.shape[2] * scale_factor), int(x.shape[3] * scale_factor))
-    return _Bilinear.apply(x, int(size[0]), int(size[1]))
+    return _Bilinear.apply(x, int(size[0]), int(size[1]), out)
 
 
 class _Pool2x2(torch.autograd.Function):
@@ -774,6 +789,37 @@ class _Cat(torch.autograd.Function):
 
 def cat(xs):
     return _Cat.apply(*xs)
+
+
+class _CatAlias(torch.autograd.Function):
+    """torch.cat(dim=1) of tensors that were PRODUCED in place: every xs[i] already is the channel slice [o_i, o_i + C_i) of `buf`
+    (its producer was given that slice as destination), so the forward copies nothing; backward hands out slice views of dy."""
+
+    @staticmethod
+    def forward(ctx, buf, *xs):
+        o, cs = 0, []
+        for x in xs:
+            c = x.shape[1]
+            if x.data_ptr() != buf[:, o:o + c].data_ptr() or ld_of(x) != ld_of(buf) or x.shape[0] != buf.shape[0] or x.shape[2:] != buf.shape[2:]:
+                raise RuntimeError("cat_alias: piece %d is not the slice [%d, %d) of the concat buffer" % (len(cs), o, o + c))
+            cs.append(c); o += c
+        if o != buf.shape[1]:
+            raise RuntimeError("cat_alias: pieces cover %d of %d channels" % (o, buf.shape[1]))
+        ctx.cs = cs
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = nhwc(dy)
+        outs, o = [], 0
+        for c in ctx.cs:
+            outs.append(dy[:, o:o + c])
+            o += c
+        return (None,) + tuple(outs)
+
+
+def cat_alias(buf, xs):
+    return _CatAlias.apply(buf, *xs)
 
 
 class _Cast(torch.autograd.Function):
@@ -916,7 +962,7 @@ class _ExpandBNAct(torch.autograd.Function):
     """Conv2d(1, C, 1x1) -> BatchNorm -> ReLU on a one-channel float32 map as ONE per-pixel affine map (csrc/expand.hip)."""
 
     @staticmethod
-    def forward(ctx, a, w, b, gamma, beta, rmean, rvar, momentum, eps, training, relu, out_dtype):
+    def forward(ctx, a, w, b, gamma, beta, rmean, rvar, momentum, eps, training, relu, out_dtype, out=None):
         a = nhwc(a)
         _check_dev(a)
         if not a.is_contiguous():          # the kernels index the one-channel map as a dense [P] vector
@@ -929,7 +975,7 @@ class _ExpandBNAct(torch.autograd.Function):
         L.call("saunet_expand_coeff", c, stats[0, 0].data_ptr() if training else None, stats[0, 1].data_ptr() if training else None,
                stats.shape[0] if training else 1, stats.stride(0) if training else 0, float(P), w.data_ptr(), L.ptr(b), gamma.data_ptr(),
                beta.data_ptr(), float(eps), float(momentum), L.ptr(rmean), L.ptr(rvar), coef.data_ptr(), mv.data_ptr(), 1 if training else 0, L.stream())
-        y = new_act(n, c, h, wd, out_dtype, dev)
+        y = out if out is not None else new_act(n, c, h, wd, out_dtype, dev)
         L.call("saunet_expand_forward", L.dtype_code(y), a.data_ptr(), P, c, coef.data_ptr(), y.data_ptr(), ld_of(y), 1 if relu else 0, L.stream())
         ctx.save_for_backward(a, coef, mv)
         ctx.cfg = (relu, training, b is not None)
@@ -951,7 +997,7 @@ class _ExpandBNAct(torch.autograd.Function):
         L.call("saunet_expand_backward", L.dtype_code(dy), dy.data_ptr(), ld_of(dy), a.data_ptr(), P, c, coef.data_ptr(), mv.data_ptr(), 1 if relu else 0,
                sums.data_ptr(), sums.shape[0], sums.stride(0), dw.data_ptr(), db.data_ptr(), dg.data_ptr(), dbeta.data_ptr(), D.data_ptr(), da.data_ptr(),
                L.stream())
-        return da, dw.view(c, 1, 1, 1), (db if has_bias else None), dg, dbeta, None, None, None, None, None, None, None
+        return da, dw.view(c, 1, 1, 1), (db if has_bias else None), dg, dbeta, None, None, None, None, None, None, None, None
 
 
 def expand_fusable(x, conv, bn):
@@ -960,23 +1006,24 @@ def expand_fusable(x, conv, bn):
             and x.dtype == torch.float32 and x.is_cuda and (bn.training or not torch.is_grad_enabled()))
 
 
-def expand_bn_act(x, conv, bn, relu=True, out_dtype=None):
+def expand_bn_act(x, conv, bn, relu=True, out_dtype=None, out=None):
     _bump(bn)
     return _ExpandBNAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, bn.training,
-                              relu, out_dtype or x.dtype)
+                              relu, out_dtype or x.dtype, out)
 
 
 class _DualAttTail(torch.autograd.Function):
     """out = (S + 1) * F * sigmoid(fc2(relu(fc1(avgpool(F)))))  (attention_blocks.py:50-57, 237)."""
 
     @staticmethod
-    def forward(ctx, F, S, w1, b1, w2, b2):
+    def forward(ctx, F, S, w1, b1, w2, b2, pooled=None):
         F = nhwc(F); S = nhwc(S)
         n, c, h, w = F.shape
         cr = w1.shape[0]
         dev = F.device
-        pooled = torch.empty(n, c, dtype=torch.float32, device=dev)
-        L.call("saunet_global_avgpool", L.dtype_code(F), F.data_ptr(), n, h * w, c, ld_of(F), pooled.data_ptr(), L.stream())
+        if pooled is None:      # the producer of F did not pool it on the way out: one extra read of F
+            pooled = torch.empty(n, c, dtype=torch.float32, device=dev)
+            L.call("saunet_global_avgpool", L.dtype_code(F), F.data_ptr(), n, h * w, c, ld_of(F), pooled.data_ptr(), L.stream())
         hidden = torch.empty(n, cr, dtype=torch.float32, device=dev)
         se = torch.empty(n, c, dtype=torch.float32, device=dev)
         w1c, w2c = w1.detach().reshape(cr, c), w2.detach().reshape(c, cr)
@@ -1009,11 +1056,12 @@ class _DualAttTail(torch.autograd.Function):
         L.call("saunet_se_excite_backward", pooled.data_ptr(), hidden.data_ptr(), se.data_ptr(), dse.data_ptr(), n, c, cr,
                w1c.data_ptr(), w2c.data_ptr(), dpooled.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), L.stream())
         L.call("saunet_add_pooled_grad", dt, dF.data_ptr(), ld_of(dF), dpooled.data_ptr(), n, h * w, c, L.stream())
-        return dF, dS, dw1.view(w1.shape), db1, dw2.view(w2.shape), db2
+        return dF, dS, dw1.view(w1.shape), db1, dw2.view(w2.shape), db2, None
 
 
-def dual_att_tail(F, S, fc1, fc2):
-    return _DualAttTail.apply(F, S, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
+def dual_att_tail(F, S, fc1, fc2, pooled=None):
+    """pooled: the global average pool of F [N, C] float32 if its producer already computed it (conv_bn_act(..., pool=...))"""
+    return _DualAttTail.apply(F, S, fc1.weight, fc1.bias, fc2.weight, fc2.bias, pooled)
 
 
 POOL_MODES = {"avg": 0, "max": 1, "avgmax": 2, "avgmaxc": 3}

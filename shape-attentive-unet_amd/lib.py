@@ -51,6 +51,7 @@ _SIGS = {
     "saunet_bn_finalize": [i32, vp, vp, i32, i32, f64, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i32, vp],
     "saunet_syncbn_finalize": [i32, vp, vp, i32, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "saunet_affine_act": [i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, i64, i32, vp],
+    "saunet_affine_act_pool": [i32, vp, i32, vp, vp, i32, vp, i32, i64, i32, vp, i32, vp],
     "saunet_bn_backward_reduce": [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, i32, i64, i32, vp],
     "saunet_bn_backward_apply": [i32, vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, i32, f64, i32, i32,
                                  vp, i32, vp, i32, vp, vp, i64, i32, vp],

@@ -76,11 +76,15 @@ class ConvBNReLU(nn.Sequential):
         super().__init__(nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride, padding=padding, bias=bias),
                          nn.BatchNorm2d(out_planes), nn.ReLU(inplace=True))
 
-    def forward(self, x, out_dtype=None):
+    def forward(self, x, out_dtype=None, out=None, pool=None):
+        """out: optional destination (a channel slice of a concat buffer, see HF.cat_alias); ignored where a cast is needed.
+        pool: optional float32 [N, C] tensor receiving the global average pool of the result (SE squeeze fused into the BN-apply pass)."""
         conv, bn = self[0], self[1]
         if HF.expand_fusable(x, conv, bn):
-            return HF.expand_bn_act(x, conv, bn, relu=True, out_dtype=out_dtype)      # 1 -> C broadcast (SAUNet.expand)
-        y = HF.conv_bn_act(x, conv.weight, conv.bias, bn, relu=True, stride=conv.stride[0], padding=conv.padding[0])
+            return HF.expand_bn_act(x, conv, bn, relu=True, out_dtype=out_dtype, out=out)      # 1 -> C broadcast (SAUNet.expand)
+        direct = out is not None and (out_dtype is None or out_dtype == x.dtype)
+        y = HF.conv_bn_act(x, conv.weight, conv.bias, bn, relu=True, stride=conv.stride[0], padding=conv.padding[0], out=out if direct else None,
+                           pool=pool)
         return y if out_dtype is None or out_dtype == y.dtype else HF.cast(y, out_dtype)
 
 
@@ -177,9 +181,15 @@ class _MRF(nn.Module):
                                 nn.BatchNorm2d(inchannels[0]), nn.ReLU(inplace=True))
         _init_conv_bn(self)
 
-    def forward(self, channels):
+    def forward(self, channels, cat_buf=None):
+        """cat_buf: optional preallocated concat buffer [N, C_skip + C_up, H, W] whose first C_skip channels ARE channels[1] (its
+        producer wrote them there); the up-sampled branch is then written next to them and nothing is copied."""
         if len(channels) == 1:
             return channels[0]
+        if cat_buf is not None:
+            cs = channels[1].shape[1]
+            up = HF.conv_bn_act(channels[0], self.up[0].weight, self.up[0].bias, self.up[1], relu=True, transposed=True, out=cat_buf[:, cs:])
+            return HF.cat_alias(cat_buf, [channels[1], up])
         up = HF.conv_bn_act(channels[0], self.up[0].weight, self.up[0].bias, self.up[1], relu=True, transposed=True)
         return HF.cat([channels[1], up])
 
@@ -193,10 +203,13 @@ class DualAttBlock(nn.Module):
         self.c3x3rb = ConvBNReLU(sum(inchannels), outchannels, 3, 1, 1)
         _init_conv_bn(self)
 
-    def forward(self, x):
-        fused = self.c3x3rb(self.mrf(x))
+    def forward(self, x, cat_buf=None):
+        cat = self.mrf(x, cat_buf)
+        # channel attention squeeze: the global average pool of F is accumulated while F is written (BN-apply pass of c3x3rb)
+        pooled = torch.empty(cat.shape[0], self.c3x3rb[0].out_channels, dtype=torch.float32, device=cat.device) if cat.is_cuda else None
+        fused = self.c3x3rb(cat, pool=pooled)
         spatial = self.spatialAttn(fused)
-        out = HF.dual_att_tail(fused, spatial, self.channelAttn.fc1, self.channelAttn.fc2)  # (1 + S) * SE(F)
+        out = HF.dual_att_tail(fused, spatial, self.channelAttn.fc1, self.channelAttn.fc2, pooled)  # (1 + S) * SE(F)
         return out, spatial
 
 
@@ -211,9 +224,9 @@ class DecoderBlock(nn.Module):
                                    nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
         _init_conv_bn(self, (nn.Conv2d,))
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         b = self.block
-        return HF.conv_bn_act(b[0](x), b[1].weight, b[1].bias, b[2], relu=True, transposed=True)
+        return HF.conv_bn_act(b[0](x), b[1].weight, b[1].bias, b[2], relu=True, transposed=True, out=out)
 
 
 # ------------------------------------------------------------------------------------------------ selectable global pooling
@@ -330,9 +343,9 @@ class _Stem(nn.Sequential):
 class _Tail(nn.Sequential):
     """denseblock4 + norm5 (no ReLU), models/models.py:312-313."""
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         buf, stats = self[0](x, with_stats=True)
-        return HF.batch_norm_act(buf, self[1], relu=False, stats=stats if self.training else None)
+        return HF.batch_norm_act(buf, self[1], relu=False, stats=stats if self.training else None, out=out)
 
 
 # ------------------------------------------------------------------------------------------------ SAUNet
@@ -419,11 +432,20 @@ class SAUNet(nn.Module):
             self._bump_counters()
         size = x.shape[2:]
         up = HF.interpolate_bilinear
+        n, dev, dt = x.shape[0], x.device, self.compute_dtype
+        h16, w16 = size[0] // 16, size[1] // 16
+        # decoder concatenations [skip | up-sampled] are preallocated; their producers write straight into the channel slices
+        cat5 = HF.new_act(n, 1024 + 512, h16, w16, dt, dev)
+        cat4 = HF.new_act(n, 512 + 512, 2 * h16, 2 * w16, dt, dev)
+        cat3 = HF.new_act(n, 256 + 256, 4 * h16, 4 * w16, dt, dev)
+        cat2 = HF.new_act(n, 128 + 128, 8 * h16, 8 * w16, dt, dev)
+        nf = self.final.in_channels
+        cat0 = HF.new_act(n, 2 * nf, size[0], size[1], dt, dev)
         conv1 = self.conv1(self._prep_input(x))
         buf, st = self.conv2(conv1, with_stats=True); conv2 = self.conv2t(buf, st)
         buf, st = self.conv3(conv2, with_stats=True); conv3 = self.conv3t(buf, st)
         buf, st = self.conv4(conv3, with_stats=True); conv4 = self.conv4t(buf, st)
-        conv5 = self.conv5(conv4)
+        conv5 = self.conv5(conv4, out=cat5[:, :1024])
 
         def conv(m, t):
             return HF.conv2d(t, m.weight, m.bias)
@@ -444,16 +466,18 @@ class SAUNet(nn.Module):
 
         canny = HF.canny(x, 10, 100, dtype=torch.float32)                 # on device, no host round trip
         acts = HF.sigmoid(conv(self.cw, HF.cat([edge_out, canny])))
-        edge = self.expand(acts, out_dtype=self.compute_dtype)
+        edge = self.expand(acts, out_dtype=self.compute_dtype, out=cat0[:, nf:])
 
-        conv2u, conv3u, conv4u = up(conv2, scale_factor=2), up(conv3, scale_factor=2), up(conv4, scale_factor=2)
+        conv2u = up(conv2, scale_factor=2, out=cat2[:, :128])
+        conv3u = up(conv3, scale_factor=2, out=cat3[:, :256])
+        conv4u = up(conv4, scale_factor=2, out=cat4[:, :512])
         center = self.center(HF.max_pool2x2(conv5))
-        dec5, att5 = self.dec5([center, conv5])
-        dec4, att4 = self.dec4([dec5, conv4u])
-        dec3, att3 = self.dec3([dec4, conv3u])
-        dec2, att2 = self.dec2([dec3, conv2u])
-        dec1 = self.dec1(dec2)
-        dec0 = self.dec0(HF.cat([dec1, edge]))
+        dec5, att5 = self.dec5([center, conv5], cat5)
+        dec4, att4 = self.dec4([dec5, conv4u], cat4)
+        dec3, att3 = self.dec3([dec4, conv3u], cat3)
+        dec2, att2 = self.dec2([dec3, conv2u], cat2)
+        dec1 = self.dec1(dec2, out=cat0[:, :nf])
+        dec0 = self.dec0(HF.cat_alias(cat0, [dec1, edge]))
         x_out = conv(self.final, dec0)
         if return_att:
             with torch.no_grad():
