@@ -44,42 +44,57 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "radam"])
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel probe (the command profiles/ was made with)")
+    ap.add_argument("--no-launch-mix", action="store_true", help="skip the 58-geometry launch-mix timing of the dominant kernel")
+    ap.add_argument("--infer", action="store_true", help="measure the inference forward (hipGraph, BN folded) instead of the training step")
     return ap.parse_args()
 
 
-def kernel_roofline(S, dtype, batch, size):
-    """Time the dominant kernel of the step on its own with HIP events on the launch stream.
+DENSE_BLOCKS = ((6, 64), (12, 128), (24, 256), (16, 512))     # (layers, first Cin) of DenseNet-121's four blocks; growth 32, bottleneck 128
 
-    Dominant kernel (profiles/r01_f_step_kernel_stats.txt): dense_dgrad_kernel -- the DenseNet conv1 data gradient with the
-    fused BatchNorm-backward epilogue (58 launches per step, one per dense layer; csrc/dense_dgrad.hip).  Probe geometry:
-    dense block 1, layer 5 (Cin = 192 earlier channels) at B x (size/2)^2 pixels.  Algorithmic bytes per launch (DESIGN.md):
-    g [P,128] read + x [P,Cin] read + dbuf [P,Cin] read and written = (128 + 3*Cin) * itemsize per pixel (+ 128*Cin weights);
-    algorithmic FLOPs = 2*P*128*Cin."""
+
+def _time_dense_dgrad(S, dtype, n, h, cin, ctot, reps, bufs=None):
+    """ms per launch of the dominant kernel at one layer geometry (HIP events on the launch stream = torch's current stream)."""
     HF = S.functional
-    h = size // 2
-    n, k, cin, ctot = batch, 128, 192, 256
-    buf = torch.randn(n, ctot, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)    # concat buffer (x)
-    dbuf = torch.randn(n, ctot, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)   # gradient buffer (y)
-    g = torch.randn(n, k, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    k = 128
+    if bufs is None:
+        bufs = (torch.randn(n, ctot, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last),
+                torch.randn(n, ctot, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last),
+                torch.randn(n, k, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last))
+    buf, dbuf, g = bufs
     w = torch.nn.Parameter(torch.randn(k, cin, 1, 1, device="cuda") * 0.05)
     p = HF.BNParams(cin, "cuda")
     p.buf[0].uniform_(0.5, 1.5); p.buf[1].normal_(0, 0.3); p.buf[2].normal_(0, 0.3); p.buf[3].uniform_(0.5, 1.5)
     sums = torch.zeros(HF.STAT_R, 2, cin, dtype=torch.float64, device="cuda")
+
     def run():
         HF.conv_dgrad_raw(g, w, (n, cin, h, h), 1, 0, out=dbuf[:, :cin], bn_epi=(buf[:, :cin], p, True, sums, True))
-    for _ in range(5):
+    for _ in range(3):
         run()
     torch.cuda.synchronize()
-    reps = 30
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
         run()
     e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
     P = n * h * h
-    flops = 2.0 * P * k * cin
     nbytes = (P * (k + 3 * cin) + k * cin) * g.element_size()
+    return e0.elapsed_time(e1) / reps, nbytes, 2.0 * P * k * cin, bufs
+
+
+def kernel_roofline(S, dtype, batch, size, launch_mix=True):
+    """Time the dominant kernel of the step on its own with HIP events on the launch stream.
+
+    Dominant kernel (profiles/r02_step_kernel_stats.txt): dense_dgrad_kernel -- the DenseNet conv1 data gradient with the
+    fused BatchNorm-backward epilogue (58 launches per step, one per dense layer; csrc/dense_dgrad.hip).  Probe geometry:
+    dense block 1, layer 5 (Cin = 192 earlier channels) at B x (size/2)^2 pixels.  Algorithmic bytes per launch (DESIGN.md):
+    g [P,128] read + x [P,Cin] read + dbuf [P,Cin] read and written = (128 + 3*Cin) * itemsize per pixel (+ 128*Cin weights);
+    algorithmic FLOPs = 2*P*128*Cin.  `launch_mix`: the same measurement over ALL 58 layer geometries of the step
+    (sum of bytes / sum of time) -- the fraction the kernel reaches over its real launch mix, not at its best geometry."""
+    h = size // 2
+    n, k, cin, ctot = batch, 128, 192, 256
+    ms, nbytes, flops, bufs = _time_dense_dgrad(S, dtype, n, h, cin, ctot, 30)
+    P = n * h * h
+    itemsize = 2 if dtype == torch.bfloat16 else 4
     tflops = flops / (ms * 1e-3) / 1e12
     gbs = nbytes / (ms * 1e-3) / 1e9
     ai = flops / nbytes
@@ -88,12 +103,51 @@ def kernel_roofline(S, dtype, batch, size):
     # the bound that applies: min(MFMA peak, AI x HBM peak)
     hbm_bound_tf = ai * HBM_PEAK_GBS / 1e3
     if hbm_bound_tf < peak_tf:
-        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": None, "kernel": label, "ms": round(ms, 4), "algorithmic_bytes": int(nbytes),
-                "tflops": round(tflops, 1), "flop_per_byte": round(ai, 1)}
-    return {"bound": "mfma", "achieved": round(tflops, 1), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(tflops / peak_tf, 4),
-            "traffic": None, "kernel": label, "ms": round(ms, 4), "algorithmic_bytes": int(nbytes),
-            "gbs": round(gbs, 1), "flop_per_byte": round(ai, 1)}
+        out = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+               "traffic": None, "kernel": label, "ms": round(ms, 4), "algorithmic_bytes": int(nbytes),
+               "tflops": round(tflops, 1), "flop_per_byte": round(ai, 1)}
+    else:
+        out = {"bound": "mfma", "achieved": round(tflops, 1), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(tflops / peak_tf, 4),
+               "traffic": None, "kernel": label, "ms": round(ms, 4), "algorithmic_bytes": int(nbytes),
+               "gbs": round(gbs, 1), "flop_per_byte": round(ai, 1)}
+    del bufs
+    if launch_mix:
+        tot_ms = tot_bytes = 0.0
+        per_block = []
+        for b, (layers, c0) in enumerate(DENSE_BLOCKS):
+            hb = size // (2 << b)
+            bufs, bms, bby = None, 0.0, 0.0
+            for l in range(layers):
+                m_, by_, _, bufs = _time_dense_dgrad(S, dtype, n, hb, c0 + 32 * l, c0 + 32 * layers, 8, bufs)
+                bms += m_; bby += by_
+            del bufs
+            per_block.append({"block": b + 1, "launches": layers, "ms": round(bms, 4), "GBs": round(bby / (bms * 1e-3) / 1e9, 1)})
+            tot_ms += bms; tot_bytes += bby
+        mix_gbs = tot_bytes / (tot_ms * 1e-3) / 1e9
+        out["launch_mix"] = {"launches": sum(l for l, _ in DENSE_BLOCKS), "ms_per_step": round(tot_ms, 4), "algorithmic_bytes": int(tot_bytes),
+                             "achieved": round(mix_gbs, 1), "frac": round(mix_gbs / HBM_PEAK_GBS, 4), "per_block": per_block}
+    return out
+
+
+def step_roofline(args, ms_per_step):
+    """Whole-step roofline against SURVEY 8(d)'s ideal-fusion algorithmic bytes (1.086 GB per 256x256 slice in bf16, 2.171 GB in float32:
+    every conv reads its input once and writes its output once, forward + backward) and the measured HBM traffic of the committed
+    whole-step PMC passes (profiles/step_pmc.json, produced by scripts/collect_step_pmc.sh for the default configuration)."""
+    per_slice = (1.086e9 if args.dtype == "bf16" else 2.171e9) * (args.size / 256.0) ** 2
+    alg = per_slice * args.batch
+    gbs = alg / (ms_per_step * 1e-3) / 1e9
+    out = {"algorithmic_bytes": int(alg), "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic_bytes": None, "traffic_ratio": None,
+           "mfma_frac": round(args.batch * TRAIN_GFLOP_PER_SLICE_256 * (args.size / 256.0) ** 2 / ms_per_step / (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS), 4)}
+    try:
+        with open(os.path.join(ROOT, "profiles", "step_pmc.json")) as f:
+            rec = json.load(f)
+        if rec.get("config") == [args.size, args.batch, args.dtype]:
+            out["traffic_bytes"] = int(rec["traffic_bytes_per_step"])
+            out["traffic_ratio"] = round(rec["traffic_bytes_per_step"] / alg, 3)
+            out["traffic_source"] = rec.get("source")
+    except Exception:
+        pass
+    return out
 
 
 def config_name(args, world):
@@ -122,37 +176,79 @@ def pmc_traffic(kernel_label):
 
 
 def cpu_baseline(size):
-    """The CPU oracle (oracle/saunet_ref.py, the pinned restatement of the reference's PyTorch path) timed on this
-    host: B=2 slices, fwd+bwd+SGD, a bounded number of iterations."""
+    """The CPU oracle (oracle/saunet_ref.py, the pinned restatement of the reference's PyTorch path) timed on this host with
+    SURVEY 8(d)'s protocol: fwd + bwd + SGD, 3 warm-up + 10 timed iterations at B=2 and (bounded: 1 + 4) at B=8, median s/iter."""
     from oracle import saunet_ref as R, weights as Wt
     # intra-op threads: a few dozen at most -- with one thread per core of a 256-core host the small-channel layers spend their
     # time in thread wake-ups and the same step runs ~100x slower (measured: 470 s/iteration with 256 threads)
-    cores = max(1, min(os.cpu_count() or 1, 32))
+    ncpu = os.cpu_count() or 1
+    cores = max(1, min(ncpu, 32))
     torch.set_num_threads(cores)
     spec = R.state_dict_spec()
-    sd = Wt.make_state_dict(spec, 0)
     keys = Wt.trainable_keys(spec)
-    for k in keys:
-        sd[k].requires_grad_(True)
-    B = 2
-    img, seg, edge = Wt.synthetic_batch(B, size, size)
-    canny = R.canny_branch(img)
-    opt = torch.optim.SGD([sd[k] for k in keys], lr=5e-4, momentum=0.9)
-    times = []
-    t_start = time.time()
-    for it in range(6):
-        t0 = time.time()
-        opt.zero_grad()
-        loss, *_ = R.segmentation_step(sd, img, seg, edge, True, canny=canny)
-        loss.backward(); opt.step()
-        times.append(time.time() - t0)
-        if time.time() - t_start > 20 and it >= 1:      # bounded sample: ~20 s of CPU work, at least one steady iteration
-            break
-        if time.time() - t_start > 60:
-            break
-    steady = sorted(times[1:])[len(times[1:]) // 2] if len(times) > 1 else times[0]
-    return {"value": round(B / steady, 3), "unit": "slices/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle restatement (PyTorch CPU fp32), B=2 %dx%d, fwd+bwd+SGD, median of %d iters after 1 warm-up" % (size, size, len(times) - 1)}
+    runs = []
+    for B, warm, timed, budget in ((2, 3, 10, 40.0), (8, 1, 4, 40.0)):
+        sd = Wt.make_state_dict(spec, 0)
+        for k in keys:
+            sd[k].requires_grad_(True)
+        img, seg, edge = Wt.synthetic_batch(B, size, size)
+        canny = R.canny_branch(img)
+        opt = torch.optim.SGD([sd[k] for k in keys], lr=5e-4, momentum=0.9)
+        times, t_start = [], time.time()
+        for it in range(warm + timed):
+            t0 = time.time()
+            opt.zero_grad()
+            loss, *_ = R.segmentation_step(sd, img, seg, edge, True, canny=canny)
+            loss.backward(); opt.step()
+            times.append(time.time() - t0)
+            if time.time() - t_start > budget and it >= warm:      # bounded sample
+                break
+        steady = sorted(times[warm:]) if len(times) > warm else times[-1:]
+        med = steady[len(steady) // 2]
+        runs.append({"B": B, "s_per_iter": round(med, 4), "slices_per_s": round(B / med, 3), "warmup": min(warm, len(times) - len(steady)), "timed": len(steady)})
+    best = max(runs, key=lambda r: r["slices_per_s"])
+    return {"value": best["slices_per_s"], "unit": "slices/s", "cores": torch.get_num_threads(), "host_cpus": ncpu, "kind": "port", "runs": runs,
+            "sample": "oracle restatement (PyTorch CPU fp32) %dx%d, fwd+bwd+SGD, median s/iter: B=2 3 warm-up + 10 timed, B=8 1 + 4 (bounded); "
+                      "%d intra-op threads on a %d-CPU host" % (size, size, torch.get_num_threads(), ncpu)}
+
+
+def infer_bench(args, S, dev, dtype):
+    """--infer: eval-mode forward (SegmentationModule test branch semantics: logits -> softmax/argmax on the device) captured in a hipGraph."""
+    from saunet_amd import data
+    from saunet_amd.graph import GraphedStep
+    torch.manual_seed(304)
+    net = S.SAUNet(num_classes=4).to(dev).eval()
+    img, seg, edge = data.synthetic_batch(args.batch, args.size, args.size, seed=304, device=dev)
+
+    def fwd():
+        with torch.no_grad():
+            logits, edge_out = net(img)
+            return S.functional.softmax_argmax(logits)
+    for _ in range(max(args.warmup, 2)):
+        fwd()
+    torch.cuda.synchronize()
+    mode = "hipgraph(forward+softmax/argmax)"
+    try:
+        g = GraphedStep(fwd, warmup=1, changes_params=False)
+        run = g.replay
+    except Exception as e:
+        run, mode = fwd, "eager (graph capture failed: %s)" % (str(e).splitlines()[0][:80])
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = dt / args.steps * 1e3
+    scale = (args.size / 256.0) ** 2
+    return {"metric": "2D slices/sec (inference forward) at %dx%d" % (args.size, args.size), "value": round(args.batch * args.steps / dt, 2),
+            "unit": "slices/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (ellipse phantom, z-scored; random-init weights)",
+            "config": {"workload": "ACDC %dx%d batch=%d SAUNet %s inference (BN folded, softmax+argmax on device)" % (args.size, args.size, args.batch, args.dtype),
+                       "global_batch": args.batch, "parallelism": "dp1", "mode": mode},
+            "achieved_tflops_algorithmic": round(args.batch * args.steps / dt * 72.15 * scale / 1e3, 2)}
 
 
 def main():
@@ -161,9 +257,15 @@ def main():
     from saunet_amd import dp, data, optim
     if args.roofline_only:
         torch.cuda.set_device(0)
-        r = kernel_roofline(S, torch.bfloat16 if args.dtype == "bf16" else torch.float32, args.batch, args.size)
+        r = kernel_roofline(S, torch.bfloat16 if args.dtype == "bf16" else torch.float32, args.batch, args.size, launch_mix=not args.no_launch_mix)
         r["traffic"] = pmc_traffic(r["kernel"])
         print(json.dumps({"roofline": r}), flush=True)
+        return
+    if args.infer:
+        torch.cuda.set_device(0)
+        dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        S.set_compute_dtype(dtype)
+        print(json.dumps(infer_bench(args, S, torch.device("cuda", 0), dtype)), flush=True)
         return
     rank, local, world = dp.init_from_env()
     if world != args.gpus and world > 1:
@@ -179,6 +281,8 @@ def main():
     opt = optim.create_optimizers(net, args.optimizer, lr=5e-4, momentum=0.9, weight_decay=1e-4)[0]
     use_graph = (not args.no_graph) and (world == 1 or args.graph_dp)
     buckets = dp.GradientBuckets(list(net.parameters()), bucket_mb=32.0, overlap=not use_graph) if world > 1 else None
+    if buckets is not None:
+        buckets.time_finish = True
     img, seg, edge = data.synthetic_batch(args.batch, args.size, args.size, seed=304 + 1000 * rank, device=dev)
     feed = {"image": img, "mask": (seg, edge)}
 
@@ -212,8 +316,6 @@ def main():
     if use_graph:
         try:
             from saunet_amd.graph import GraphedStep
-            opt.upload_hyper()
-
             def captured():
                 loss = fwd_bwd()
                 if world == 1:
@@ -222,7 +324,7 @@ def main():
 
             # weight re-packing is recorded INSIDE the graph (functional.PackedWeights.prepack under capture), so every replay trains
             # on the weights its predecessor's optimiser step produced
-            graph = GraphedStep(captured, warmup=1)
+            graph = GraphedStep(captured, warmup=1, optimizers=[opt] if world == 1 else [])
             mode = "hipgraph(fwd+bwd+opt)" if world == 1 else "hipgraph(fwd+bwd)+eager(allreduce+opt)"
             graph.replay(); torch.cuda.synchronize()
         except Exception as e:  # capture unsupported -> measured eagerly, and said so in the JSON
@@ -251,10 +353,21 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    comm = None
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
+        # exposed gradient-exchange time of the LAST step on this rank: how long the compute stream sat in finish() (waits on the
+        # all-reduce stream + unpack kernels); everything else of the all-reduce ran hidden behind backward kernels
+        exposed = None
+        if buckets is not None and buckets.exposed_events is not None:
+            exposed = buckets.exposed_events[0].elapsed_time(buckets.exposed_events[1])
+        payload = sum(p.numel() for p in buckets.params) * 4 if buckets is not None else 0
+        comm = {"backend": torch.distributed.get_backend(), "rccl_ranks": world if torch.distributed.get_backend() == "nccl" else 0,
+                "buckets": len(buckets.buckets) if buckets is not None else 0, "allreduce_payload_bytes": payload,
+                "exposed_allreduce_ms_last_step": None if exposed is None else round(exposed, 3),
+                "syncbn_allreduces_per_step": 12}
     final_loss = float(loss.detach().float())
 
     if rank == 0:
@@ -271,10 +384,13 @@ def main():
                        "loss": round(final_loss, 5)},
             "achieved_tflops_algorithmic": round(slices * TRAIN_GFLOP_PER_SLICE_256 * scale / 1e3, 2),
         }
+        if comm is not None:
+            out["comm"] = comm
         if not args.no_roofline:
             try:
-                out["roofline"] = kernel_roofline(S, dtype, args.batch, args.size)
+                out["roofline"] = kernel_roofline(S, dtype, args.batch, args.size, launch_mix=not args.no_launch_mix)
                 out["roofline"]["traffic"] = pmc_traffic(out["roofline"]["kernel"])
+                out["roofline"]["step"] = step_roofline(args, ms)     # per-GPU step: weak scaling, every rank does this work
             except Exception as e:
                 out["roofline"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:

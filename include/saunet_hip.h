@@ -256,6 +256,10 @@ int saunet_dual_loss_forward(int dtype, const void* logits, int ldl, const void*
 int saunet_dual_loss_finalize(const double* sums, int64_t pixels, float* loss, float* metrics, void* stream);
 int saunet_dual_loss_backward(int dtype, const void* logits, int ldl, const void* edge, const int64_t* seg_t, const float* edge_t,
                               int64_t pixels, const double* sums, const float* dloss, void* dlogits, int lddl, void* dedge, void* stream);
+/* inference head (models/models.py:96-109 `softmax(pred, dim=1)`; train.py:47 argmax): prob [P][C] float32 (row stride ldp) and / or
+ * label [P] int64 = first maximum; either output may be NULL.  C in {2, 4, 8}. */
+int saunet_softmax_argmax(int dtype, const void* logits, int ldl, int64_t pixels, int C, float* prob, int ldp, int64_t* label, void* stream);
+
 
 /* ---- Canny branch on device (models/models.py:359-363; replaces the host cv2.Canny round trip) --
  * out[n,h,w] in {0,255} as dtype.  work: int32 [N][3][H][W] scratch. */

@@ -83,24 +83,39 @@ __global__ __launch_bounds__(256) void canny_nms_kernel(int N, int H, int W, int
 // LDS = true: the whole map of the image lives in LDS as bytes (H*W <= 152 KiB, e.g. 256x256 = 64 KiB) and the sweeps
 // never touch memory; otherwise the sweeps relax the int32 map in global memory.
 template <typename T, bool LDS>
-__global__ __launch_bounds__(1024) void canny_hyst_kernel(int H, int W, int32_t* __restrict__ work, T* __restrict__ out)
+__global__ __launch_bounds__(1024) void canny_hyst_kernel(int H, int W, int32_t* __restrict__ work, T* __restrict__ out, int list_cap)
 {
     extern __shared__ unsigned char h_map[];
     const long plane = (long)H * W;
     volatile int32_t* gmap = work + (long)blockIdx.x * 3 * plane + 2 * plane;
     volatile unsigned char* lmap = h_map;
-    __shared__ int changed;
+    __shared__ int changed, ncand;
     const int npix = H * W;
+    // weak candidates (map value 0) are a few percent of the pixels: the sweeps walk a compact list of them (built once, in LDS behind
+    // the byte map) instead of the whole image; if the list overflows its LDS budget the sweeps fall back to scanning every pixel
+    unsigned int* list = (unsigned int*)(h_map + ((npix + 15) & ~15));
+    if (threadIdx.x == 0) ncand = 0;
     if constexpr (LDS) {
         for (int i = threadIdx.x; i < npix; i += 1024) lmap[i] = (unsigned char)gmap[i];
-        __syncthreads();
     }
+    __syncthreads();
     auto at = [&](int i) -> int { if constexpr (LDS) return lmap[i]; else return gmap[i]; };
+    bool use_list = false;
+    if constexpr (LDS) {
+        if (list_cap > 0) {
+            for (int i = threadIdx.x; i < npix; i += 1024)
+                if (lmap[i] == 0) { const int pos = atomicAdd(&ncand, 1); if (pos < list_cap) list[pos] = (unsigned)i; }
+            __syncthreads();
+            use_list = ncand <= list_cap;
+        }
+    }
+    const int nwork = use_list ? ncand : npix;
     for (int it = 0; it < npix; ++it) {
         if (threadIdx.x == 0) changed = 0;
         __syncthreads();
         int any = 0;
-        for (int i = threadIdx.x; i < npix; i += 1024) {
+        for (int k = threadIdx.x; k < nwork; k += 1024) {
+            const int i = use_list ? (int)list[k] : k;
             if (at(i) != 0) continue;
             const int y = i / W, x = i - y * W;
             bool hit = false;
@@ -179,15 +194,20 @@ extern "C" int saunet_canny(int dtype, const float* image, int N, int H, int W, 
     if (map_bytes <= 152 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)canny_hyst_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-            (void)hipFuncSetAttribute((const void*)canny_hyst_kernel<u16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            (void)hipFuncSetAttribute((const void*)canny_hyst_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+            (void)hipFuncSetAttribute((const void*)canny_hyst_kernel<u16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
             attr_set = true;
         }
-        if (dtype == SAUNET_F32) hipLaunchKernelGGL((canny_hyst_kernel<float, true>), dim3(N), dim3(1024), map_bytes, st, H, W, work, (float*)out);
-        else hipLaunchKernelGGL((canny_hyst_kernel<u16, true>), dim3(N), dim3(1024), map_bytes, st, H, W, work, (u16*)out);
+        // candidate list behind the byte map: up to a quarter of the pixels (weak candidates are typically < 5 %), within the LDS budget
+        const size_t map_al = (map_bytes + 15) & ~(size_t)15;
+        size_t cap = map_bytes / 4;
+        if (map_al + cap * 4 > 156 * 1024) cap = (156 * 1024 - map_al) / 4;
+        const size_t lds = map_al + cap * 4;
+        if (dtype == SAUNET_F32) hipLaunchKernelGGL((canny_hyst_kernel<float, true>), dim3(N), dim3(1024), lds, st, H, W, work, (float*)out, (int)cap);
+        else hipLaunchKernelGGL((canny_hyst_kernel<u16, true>), dim3(N), dim3(1024), lds, st, H, W, work, (u16*)out, (int)cap);
     } else {
-        if (dtype == SAUNET_F32) hipLaunchKernelGGL((canny_hyst_kernel<float, false>), dim3(N), dim3(1024), 0, st, H, W, work, (float*)out);
-        else hipLaunchKernelGGL((canny_hyst_kernel<u16, false>), dim3(N), dim3(1024), 0, st, H, W, work, (u16*)out);
+        if (dtype == SAUNET_F32) hipLaunchKernelGGL((canny_hyst_kernel<float, false>), dim3(N), dim3(1024), 0, st, H, W, work, (float*)out, 0);
+        else hipLaunchKernelGGL((canny_hyst_kernel<u16, false>), dim3(N), dim3(1024), 0, st, H, W, work, (u16*)out, 0);
     }
     SAUNET_CHECK_LAUNCH("canny");
     return SAUNET_OK;

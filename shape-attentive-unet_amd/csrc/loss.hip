@@ -129,6 +129,32 @@ __global__ __launch_bounds__(256) void dual_loss_bwd_kernel(const T* __restrict_
     }
 }
 
+// Inference head: probabilities = softmax over the C class logits of every pixel (float32, NHWC) and / or the predicted label
+// = argmax (first maximum, like torch.argmax) -- SegmentationModule's test / inference branches (/root/reference/models/models.py:96-109:
+// `torch.nn.functional.softmax(pred, dim=1)`) followed by train.py:47 / test_and_pack.py's argmax.
+template <typename T, int C>
+__global__ __launch_bounds__(256) void softmax_argmax_kernel(const T* __restrict__ logits, int ldl, long P, float* __restrict__ prob, int ldp,
+                                                             int64_t* __restrict__ label)
+{
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        float z[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) z[c] = Elem<T>::load(logits + p * ldl + c);
+        float m = z[0]; int am = 0;
+#pragma unroll
+        for (int c = 1; c < C; ++c) if (z[c] > m) { m = z[c]; am = c; }
+        if (prob) {
+            float e[C], sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) { e[c] = expf(z[c] - m); sum += e[c]; }
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int c = 0; c < C; ++c) prob[p * ldp + c] = e[c] * inv;
+        }
+        if (label) label[p] = am;
+    }
+}
+
 }  // namespace saunet
 
 using namespace saunet;
@@ -163,6 +189,23 @@ int saunet_dual_loss_backward(int dtype, const void* logits, int ldl, const void
     else if (dtype == SAUNET_BF16) hipLaunchKernelGGL(dual_loss_bwd_kernel<u16>, dim3((unsigned)blocks), dim3(256), 0, st, (const u16*)logits, ldl, (const u16*)edge, seg_t, edge_t, (long)pixels, sums, dloss, (u16*)dlogits, lddl, (u16*)dedge);
     else return set_error(SAUNET_BAD_DTYPE, "dual_loss: dtype %d", dtype);
     SAUNET_CHECK_LAUNCH("dual_loss_backward");
+    return SAUNET_OK;
+}
+
+int saunet_softmax_argmax(int dtype, const void* logits, int ldl, int64_t pixels, int C, float* prob, int ldp, int64_t* label, void* stream)
+{
+    if (C != 2 && C != 4 && C != 8) return set_error(SAUNET_UNSUPPORTED, "softmax_argmax: %d classes (2, 4 or 8)", C);
+    if (!prob && !label) return set_error(SAUNET_BAD_SHAPE, "softmax_argmax: no output requested");
+    long b = (pixels + 255) / 256; if (b > 4096) b = 4096; if (b < 1) b = 1;
+    hipStream_t st = (hipStream_t)stream;
+#define SM(TT, CC) hipLaunchKernelGGL((softmax_argmax_kernel<TT, CC>), dim3((unsigned)b), dim3(256), 0, st, (const TT*)logits, ldl, (long)pixels, prob, ldp, label)
+#define SMT(TT) do { if (C == 2) SM(TT, 2); else if (C == 4) SM(TT, 4); else SM(TT, 8); } while (0)
+    if (dtype == SAUNET_F32) SMT(float);
+    else if (dtype == SAUNET_BF16) SMT(u16);
+    else return set_error(SAUNET_BAD_DTYPE, "softmax_argmax: dtype %d", dtype);
+#undef SMT
+#undef SM
+    SAUNET_CHECK_LAUNCH("softmax_argmax");
     return SAUNET_OK;
 }
 

@@ -1162,6 +1162,19 @@ def dual_loss(logits, edge, seg_t, edge_t):
     return _DualLoss.apply(logits, edge, seg_t, edge_t)
 
 
+def softmax_argmax(logits, want_prob=True, want_label=True):
+    """Inference head on the device: (softmax over the class dimension as float32 [N,C,H,W], argmax labels int64 [N,H,W]); no gradient.
+    Replaces torch.softmax(...) + .argmax(1) of the reference's test / eval branches (models/models.py:96-109, train.py:47)."""
+    _check_dev(logits)
+    lg = nhwc(logits.detach())
+    n, c, h, w = lg.shape
+    prob = new_act(n, c, h, w, torch.float32, lg.device) if want_prob else None
+    label = torch.empty((n, h, w), dtype=torch.int64, device=lg.device) if want_label else None
+    L.call("saunet_softmax_argmax", L.dtype_code(lg), lg.data_ptr(), ld_of(lg), n * h * w, c, L.ptr(prob), ld_of(prob) if prob is not None else 0,
+           L.ptr(label), L.stream())
+    return prob, label
+
+
 def canny(image, low=10, high=100, dtype=None):
     """image: float32 [N,3,H,W] (contiguous NCHW, as the loader delivers it) -> [N,1,H,W] in {0,255}."""
     _check_dev(image)

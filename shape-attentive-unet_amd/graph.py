@@ -17,10 +17,15 @@ class GraphedStep:
     """``fn()`` is run ``warmup`` times eagerly on a side stream (allocator pools, optimiser state, pack cache), then
     captured.  ``replay()`` launches the graph and returns whatever ``fn`` returned during capture (static tensors)."""
 
-    def __init__(self, fn, warmup=1, changes_params=True):
+    def __init__(self, fn, warmup=1, changes_params=True, optimizers=()):
+        """optimizers: the fused optimisers whose step(upload=False) is inside `fn`; their device hyper-parameter arrays (learning rate,
+        Adam / RAdam bias-correction terms) are refreshed before every replay and their host step counters advanced after it."""
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedStep needs the GPU (no CPU fallback)")
         self.changes_params = changes_params
+        self.optimizers = list(optimizers)
+        for o in self.optimizers:
+            o.upload_hyper()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -28,13 +33,21 @@ class GraphedStep:
                 fn()
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
+        for o in self.optimizers:
+            o.upload_hyper()
         with torch.cuda.graph(self.graph):
             self.out = fn()
+        for o in self.optimizers:
+            o.capture_rollback()
         if changes_params:
             HF.notify_params_changed()
 
     def replay(self):
+        for o in self.optimizers:
+            o.pre_replay()
         self.graph.replay()
+        for o in self.optimizers:
+            o.post_replay()
         if self.changes_params:
             HF.notify_params_changed()
         return self.out

@@ -88,6 +88,7 @@ _SIGS = {
     "saunet_dual_loss_forward": [i32, vp, i32, vp, vp, vp, i64, vp, vp],
     "saunet_dual_loss_finalize": [vp, i64, vp, vp, vp],
     "saunet_dual_loss_backward": [i32, vp, i32, vp, vp, vp, i64, vp, vp, vp, i32, vp, vp],
+    "saunet_softmax_argmax": [i32, vp, i32, i64, i32, vp, i32, vp, vp],
     "saunet_canny": [i32, vp, i32, i32, i32, i32, i32, vp, vp, vp],
     "saunet_mask_to_edges": [vp, i32, i32, i32, i32, vp, vp],
     "saunet_sgd_step": [C.POINTER(TensorList), vp, vp],

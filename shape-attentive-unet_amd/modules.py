@@ -523,11 +523,11 @@ class SegmentationModule(SegmentationModuleBase):
             return loss, self.pixel_acc(self.crit.last_metrics, self.num_class)
         if segSize is True:  # test
             p, e, maps = self.unet(feed_dict["image"], return_att=True)
-            return torch.softmax(p.float(), dim=1), maps
+            return HF.softmax_argmax(p, want_label=False)[0], maps
         out = self.unet(feed_dict["image"], return_att=return_att)
         seg_t, edge_t = feed_dict["mask"]
         loss = self.crit((out[0], out[1]), (seg_t.long().unsqueeze(0), edge_t.unsqueeze(0)))
-        return torch.softmax(out[0].float(), dim=1), loss
+        return HF.softmax_argmax(out[0], want_label=False)[0], loss
 
 
 class ModelBuilder:

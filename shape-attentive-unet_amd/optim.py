@@ -94,6 +94,20 @@ class _FusedBase(torch.optim.Optimizer):
         h.copy_(host, non_blocking=True)
         pv["vals"], pv["dev"] = values, h.data_ptr()
 
+    # ---- hipGraph protocol (saunet_amd.graph.GraphedStep): a captured step() launches the update kernels with whatever the device
+    # hyper-parameter array holds at replay time, so the host refreshes that array before every replay and keeps the step counters
+    def pre_replay(self):
+        self.upload_hyper()
+
+    def post_replay(self, n=1):
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] += n
+
+    def capture_rollback(self):
+        """stream capture ran step()'s host code once without executing anything on the device"""
+        self.post_replay(-1)
+
     def _live(self, group):
         HF.WGRAD_SIDE.join()      # weight gradients are produced on a side stream
         ps = [p for p in group["params"] if p.grad is not None]
@@ -113,9 +127,9 @@ class FusedSGD(_FusedBase):
 
     def upload_hyper(self):
         for g in self.param_groups:
-            # first step <=> no momentum buffer exists yet (also right after load_state_dict of a fresh or a resumed optimiser)
-            first = 0.0 if any("momentum_buffer" in self.state.get(p, {}) for p in g["params"]) else 1.0
-            self._upload(g, [g["lr"], g["momentum"], g["weight_decay"], first, self.grad_scale, 0, 0, 0])
+            # the kernel's "first step" flag (buf = grad, do not read the buffer) stays 0: momentum buffers are created ZERO-filled, for
+            # which buf = momentum*0 + grad is the same value -- and a hyper array captured by a hipGraph must not carry a per-step flag
+            self._upload(g, [g["lr"], g["momentum"], g["weight_decay"], 0.0, self.grad_scale, 0, 0, 0])
 
     @torch.no_grad()
     def step(self, closure=None, upload=True):
