@@ -1,0 +1,25 @@
+"""Run ONE conv geometry a few times (for rocprofv3 PMC passes): python scripts/one_kernel.py conv2|conv1|res1|dgrad1 [reps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import saunet_amd as S
+HF = S.functional
+which = sys.argv[1]; reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+dt = torch.bfloat16
+n = 32
+if which == "conv2":
+    cin, h, cout, k, pro = 128, 128, 32, 3, True
+elif which == "conv1":
+    cin, h, cout, k, pro = 160, 128, 128, 1, True
+elif which == "res1":
+    cin, h, cout, k, pro = 64, 256, 64, 3, False
+elif which == "dec3":
+    cin, h, cout, k, pro = 512, 64, 128, 3, False
+x = torch.randn(n, cin, h, h, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+w = torch.nn.Parameter(torch.randn(cout, cin, k, k, device="cuda") * 0.03)
+sc = torch.rand(cin, device="cuda") + 0.5; sh = torch.randn(cin, device="cuda") * 0.1
+out = HF.new_act(n, cout, h, h, dt, "cuda")
+st = torch.zeros(HF.STAT_R, 2, cout, dtype=torch.float64, device="cuda")
+for _ in range(reps):
+    HF.conv_forward_raw(x, w, None, 1, k // 2, pro=(sc, sh, True) if pro else None, out=out, stats=st)
+torch.cuda.synchronize()

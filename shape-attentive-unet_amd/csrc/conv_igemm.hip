@@ -97,6 +97,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void conv_igemm_fwd_
 
     const int nk = taps * a.kpt;
     const float relu_lo = a.pro_relu ? 0.f : -__builtin_inff();
+    // BatchNorm prologue vectors in LDS (behind the two stages): fetching them from global memory inside the K loop would put their
+    // loads BEHIND the prefetched A/B pieces in the in-order vmcnt queue -- waiting for them then drains the prefetch (vmcnt(0) before
+    // every commit).  LDS reads retire on lgkmcnt.
+    float* s_pro = (float*)(smem + 2 * STAGE);
+    const int cpad = a.kpt * KC;
+    if (has_pro) {
+        for (int i = tid; i < cpad; i += NT) { s_pro[i] = i < a.Cin ? a.pro_scale[i] : 0.f; s_pro[cpad + i] = i < a.Cin ? a.pro_shift[i] : 0.f; }
+        __syncthreads();
+    }
 
     // Two register stages: the loads of K-step k+2 are issued before the MFMAs of step k, and only converted
     // (BN+ReLU prologue, zero padding) and written to LDS after the MFMAs of step k+1 -- a load has two MFMA phases to land.
@@ -139,7 +148,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void conv_igemm_fwd_
             float sc[EPC], sh[EPC];
 #pragma unroll
             for (int j = 0; j < EPC; j += 4) {
-                f32x4 s4 = *(const f32x4*)(a.pro_scale + S.cs + j), t4 = *(const f32x4*)(a.pro_shift + S.cs + j);
+                f32x4 s4 = *(const f32x4*)(s_pro + S.cs + j), t4 = *(const f32x4*)(s_pro + cpad + S.cs + j);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { sc[j + q] = s4[q]; sh[j + q] = t4[q]; }
             }
@@ -327,12 +336,14 @@ static int launch_fwd_i(const IgemmArgs& a, int phases, hipStream_t st)
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     constexpr int STAGE = (BM + BN) * CPR * 16;
     constexpr int EPI = BM * BN * (int)sizeof(T) + 2 * BN * 4;
-    constexpr int LDS = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+    constexpr int EPC_ = 16 / (int)sizeof(T);
+    const int pro_bytes = a.pro_scale ? 2 * a.kpt * CPR * EPC_ * 4 : 0;      // prologue scale/shift vectors behind the two stages
+    const int LDS = (2 * STAGE + pro_bytes > EPI) ? 2 * STAGE + pro_bytes : EPI;
     auto kern = conv_igemm_fwd_kernel<T, BM, BN, WM, WN, CPR, BNEPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int attr_lds = 0;
+    if (LDS > attr_lds) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
+        attr_lds = LDS;
     }
     dim3 grid(cdiv(a.M, BM), cdiv(a.Cout, BN), phases);
     hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, st, a);

@@ -371,6 +371,14 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
     // block-lifetime accumulators (statistics / BN-backward sums): flushed to global memory once per n-tile, not per tile
     float* s_acc = (float*)(smem + a.lds_acc_off);      // [2][BN]
     for (int i = tid; i < 2 * BN; i += NT) s_acc[i] = 0.f;
+    // BatchNorm prologue vectors live in LDS for the block's lifetime.  They must NOT be fetched from global memory inside the unit
+    // loop: vmcnt retires in order, so waiting for a scale/shift load issued after the halo prefetch drains the whole prefetch queue
+    // (s_waitcnt vmcnt(0) right before the commit -- the prefetch then overlaps nothing).  LDS reads count on lgkmcnt instead.
+    float* s_pro = s_acc + 2 * BN;                       // [2][ncb * KC]
+    if (has_pro) {
+        const int cpad = ncb * KC;
+        for (int i = tid; i < cpad; i += NT) { s_pro[i] = i < a.Cin ? a.pro_scale[i] : 0.f; s_pro[cpad + i] = i < a.Cin ? a.pro_shift[i] : 0.f; }
+    }
     auto flush_acc = [&](int nt) {
         __syncthreads();
         const int n0f = nt * BN;
@@ -390,10 +398,13 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
     };
 
     int cur_nt = -1;
-    u32x4 hreg[H_ITERS];
-    bool hok[H_ITERS];
+    // TWO register stages: the halo loads of units u+1 and u+2 are both in flight while the MFMAs of unit u run, so a load has two
+    // MFMA phases plus a commit to land and the CU always has ~80 KB outstanding (one stage left HBM idle during every commit: the
+    // DenseNet conv2 forward ran at a third of the per-CU load rate).  The accumulators are small here, the registers are free.
+    u32x4 hregA[H_ITERS], hregB[H_ITERS];
+    bool hokA[H_ITERS], hokB[H_ITERS];
 
-    auto issue_halo = [&](int item, int cb) {   // global -> registers (no wait)
+    auto issue_halo = [&](int item, int cb, u32x4 (&hreg)[H_ITERS], bool (&hok)[H_ITERS]) {   // global -> registers (no wait)
         const int tile = item % ntile;
         int bt = tile;
         const int txi = bt % a.tiles_x; bt /= a.tiles_x;
@@ -412,14 +423,15 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
             hreg[i] = *(const u32x4*)(xg + (ok ? (size_t)(iy * a.W + ix) * a.ldx + c : (size_t)0));
         }
     };
-    auto commit_halo = [&](int cb) {            // transform + registers -> LDS
+    auto commit_halo = [&](int cb, u32x4 (&hreg)[H_ITERS], bool (&hok)[H_ITERS]) {            // transform + registers -> LDS
         const int c = cb * KC + chunk * EPC;
         const int cs = c < a.Cin ? c : 0;
         float sc[EPC], sh[EPC];
         if (has_pro) {
+            const int cpad = ncb * KC;
 #pragma unroll
             for (int j = 0; j < EPC; j += 4) {
-                f32x4 s4 = *(const f32x4*)(a.pro_scale + cs + j), t4 = *(const f32x4*)(a.pro_shift + cs + j);
+                f32x4 s4 = *(const f32x4*)(s_pro + cs + j), t4 = *(const f32x4*)(s_pro + cpad + cs + j);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { sc[j + q] = s4[q]; sh[j + q] = t4[q]; }
             }
@@ -451,7 +463,10 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
 #pragma unroll
     for (int j = 0; j < TJ; ++j) bbase[j] = (wn0 + j * 32 + lr) * PITCH + lh * 16;
 
-    issue_halo(it0, 0);
+    const int nunits = (it1 - it0) * ncb;
+    issue_halo(it0, 0, hregA, hokA);
+    if (nunits > 1) issue_halo(it0 + 1 / ncb, 1 % ncb, hregB, hokB);
+    int unit = 0;
     for (int item = it0; item < it1; ++item) {
         const int nt = item / ntile, tile = item - nt * ntile;
         const int n0 = nt * BN;
@@ -477,17 +492,21 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        for (int cb = 0; cb < ncb; ++cb) {
+        for (int cb = 0; cb < ncb; ++cb, ++unit) {
             __syncthreads();                 // previous unit's fragment reads (and the epilogue's use of the halo area) are done
-            commit_halo(cb);
-            __syncthreads();
-            // prefetch the next unit's halo while this unit's MFMAs run
-            if (cb + 1 < ncb) issue_halo(item, cb + 1);
-            else if (item + 1 < it1) issue_halo(item + 1, 0);
+            const int un = unit + 2;         // the stage being committed is free again right after: refill it with unit u+2
+            if (unit & 1) {
+                commit_halo(cb, hregB, hokB);
+                __syncthreads();
+                if (un < nunits) issue_halo(it0 + un / ncb, un % ncb, hregB, hokB);
+            } else {
+                commit_halo(cb, hregA, hokA);
+                __syncthreads();
+                if (un < nunits) issue_halo(it0 + un / ncb, un % ncb, hregA, hokA);
+            }
             const unsigned char* wb = s_w + cb * 9 * WTAP;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                constexpr int dummy = 0; (void)dummy;
                 const int aoff = ((tap / 3) * HPITCH + (tap % 3)) * PITCH;
 #pragma unroll
                 for (int s = 0; s < CPR / 2; ++s) {
@@ -603,7 +622,7 @@ template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI> static int la
     const int ncb = (a.Cin + CPR * EPC - 1) / (CPR * EPC);
     constexpr int HALO_B = NPIX * (CPR * 16 + 16), EPI_B = 256 * BN * (int)sizeof(T);
     int lds = (HALO_B > EPI_B ? HALO_B : EPI_B) + ncb * 9 * BN * (CPR * 16 + 16);
-    a.lds_acc_off = lds; lds += 2 * BN * 4;
+    a.lds_acc_off = lds; lds += 2 * BN * 4 + 2 * ncb * CPR * EPC * 4;      // accumulators + the prologue scale/shift vectors
     auto kern = conv3x3_res_fwd_kernel<T, BN, WM, WN, CPR, BNEPI>;
     static int attr_lds = 0;
     if (lds > attr_lds) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_lds = lds; }
@@ -625,7 +644,7 @@ template <typename T> static int dispatch_res_fwd(const TileArgs& a, hipStream_t
     const int pitch = cpr * 16 + 16;
     const int bn = a.Cout <= 32 ? 32 : (a.Cout <= 64 ? 64 : 128);
     const long halo_b = (long)NPIX * pitch, epi_b = 256L * bn * sizeof(T);
-    long lds = (halo_b > epi_b ? halo_b : epi_b) + (long)ncb * 9 * bn * pitch + 2 * bn * 4;
+    long lds = (halo_b > epi_b ? halo_b : epi_b) + (long)ncb * 9 * bn * pitch + 2 * bn * 4 + 2L * ncb * cpr * EPC * 4;
     *handled = lds <= 154 * 1024 && (a.tiles_x * a.tiles_y * a.N) >= 32;   // even at one tile per block a single bulk weight load beats nine dependent per-tap loads
     if (!*handled) return SAUNET_OK;
 #define RES(BN_, WM_, WN_, CPR_) (a.epi.bn_x ? launch_res_fwd_i<T, BN_, WM_, WN_, CPR_, true>(a, st) : launch_res_fwd_i<T, BN_, WM_, WN_, CPR_, false>(a, st))

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsaunet_hip.so")
+LIB_PATH = os.environ.get("SAUNET_HIP_LIB") or os.path.join(_HERE, "libsaunet_hip.so")      # the override serves A/B kernel measurements
 
 F32, BF16 = 0, 1
 PACK_FWD, PACK_DGRAD, PACK_CONVT_FWD, PACK_CONVT_DGRAD = 0, 1, 2, 3
