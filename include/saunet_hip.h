@@ -268,6 +268,12 @@ int saunet_canny(int dtype, const float* image_nchw3, int N, int H, int W, int l
 /* edge ground truth [N,1,H,W] in {0,1} from labels [N,H,W] (int64): radius-2 distance-transform edges of classes
  * 1..num_classes, bit-identical to data/ac17_dataloader.py:231-258 (mask_to_onehot + onehot_to_binary_edges). */
 int saunet_mask_to_edges(const int64_t* seg, int N, int H, int W, int num_classes, float* edge, void* stream);
+/* test-set post-processing (test_and_pack.py:31-76: undo_crop + order-0 resize to the original grid) as one gather:
+ * out[z][Y][X] = p[floor((Y+.5)*h/H)][floor((X+.5)*w/W)],  p[y][x] = pred[z][by0+y-top][bx0+x-left] inside the cw x ch window, else 0.
+ * pred int64 [Z][th][tw] (argmax labels), out uint8 [Z][H][W]; the geometry comes from the host (postprocess.undo_crop_geometry). */
+int saunet_labels_uncrop_resize(const int64_t* pred, int Z, int th, int tw, int bx0, int by0, int cw, int ch, int left, int top,
+                                int w, int h, int W, int H, unsigned char* out, void* stream);
+
 
 /* ---- optimiser (train.py:166-216, radam.py:5-78) as multi-tensor kernels ------------------------*/
 typedef struct saunet_tensor_list { int32_t count; const void* ptrs[4][96]; int64_t numel[96]; } saunet_tensor_list;

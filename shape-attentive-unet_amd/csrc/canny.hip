@@ -167,9 +167,39 @@ __global__ __launch_bounds__(256) void mask_to_edges_kernel(const int64_t* __res
     }
 }
 
+// Test-set post-processing (/root/reference/test_and_pack.py:31-76): undo_crop followed by the order-0 resize back to the original
+// grid, as ONE gather over the predicted labels:  out[z][Y][X] = p[z][floor((Y+.5)*h/H)][floor((X+.5)*w/W)]  with the un-cropped map
+// p[y][x] = pred[by0 + y - top][bx0 + x - left] inside the pasted window (cw x ch at (left, top)) and 0 outside.
+__global__ __launch_bounds__(256) void labels_uncrop_resize_kernel(const int64_t* __restrict__ pred, int Z, int th, int tw, int bx0, int by0, int cw, int ch,
+                                                                   int left, int top, int w, int h, int W, int H, unsigned char* __restrict__ out)
+{
+    const long total = (long)Z * H * W;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int X = (int)(i % W); long t = i / W; const int Y = (int)(t % H); const int z = (int)(t / H);
+        int y = (int)(((2L * Y + 1) * h) / (2L * H)), x = (int)(((2L * X + 1) * w) / (2L * W));     // floor((Y + 0.5) * h / H), exact in integers
+        y = min(y, h - 1); x = min(x, w - 1);
+        const int sy = y - top, sx = x - left;
+        unsigned char v = 0;
+        if ((unsigned)sy < (unsigned)ch && (unsigned)sx < (unsigned)cw) v = (unsigned char)pred[((long)z * th + by0 + sy) * tw + bx0 + sx];
+        out[i] = v;
+    }
+}
+
 }  // namespace saunet
 
 using namespace saunet;
+
+extern "C" int saunet_labels_uncrop_resize(const int64_t* pred, int Z, int th, int tw, int bx0, int by0, int cw, int ch, int left, int top,
+                                           int w, int h, int W, int H, unsigned char* out, void* stream)
+{
+    if (Z <= 0 || th <= 0 || tw <= 0 || w <= 0 || h <= 0 || W <= 0 || H <= 0 || bx0 < 0 || by0 < 0 || bx0 + cw > tw || by0 + ch > th)
+        return set_error(SAUNET_BAD_SHAPE, "labels_uncrop_resize: window %dx%d at (%d,%d) outside the %dx%d prediction", cw, ch, bx0, by0, tw, th);
+    const long total = (long)Z * H * W;
+    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(labels_uncrop_resize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, Z, th, tw, bx0, by0, cw, ch, left, top, w, h, W, H, out);
+    SAUNET_CHECK_LAUNCH("labels_uncrop_resize");
+    return SAUNET_OK;
+}
 
 extern "C" int saunet_mask_to_edges(const int64_t* seg, int N, int H, int W, int num_classes, float* edge, void* stream)
 {

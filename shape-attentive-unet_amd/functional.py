@@ -121,6 +121,7 @@ def notify_params_changed():
     themselves; only ``graph.replay()`` needs the explicit call -- saunet_amd.graph.GraphedStep makes it.)"""
     PACKS.invalidate()
     _EVAL_BN.clear()
+    INFER.clear()
 
 
 class PackedWeights:
@@ -208,6 +209,73 @@ class PackedWeights:
 PACKS = PackedWeights()
 
 
+class InferenceCache:
+    """Derived inference tensors (BatchNorm folded into convolution weights, packed for the MFMA kernels) keyed by the tensors they
+    derive from: identity + version counter of each + PACKS.generation (bumped by fused optimiser steps, training-mode BatchNorm and
+    notify_params_changed).  Entries are never modified in place: when a source changes a NEW entry is built, and once a hipGraph has
+    been captured while the cache was in use, replaced entries are kept alive (a captured inference graph reads their addresses)."""
+
+    def __init__(self):
+        self.entries = {}
+        self.retired = []
+        self.seen_capture = False
+
+    def get(self, tensors, build):
+        key = tuple(id(t) for t in tensors)
+        vers = tuple(t._version for t in tensors) + (PACKS.generation,)
+        ent = self.entries.get(key)
+        if capturing():
+            self.seen_capture = True
+        if ent is not None and ent[0] == vers and all(r() is t for r, t in zip(ent[1], tensors)):
+            return ent[2]
+        val = build()
+        if ent is not None and self.seen_capture:
+            self.retired.append(ent[2])
+        if len(self.entries) > 4096:
+            self.entries = {k: v for k, v in self.entries.items() if all(r() is not None for r in v[1])}
+        self.entries[key] = (vers, [weakref.ref(t) for t in tensors], val)
+        return val
+
+    def clear(self):
+        if self.seen_capture:
+            self.retired.extend(v[2] for v in self.entries.values())
+        self.entries = {}
+
+
+INFER = InferenceCache()
+
+
+def _pack_now(w, mode, dtype):
+    """pack a float32 weight tensor (not a Parameter) into a fresh buffer"""
+    wd = w.detach()
+    if not wd.is_contiguous() or wd.dtype != torch.float32:
+        wd = wd.contiguous().float()
+    if mode in (L.PACK_CONVT_FWD, L.PACK_CONVT_DGRAD):
+        ci, co, kh, kw = wd.shape
+    else:
+        co, ci, kh, kw = wd.shape
+    out = torch.empty(wd.numel(), dtype=dtype, device=wd.device)
+    L.call("saunet_pack_weight", mode, L.BF16 if dtype == torch.bfloat16 else L.F32, wd.data_ptr(), co, ci, kh, kw, out.data_ptr(), L.stream())
+    return out
+
+
+def folded_conv_bn(weight, bias, bn, transposed, dtype):
+    """Inference: (packed w', b') with BatchNorm folded in -- w' = w * gamma/sqrt(var+eps) per output channel, b' = beta - mean*scale
+    (+ scale * conv bias).  Cached until the weights or the running statistics change."""
+    srcs = [weight, bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([bias] if bias is not None else [])
+
+    def build():
+        p = bn_finalize(None, 1, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, False)
+        wf = weight.detach() * (p.scale.view(1, -1, 1, 1) if transposed else p.scale.view(-1, 1, 1, 1))
+        bf = p.shift.clone() if bias is None else torch.addcmul(p.shift, bias.detach(), p.scale)
+        return _pack_now(wf, L.PACK_CONVT_FWD if transposed else L.PACK_FWD, dtype), bf
+
+    return INFER.get(srcs + [_DTYPE_TOKEN[dtype]], build)
+
+
+_DTYPE_TOKEN = {torch.float32: torch.zeros(0), torch.bfloat16: torch.zeros(0)}    # distinct key objects per storage dtype
+
+
 def _desc(x, cout, ldy, ho, wo, kh, kw, stride, pad, transposed=False, pro_relu=False, cin=None):
     d = L.ConvDesc()
     d.dtype = L.dtype_code(x)
@@ -228,10 +296,11 @@ def conv_out_hw(h, w, kh, kw, stride, pad, transposed):
     return (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
 
 
-def conv_forward_raw(x, weight, bias, stride, pad, transposed=False, pro=None, out=None, stats=None, act_relu=False):
+def conv_forward_raw(x, weight, bias, stride, pad, transposed=False, pro=None, out=None, stats=None, act_relu=False, packed=None):
     """y = conv(prologue(x), weight) + bias.  pro = (scale, shift, relu) or None.
     out: optional pre-allocated (channel-slice) destination.  stats = [R, 2, Cout] float64 accumulators (may be a
-    channel slice of a wider [R, 2, Ctot] buffer)."""
+    channel slice of a wider [R, 2, Ctot] buffer).  packed: the already packed (forward layout, storage dtype) form of `weight`
+    -- inference passes its cached folded weights here; `weight` then only supplies the shape."""
     _check_dev(x)
     x = nhwc(x)
     if transposed:
@@ -243,7 +312,7 @@ def conv_forward_raw(x, weight, bias, stride, pad, transposed=False, pro=None, o
     ho, wo = conv_out_hw(x.shape[2], x.shape[3], kh, kw, stride, pad, transposed)
     if out is None:
         out = new_act(x.shape[0], cout, ho, wo, x.dtype, x.device)
-    wp = PACKS.get(weight, L.PACK_CONVT_FWD if transposed else L.PACK_FWD, x.dtype)
+    wp = packed if packed is not None else PACKS.get(weight, L.PACK_CONVT_FWD if transposed else L.PACK_FWD, x.dtype)
     d = _desc(x, cout, ld_of(out), ho, wo, kh, kw, stride, pad, transposed, bool(pro and pro[2]))
     if stats is not None:
         d.stat_replicas, d.stat_rstride = stats.shape[0], stats.stride(0)
@@ -632,10 +701,15 @@ def conv_bn_act(x, weight, bias, bn, relu=True, residual=None, stride=1, padding
     if not bn.training and not torch.is_grad_enabled() and residual is None and x.is_cuda:
         # inference: BatchNorm folded into the convolution -- w' = w * gamma/sqrt(var+eps) per output channel, b' = the BN shift
         # (incl. the conv bias), ReLU in the conv epilogue: one kernel, no normalisation pass
-        p = bn_finalize(None, 1, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, False)
-        wf = weight * (p.scale.view(1, -1, 1, 1) if transposed else p.scale.view(-1, 1, 1, 1))
-        bf = p.shift if bias is None else torch.addcmul(p.shift, bias, p.scale)
-        y = conv_forward_raw(x, wf, bf, stride, padding, transposed, act_relu=relu, out=out)
+        x = nhwc(x)
+        if isinstance(weight, torch.nn.Parameter):
+            wp, bf = folded_conv_bn(weight, bias, bn, transposed, x.dtype)          # folded + packed once, cached across calls
+            y = conv_forward_raw(x, weight, bf, stride, padding, transposed, act_relu=relu, out=out, packed=wp)
+        else:        # derived weight tensors (the stem's im2col matrix): fold on the fly
+            p = bn_finalize(None, 1, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, False)
+            wf = weight * (p.scale.view(1, -1, 1, 1) if transposed else p.scale.view(-1, 1, 1, 1))
+            bf = p.shift if bias is None else torch.addcmul(p.shift, bias, p.scale)
+            y = conv_forward_raw(x, wf, bf, stride, padding, transposed, act_relu=relu, out=out)
         if pool is not None:
             L.call("saunet_global_avgpool", L.dtype_code(y), y.data_ptr(), y.shape[0], y.shape[2] * y.shape[3], y.shape[1], ld_of(y), pool.data_ptr(), L.stream())
         return y
@@ -1354,8 +1428,31 @@ class _DenseBlock(torch.autograd.Function):
         return (dx0, None, None) + tuple(grads) + (None,) * (4 * nl)
 
 
+def dense_block_infer(x0, layers):
+    """Inference form of a DenseNet block: per layer ONE prologue'd 1x1 conv whose weights carry norm2 (w' = w * s2, bias = t2, ReLU in the
+    epilogue -> the 3x3 conv needs no prologue) and one plain 3x3 conv writing its 32 channels into the concat buffer.  norm1 cannot be
+    folded (a ReLU sits between it and conv1 and every layer has its own gamma/beta over the shared concat channels): it stays the operand
+    prologue, with its eval-mode coefficients cached (bn_finalize)."""
+    x0 = nhwc(x0)
+    n, c0, h, w = x0.shape
+    growth = layers[0].conv2.weight.shape[0]
+    ctot = c0 + growth * len(layers)
+    buf = new_act(n, ctot, h, w, x0.dtype, x0.device)
+    copy_channels(x0, buf[:, :c0])
+    cin = c0
+    for m in layers:
+        p1 = bn_finalize(None, 1, m.norm1.weight, m.norm1.bias, m.norm1.running_mean, m.norm1.running_var, m.norm1.momentum, m.norm1.eps, False)
+        w1p, b1 = folded_conv_bn(m.conv1.weight, None, m.norm2, False, x0.dtype)
+        a2 = conv_forward_raw(buf[:, :cin], m.conv1.weight, b1, 1, 0, pro=(p1.scale, p1.shift, True), act_relu=True, packed=w1p)
+        conv_forward_raw(a2, m.conv2.weight, None, 1, 1, out=buf[:, cin:cin + growth])
+        cin += growth
+    return buf
+
+
 def dense_block(x0, layers, training):
     """layers: list of modules with norm1, conv1, norm2, conv2.  Returns (concat buffer, its channel statistics)."""
+    if not training and not torch.is_grad_enabled() and x0.is_cuda:
+        return dense_block_infer(x0, layers), None
     params, bufs, cfgs = [], [], []
     for m in layers:
         params += [m.norm1.weight, m.norm1.bias, m.conv1.weight, m.norm2.weight, m.norm2.bias, m.conv2.weight]

@@ -91,6 +91,7 @@ _SIGS = {
     "saunet_softmax_argmax": [i32, vp, i32, i64, i32, vp, i32, vp, vp],
     "saunet_canny": [i32, vp, i32, i32, i32, i32, i32, vp, vp, vp],
     "saunet_mask_to_edges": [vp, i32, i32, i32, i32, vp, vp],
+    "saunet_labels_uncrop_resize": [vp] + [i32] * 13 + [vp, vp],
     "saunet_sgd_step": [C.POINTER(TensorList), vp, vp],
     "saunet_radam_step": [C.POINTER(TensorList), vp, vp],
     "saunet_adam_step": [C.POINTER(TensorList), vp, vp],

@@ -214,3 +214,40 @@ def test_properties_at_bench_size():
     l1 = crit((lg1.detach(), eo.detach()), (seg.cuda(), edge.cuda()))
     l2 = crit((lg1.detach() + 3.0, eo.detach()), (seg.cuda(), edge.cuda()))
     assert abs(float(l1) - float(l2)) < 1e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+def test_inference_path_folded_and_cached(dtype, tol):
+    """Eval-mode forward without grad (the inference path: BatchNorm folded into the conv weights -- incl. DenseNet norm2 -> conv1 --, folded
+    weights cached across calls, device softmax/argmax) against the oracle's eval forward; the cache must follow weight changes
+    (load_state_dict, an optimiser step) and survive unchanged weights (second call issues no fold / pack work: same result object ids)."""
+    S, spec, sd, net, sm = make_net(23, dtype)
+    try:
+        img, seg, edge = Wt.synthetic_batch(2, 128, 128, seed=55)
+        with torch.no_grad():
+            lg_o, eo_o = R.saunet_forward({k: v.clone() for k, v in sd.items()}, img, False)
+        net.eval()
+        HF = S.functional
+        with torch.no_grad():
+            lg, eo = net(img.cuda())
+            n_entries = len(HF.INFER.entries)
+            ids = {k: id(v[2]) for k, v in HF.INFER.entries.items()}
+            lg2, _ = net(img.cuda())
+        assert n_entries >= 58 + 10                                   # every dense layer's folded conv1 + the conv-BN-ReLU units
+        assert {k: id(v[2]) for k, v in HF.INFER.entries.items()} == ids      # second call: pure cache hits
+        assert torch.equal(lg, lg2)
+        scale = float(lg_o.abs().max())
+        assert float((lg.float().cpu() - lg_o).abs().max()) < tol * scale
+        assert float((eo.float().cpu() - eo_o).abs().max()) < max(tol, 2e-3)
+        prob, label = HF.softmax_argmax(lg)
+        ref = torch.softmax(lg.float(), 1)
+        assert float((prob - ref).abs().max()) < 1e-5 and torch.equal(label, lg.float().argmax(1))
+        # weights change -> folded copies must follow
+        sd2 = Wt.make_state_dict(spec, 24)
+        net.load_state_dict(sd2, strict=False)            # in-place copies bump the version counters the caches are keyed on
+        with torch.no_grad():
+            lg3, _ = net(img.cuda())
+            lg3_o, _ = R.saunet_forward({k: v.clone() for k, v in sd2.items()}, img, False)
+        assert float((lg3.float().cpu() - lg3_o).abs().max()) < tol * float(lg3_o.abs().max())
+    finally:
+        S.set_compute_dtype(torch.float32)
