@@ -404,23 +404,39 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
     u32x4 hregA[H_ITERS], hregB[H_ITERS];
     bool hokA[H_ITERS], hokB[H_ITERS];
 
-    auto issue_halo = [&](int item, int cb, u32x4 (&hreg)[H_ITERS], bool (&hok)[H_ITERS]) {   // global -> registers (no wait)
-        const int tile = item % ntile;
-        int bt = tile;
-        const int txi = bt % a.tiles_x; bt /= a.tiles_x;
-        const int tyi = bt % a.tiles_y; const int n = bt / a.tiles_y;
-        const T* xg = (const T*)a.x + (size_t)n * a.H * a.W * a.ldx;
-        const int c = cb * KC + chunk * EPC;
+    // Prefetch cursor: the (tile, channel block) unit whose halo is issued next.  Units are visited in order, so the tile coordinates advance
+    // incrementally (no integer division in the loop: the five runtime div/mod of a from-scratch decode cost ~1000 cycles per issue), and
+    // everything that depends only on the thread (its halo pixel and chunk per piece) is decoded once.
+    int poff[H_ITERS], phyx[H_ITERS];
+#pragma unroll
+    for (int i = 0; i < H_ITERS; ++i) {
+        const int q = tid + i * NT;
+        const int pix = q / CPR;
+        const int hy = pix / HPITCH, hx = pix - hy * HPITCH;
+        poff[i] = (hy * a.W + hx) * a.ldx;
+        phyx[i] = q < NPIX * CPR ? (hy | (hx << 8)) : (0x7f | (0x7f << 8));      // pieces beyond the halo never pass the bounds test
+    }
+    int p_cb = 0, p_txi, p_tyi, p_n;
+    {
+        int bt = it0 % ntile;
+        p_txi = bt % a.tiles_x; bt /= a.tiles_x;
+        p_tyi = bt % a.tiles_y; p_n = bt / a.tiles_y;
+    }
+    auto issue_halo = [&](u32x4 (&hreg)[H_ITERS], bool (&hok)[H_ITERS]) {   // global -> registers (no wait); advances the cursor by one unit
+        const int c = p_cb * KC + chunk * EPC;
         const bool cok = c < a.Cin;
+        const int y0 = p_tyi * TILE - 1, x0 = p_txi * TILE - 1;
+        const T* xg = (const T*)a.x + ((size_t)p_n * a.H * a.W + (ptrdiff_t)y0 * a.W + x0) * a.ldx + (cok ? c : 0);
 #pragma unroll
         for (int i = 0; i < H_ITERS; ++i) {
-            const int q = tid + i * NT;
-            const int pix = q / CPR;
-            const int hy = pix / HPITCH, hx = pix - hy * HPITCH;
-            const int iy = tyi * TILE + hy - 1, ix = txi * TILE + hx - 1;
-            const bool ok = cok && q < NPIX * CPR && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const int iy = y0 + (phyx[i] & 0xff), ix = x0 + (phyx[i] >> 8);
+            const bool ok = cok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             hok[i] = ok;
-            hreg[i] = *(const u32x4*)(xg + (ok ? (size_t)(iy * a.W + ix) * a.ldx + c : (size_t)0));
+            hreg[i] = *(const u32x4*)(ok ? xg + poff[i] : (const T*)a.x);
+        }
+        if (++p_cb == ncb) {
+            p_cb = 0;
+            if (++p_txi == a.tiles_x) { p_txi = 0; if (++p_tyi == a.tiles_y) { p_tyi = 0; if (++p_n == a.N) p_n = 0; } }
         }
     };
     auto commit_halo = [&](int cb, u32x4 (&hreg)[H_ITERS], bool (&hok)[H_ITERS]) {            // transform + registers -> LDS
@@ -464,70 +480,73 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
     for (int j = 0; j < TJ; ++j) bbase[j] = (wn0 + j * 32 + lr) * PITCH + lh * 16;
 
     const int nunits = (it1 - it0) * ncb;
-    issue_halo(it0, 0, hregA, hokA);
-    if (nunits > 1) issue_halo(it0 + 1 / ncb, 1 % ncb, hregB, hokB);
-    int unit = 0;
-    for (int item = it0; item < it1; ++item) {
-        const int nt = item / ntile, tile = item - nt * ntile;
-        const int n0 = nt * BN;
-        if (nt != cur_nt) {   // (re)load this n-tile's weights: [cb][tap][BN rows][PITCH]
-            if (cur_nt >= 0) flush_acc(cur_nt);
-            __syncthreads();
-            const int pieces = ncb * 9 * BN * CPR;
-            for (int q = tid; q < pieces; q += NT) {
-                const int ch = q % CPR; int t = q / CPR;
-                const int brow = t % BN; t /= BN;
-                const int tap = t % 9, cb = t / 9;
-                const int c = cb * KC + ch * EPC;
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (n0 + brow < a.Cout && c < a.Cin) v = *(const u32x4*)(wg + ((size_t)(n0 + brow) * 9 + tap) * a.Cin + c);
-                *(u32x4*)(s_w + (cb * 9 + tap) * WTAP + brow * PITCH + ch * 16) = v;
-            }
-            cur_nt = nt;
-        }
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr bool TWO = BN < 128;      // the 128-wide tile has no registers to spare for a second stage
+    constexpr int AHEAD = TWO ? 2 : 1;
+    issue_halo(hregA, hokA);
+    if (TWO && nunits > 1) issue_halo(hregB, hokB);
 
-        for (int cb = 0; cb < ncb; ++cb, ++unit) {
-            __syncthreads();                 // previous unit's fragment reads (and the epilogue's use of the halo area) are done
-            const int un = unit + 2;         // the stage being committed is free again right after: refill it with unit u+2
-            if (unit & 1) {
-                commit_halo(cb, hregB, hokB);
+    // Compute cursor (the unit whose MFMAs run): advanced incrementally like the prefetch cursor.
+    int c_cb = 0, c_nt = it0 / ntile, c_txi, c_tyi, c_n;
+    {
+        int bt = it0 % ntile;
+        c_txi = bt % a.tiles_x; bt /= a.tiles_x;
+        c_tyi = bt % a.tiles_y; c_n = bt / a.tiles_y;
+    }
+    // One unit = one (tile, channel block).  The body is instantiated once per register stage and the unit loop below is unrolled by two,
+    // so each stage is a FIXED set of registers in straight-line code: selecting the stage with a runtime `unit & 1` made the compiler shuffle
+    // the two register sets through v_mov copies behind an s_waitcnt vmcnt(0), i.e. it waited for the loads it had just issued (3-6k cycles on
+    // every second unit, measured with s_memtime stamps).
+    auto unit_body = [&](u32x4 (&hreg)[H_ITERS], bool (&hok)[H_ITERS], int unit) {
+        const int n0 = c_nt * BN;
+        if (c_cb == 0) {
+            if (c_nt != cur_nt) {   // (re)load this n-tile's weights: [cb][tap][BN rows][PITCH]
+                if (cur_nt >= 0) flush_acc(cur_nt);
                 __syncthreads();
-                if (un < nunits) issue_halo(it0 + un / ncb, un % ncb, hregB, hokB);
-            } else {
-                commit_halo(cb, hregA, hokA);
-                __syncthreads();
-                if (un < nunits) issue_halo(it0 + un / ncb, un % ncb, hregA, hokA);
-            }
-            const unsigned char* wb = s_w + cb * 9 * WTAP;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int aoff = ((tap / 3) * HPITCH + (tap % 3)) * PITCH;
-#pragma unroll
-                for (int s = 0; s < CPR / 2; ++s) {
-                    u32x4 af[TI], bfr[TJ];
-#pragma unroll
-                    for (int i = 0; i < TI; ++i) af[i] = *(const u32x4*)(s_halo + abase[i] + aoff + s * 32);
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j) bfr[j] = *(const u32x4*)(wb + bbase[j] + tap * WTAP + s * 32);
-#pragma unroll
-                    for (int i = 0; i < TI; ++i)
-#pragma unroll
-                        for (int j = 0; j < TJ; ++j) MmaT<T>::run(af[i], bfr[j], acc[i][j]);
+                const int pieces = ncb * 9 * BN * CPR;
+                for (int q = tid; q < pieces; q += NT) {
+                    const int ch = q % CPR; int t = q / CPR;
+                    const int brow = t % BN; t /= BN;
+                    const int tap = t % 9, cb = t / 9;
+                    const int c = cb * KC + ch * EPC;
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (n0 + brow < a.Cout && c < a.Cin) v = *(const u32x4*)(wg + ((size_t)(n0 + brow) * 9 + tap) * a.Cin + c);
+                    *(u32x4*)(s_w + (cb * 9 + tap) * WTAP + brow * PITCH + ch * 16) = v;
                 }
+                cur_nt = c_nt;
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+        __syncthreads();                 // previous unit's fragment reads (and the epilogue's use of the halo area) are done
+        commit_halo(c_cb, hreg, hok);
+        __syncthreads();
+        if (unit + AHEAD < nunits) issue_halo(hreg, hok);      // this stage is free again: refill it with unit u+2 (u+1 with one stage)
+        const unsigned char* wb = s_w + c_cb * 9 * WTAP;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int aoff = ((tap / 3) * HPITCH + (tap % 3)) * PITCH;
+#pragma unroll
+            for (int s = 0; s < CPR / 2; ++s) {
+                u32x4 af[TI], bfr[TJ];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) af[i] = *(const u32x4*)(s_halo + abase[i] + aoff + s * 32);
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) bfr[j] = *(const u32x4*)(wb + bbase[j] + tap * WTAP + s * 32);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) MmaT<T>::run(af[i], bfr[j], acc[i][j]);
             }
         }
+        if (++c_cb < ncb) return;
+        c_cb = 0;
         // ---- epilogue for this tile (output staged in the halo area)
         __syncthreads();
-        int bt = tile;
-        const int txi = bt % a.tiles_x; bt /= a.tiles_x;
-        const int tyi = bt % a.tiles_y; const int n = bt / a.tiles_y;
-        const int ty0 = tyi * TILE, tx0 = txi * TILE;
+        const int n = c_n, ty0 = c_tyi * TILE, tx0 = c_txi * TILE;
         float* s_sum = s_acc;
         float* s_sq = s_acc + BN;
         const bool do_stats = !BNEPI && a.stat_sum != nullptr;
@@ -605,6 +624,15 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
                 if (cok) *(u32x4*)(yg + opix * a.ldy + colv) = *(const u32x4*)(so + row * BN + ch * EPC);
             }
         }
+        if (++c_txi == a.tiles_x) { c_txi = 0; if (++c_tyi == a.tiles_y) { c_tyi = 0; if (++c_n == a.N) { c_n = 0; ++c_nt; } } }
+    };
+    if constexpr (TWO) {
+        for (int unit = 0; unit < nunits; unit += 2) {
+            unit_body(hregA, hokA, unit);
+            if (unit + 1 < nunits) unit_body(hregB, hokB, unit + 1);
+        }
+    } else {
+        for (int unit = 0; unit < nunits; ++unit) unit_body(hregA, hokA, unit);
     }
     flush_acc(cur_nt);
 }
