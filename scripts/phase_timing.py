@@ -1,0 +1,56 @@
+"""Per-phase cycle stamps of one kernel launch (profiling build: python -m saunet_amd._build --timing; run with
+SAUNET_HIP_LIB=scripts/_ab/libsaunet_timing.so).  usage: phase_timing.py <case> ; cases: conv2fwd conv2wgrad conv1wgrad conv1dgrad conv1fwd dec3wgrad"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import saunet_amd as S
+HF = S.functional
+case = sys.argv[1]
+dt = torch.bfloat16
+n = 32
+def act(c, h): return torch.randn(n, c, h, h, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+unit = "conv_tile"
+if case == "conv2fwd":
+    x = act(128, 128); w = torch.nn.Parameter(torch.randn(32, 128, 3, 3, device="cuda") * 0.03)
+    sc = torch.rand(128, device="cuda") + 0.5; sh = torch.randn(128, device="cuda") * 0.1
+    out = HF.new_act(n, 32, 128, 128, dt, "cuda"); st = torch.zeros(HF.STAT_R, 2, 32, dtype=torch.float64, device="cuda")
+    run = lambda: HF.conv_forward_raw(x, w, None, 1, 1, pro=(sc, sh, True), out=out, stats=st)
+elif case in ("conv2wgrad", "conv1wgrad", "dec3wgrad"):
+    cin, h, cout, k = {"conv2wgrad": (128, 128, 32, 3), "conv1wgrad": (192, 128, 128, 1), "dec3wgrad": (512, 64, 128, 3)}[case]
+    x = act(cin, h); dy = act(cout, h); w = torch.nn.Parameter(torch.randn(cout, cin, k, k, device="cuda") * 0.03)
+    sc = torch.rand(cin, device="cuda") + 0.5; sh = torch.randn(cin, device="cuda") * 0.1
+    run = lambda: (HF.GRADS.reset(), HF.conv_wgrad_raw(x, dy, w, 1, k // 2, pro=(sc, sh, True) if case != "dec3wgrad" else None))
+elif case == "conv1fwd":
+    unit = "conv_igemm"
+    x = act(192, 128); w = torch.nn.Parameter(torch.randn(128, 192, 1, 1, device="cuda") * 0.03)
+    sc = torch.rand(192, device="cuda") + 0.5; sh = torch.randn(192, device="cuda") * 0.1
+    out = HF.new_act(n, 128, 128, 128, dt, "cuda"); st = torch.zeros(HF.STAT_R, 2, 128, dtype=torch.float64, device="cuda")
+    run = lambda: HF.conv_forward_raw(x, w, None, 1, 0, pro=(sc, sh, True), out=out, stats=st)
+elif case == "conv1dgrad":
+    unit = "dense_dgrad"
+    cin, ctot, h = 192, 256, 128
+    buf = act(ctot, h); dbuf = act(ctot, h); g = act(128, h)
+    w = torch.nn.Parameter(torch.randn(128, cin, 1, 1, device="cuda") * 0.05)
+    p = HF.BNParams(cin, "cuda"); p.buf[0].uniform_(0.5, 1.5); p.buf[1].normal_(0, 0.3); p.buf[2].normal_(0, 0.3); p.buf[3].uniform_(0.5, 1.5)
+    sums = torch.zeros(HF.STAT_R, 2, cin, dtype=torch.float64, device="cuda")
+    run = lambda: HF.conv_dgrad_raw(g, w, (n, cin, h, h), 1, 0, out=dbuf[:, :cin], bn_epi=(buf[:, :cin], p, True, sums, True))
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+lib = S.lib.load()
+N = 400
+buf_ = (ctypes.c_ulonglong * N)()
+getattr(lib, "saunet_debug_timing_" + unit)(buf_, N)
+vals = [(v >> 56, v & 0x00ffffffffffffff) for v in buf_ if v]
+t0 = vals[0][1]; prev = t0
+import collections
+agg = collections.defaultdict(list)
+last = None
+for slot, t in vals:
+    if last is not None:
+        agg[(last, slot)].append(t - prev)
+    prev = t; last = slot
+print("case", case, "stamps", len(vals), "total cycles", vals[-1][1] - t0)
+for k, v in sorted(agg.items()):
+    v2 = sorted(v)
+    print("  %2d -> %2d : n=%3d  median %6d  min %6d  max %6d  sum %8d" % (k[0], k[1], len(v), v2[len(v2) // 2], v2[0], v2[-1], sum(v)))

@@ -33,7 +33,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, timing=False):
+    """timing=True: the profiling build with the TSTAMP phase stamps compiled in (common.h) -> scripts/_ab/libsaunet_timing.so;
+    select it at run time with SAUNET_HIP_LIB (never used by the product path)."""
+    global OBJ, LIB, FLAGS
+    if timing:
+        OBJ = os.path.join(HERE, "_obj_timing")
+        LIB = os.path.join(ROOT, "scripts", "_ab", "libsaunet_timing.so")
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        FLAGS = FLAGS + ["-DSAUNET_TIMING"]
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
@@ -66,4 +74,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, timing="--timing" in sys.argv))

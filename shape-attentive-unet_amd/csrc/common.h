@@ -125,4 +125,24 @@ struct FastDiv {
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// ---- phase timing (profiling builds only: python -m saunet_amd._build --timing -> scripts/_ab/libsaunet_timing.so) -------------------
+// TSTAMP(slot) records (slot, s_memtime) from thread 0 of ONE block into a per-translation-unit device array that
+// saunet_debug_timing_<unit>() copies out; scripts/phase_timing.py prints the per-phase cycle deltas.  This is how the serialised
+// waits inside a kernel are found when the PMC counters only say "waiting".  In the product build every macro expands to nothing.
+#ifdef SAUNET_TIMING
+static __device__ unsigned long long g_timing[2048];
+#define TSTAMP_INIT() int tcount__ = 0
+#define TSTAMP(slot) do { if (blockIdx.x == SAUNET_TIMING_BLOCK && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && tcount__ < 2000) \
+        g_timing[tcount__++] = ((unsigned long long)(slot) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); } while (0)
+#define SAUNET_TIMING_READER(unit) extern "C" int saunet_debug_timing_##unit(unsigned long long* out, int n) \
+    { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(saunet::g_timing), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost); }
+#ifndef SAUNET_TIMING_BLOCK
+#define SAUNET_TIMING_BLOCK 7
+#endif
+#else
+#define TSTAMP_INIT() do {} while (0)
+#define TSTAMP(slot) do {} while (0)
+#define SAUNET_TIMING_READER(unit)
+#endif
+
 }  // namespace saunet

@@ -480,6 +480,8 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
     for (int j = 0; j < TJ; ++j) bbase[j] = (wn0 + j * 32 + lr) * PITCH + lh * 16;
 
     const int nunits = (it1 - it0) * ncb;
+    TSTAMP_INIT();
+    TSTAMP(0);
     constexpr bool TWO = BN < 128;      // the 128-wide tile has no registers to spare for a second stage
     constexpr int AHEAD = TWO ? 2 : 1;
     issue_halo(hregA, hokA);
@@ -521,10 +523,15 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         }
+        TSTAMP(1);
         __syncthreads();                 // previous unit's fragment reads (and the epilogue's use of the halo area) are done
+        TSTAMP(2);
         commit_halo(c_cb, hreg, hok);
+        TSTAMP(3);
         __syncthreads();
+        TSTAMP(4);
         if (unit + AHEAD < nunits) issue_halo(hreg, hok);      // this stage is free again: refill it with unit u+2 (u+1 with one stage)
+        TSTAMP(5);
         const unsigned char* wb = s_w + c_cb * 9 * WTAP;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -542,6 +549,7 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
                     for (int j = 0; j < TJ; ++j) MmaT<T>::run(af[i], bfr[j], acc[i][j]);
             }
         }
+        TSTAMP(6);
         if (++c_cb < ncb) return;
         c_cb = 0;
         // ---- epilogue for this tile (output staged in the halo area)
@@ -788,12 +796,16 @@ __global__ __launch_bounds__(256, 2) void conv_tile_wgrad_kernel(TileWgradArgs a
 
     const int li = lane & 15, lg = lane >> 4, nhalf = lg & 1, khalf = lg >> 1;
 
+    TSTAMP_INIT();
+    TSTAMP(20);
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         int bt = tile;
         const int txi = bt % a.tiles_x; bt /= a.tiles_x;
         const int tyi = bt % a.tiles_y; const int n = bt / a.tiles_y;
         const int ty0 = tyi * TR, tx0 = txi * TILE;
+        TSTAMP(21);
         __syncthreads();   // previous tile fully consumed
+        TSTAMP(22);
         {
             u32x4 yreg[YI];
             const u32x4 z = {0u, 0u, 0u, 0u};
@@ -812,6 +824,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_wgrad_kernel(TileWgradArgs a
                 if (YI * 256 == NPY * CHY || q < NPY * CHY) *(u32x4*)(s_y + pix * PY + ch * 16) = yreg[i];
             }
         }
+        TSTAMP(23);
 #pragma unroll
         for (int b0 = 0; b0 < XI; b0 += XB) {
             u32x4 xreg[XB]; bool okx[XB]; int cx[XB];
@@ -854,7 +867,9 @@ __global__ __launch_bounds__(256, 2) void conv_tile_wgrad_kernel(TileWgradArgs a
                 if ((b0 + i < XI) && q < NPX * CHX) *(u32x4*)(s_x + pix * PX + ch * 16) = okx[i] ? xreg[i] : z;
             }
         }
+        TSTAMP(24);
         __syncthreads();
+        TSTAMP(25);
         // ---- one MFMA K-step = one tile row (16 pixels)
         for (int ty = kwave; ty < TR; ty += KSPLIT) {
             if constexpr (sizeof(T) == 2) {
@@ -898,6 +913,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_wgrad_kernel(TileWgradArgs a
             }
         }
     }
+    TSTAMP(26);
     const int lr = lane & 31, lh = lane >> 5;
     float* s_red = (float*)smem;   // [KSPLIT-1][64 lanes][16] floats per (m, n, tap) round
 #pragma unroll
@@ -946,7 +962,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 static int tile_wgrad_groups(int ntiles, int nchan_tiles)
 {
-    int groups = 512 / nchan_tiles; if (groups < 1) groups = 1; if (groups > ntiles) groups = ntiles;
+    int groups = 512 / nchan_tiles; if (groups < 1) groups = 1;
+    if (groups > ntiles) groups = ntiles;
     // every group writes a full partial gradient: on small maps (few pixel tiles) let a block take at least two tiles as long as
     // 256 blocks remain
     if (groups > ntiles / 2 && (ntiles / 2) * nchan_tiles >= 256) groups = ntiles / 2;
@@ -1037,3 +1054,5 @@ int tile_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const f
 }
 
 }  // namespace saunet
+
+SAUNET_TIMING_READER(conv_tile)
