@@ -274,6 +274,23 @@ int saunet_mask_to_edges(const int64_t* seg, int N, int H, int W, int num_classe
 int saunet_labels_uncrop_resize(const int64_t* pred, int Z, int th, int tw, int bx0, int by0, int cw, int ch, int left, int top,
                                 int w, int h, int W, int H, unsigned char* out, void* stream);
 
+/* ---- training-time augmentation on the device (data/augmentations.py:223-264, 308-331, 392-412; data/ac17_dataloader.py:22-57,
+ * 139-150, 196-216, 260-287) over a zero-padded batch of raw slices [B][Hm][Wm] (float32 image, float32 mask) -------------------------
+ * geometric: PaddingCenterCrop(S) + flips + rotation as ONE gather per output pixel (image bilinear, mask nearest, fill 0).  params is a
+ *   device array of B records {int32 h, w, oy, ox, hflip, vflip, rotate; float cos, sin}: (h, w) the slice size, (oy, ox) the crop/pad offset
+ *   (source = output + offset), rotate = 0 skips the affine map.
+ * gamma_zscore: per slice x <- zscore(((x-min)/(max-min+1e-7))^gamma * (max-min) + min), population std (+1e-10); gamma <= 0: z-score only.
+ * uniform_noise / gauss_blur / elastic_warp: displacement = gaussian_filter(2u-1, sigma, zero boundary) * alpha (weights = normalised half
+ *   kernel [0..radius]); out(r,c) = in(r+drow, c+dcol), order 1, edge replication; apply[b] = 0 copies slice b through; mask outputs:
+ *   seg_f (interpolated), seg_long = trunc, seg_edge = the value where it is an exact class id 1..3 else 0 (input of saunet_mask_to_edges). */
+int saunet_augment_geometric(const float* img, const float* seg, int B, int Hm, int Wm, const void* params, int S, float* out_img, float* out_seg, void* stream);
+int saunet_augment_gamma_zscore(float* x, int B, int npix, const float* gamma, void* stream);
+int saunet_uniform_noise(uint64_t seed, float* out, int64_t n, void* stream);
+int saunet_gauss_blur(const float* in, float* tmp, float* out, int B, int H, int W, const float* weights, int radius, int affine_2u_minus_1, float scale, void* stream);
+int saunet_elastic_warp(const float* img, const float* seg, const float* drow, const float* dcol, const int* apply, int B, int H, int W,
+                        float* out_img, float* seg_f, int64_t* seg_long, int64_t* seg_edge, void* stream);
+
+
 
 /* ---- optimiser (train.py:166-216, radam.py:5-78) as multi-tensor kernels ------------------------*/
 typedef struct saunet_tensor_list { int32_t count; const void* ptrs[4][96]; int64_t numel[96]; } saunet_tensor_list;

@@ -35,3 +35,9 @@ print("%-8s %-9s %-9s %-10s %-8s %-7s %-7s %s" % ("calls/st", "ms/step", "MB/cal
 for d, k, n, fb, wb, util, valu in rows[:40]:
     print("%-8.1f %-9.3f %-9.1f %-10.0f %-8.2f %-7.1f %-7.1f %s" % (n / steps, d / steps / 1e6, (fb + wb) / n / 1e6, (fb + wb) / d if d else 0, 100 * d / tot, 100 * util, 100 * valu, short(k)))
 print("# all kernels: %.2f ms/step, %.1f GB/step HBM traffic, average %.0f GB/s" % (tot / steps / 1e6, sum(r[3] + r[4] for r in rows) / steps / 1e9, sum(r[3] + r[4] for r in rows) / tot))
+if len(sys.argv) > 3:      # machine-readable record for bench.py's roofline.step (profiles/step_pmc.json)
+    import json
+    json.dump({"config": [256, 32, "bf16"], "traffic_bytes_per_step": sum(r[3] + r[4] for r in rows) / steps,
+               "kernel_ms_per_step": tot / steps / 1e6, "steps": steps,
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --no-graph` (scripts/collect_step_pmc.sh); bytes = FETCH_SIZE*2 + WRITE_SIZE"},
+              open(sys.argv[3], "w"), indent=1)

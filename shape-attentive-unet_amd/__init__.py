@@ -15,5 +15,6 @@ from . import optim  # noqa: F401
 from . import dp  # noqa: F401
 from . import graph  # noqa: F401
 from . import postprocess  # noqa: F401
+from . import augment  # noqa: F401
 
 __version__ = "0.1.0"

@@ -92,6 +92,11 @@ _SIGS = {
     "saunet_canny": [i32, vp, i32, i32, i32, i32, i32, vp, vp, vp],
     "saunet_mask_to_edges": [vp, i32, i32, i32, i32, vp, vp],
     "saunet_labels_uncrop_resize": [vp] + [i32] * 13 + [vp, vp],
+    "saunet_augment_geometric": [vp, vp, i32, i32, i32, vp, i32, vp, vp, vp],
+    "saunet_augment_gamma_zscore": [vp, i32, i32, vp, vp],
+    "saunet_uniform_noise": [C.c_uint64, vp, i64, vp],
+    "saunet_gauss_blur": [vp, vp, vp, i32, i32, i32, vp, i32, i32, f32, vp],
+    "saunet_elastic_warp": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp],
     "saunet_sgd_step": [C.POINTER(TensorList), vp, vp],
     "saunet_radam_step": [C.POINTER(TensorList), vp, vp],
     "saunet_adam_step": [C.POINTER(TensorList), vp, vp],
