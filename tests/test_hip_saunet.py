@@ -235,7 +235,8 @@ def test_inference_path_folded_and_cached(dtype, tol):
             lg2, _ = net(img.cuda())
         assert n_entries >= 58 + 10                                   # every dense layer's folded conv1 + the conv-BN-ReLU units
         assert {k: id(v[2]) for k, v in HF.INFER.entries.items()} == ids      # second call: pure cache hits
-        assert float((lg.float() - lg2.float()).abs().max()) <= 1e-3 * float(lg.float().abs().max())      # float atomics in the SE pool: last-bit noise only
+        # float atomics in the SE pool: last-bit noise in float32, a few flipped bf16 roundings downstream in bf16
+        assert float((lg.float() - lg2.float()).abs().max()) <= (1e-3 if dtype == torch.float32 else 3e-2) * float(lg.float().abs().max())
         scale = float(lg_o.abs().max())
         assert float((lg.float().cpu() - lg_o).abs().max()) < tol * scale
         assert float((eo.float().cpu() - eo_o).abs().max()) < max(tol, 2e-3)
