@@ -65,6 +65,8 @@ constexpr int DG_WAVES = 4;
 __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgradArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char d_smem[];
+    TSTAMP_INIT();
+    TSTAMP(40);
     const int g0 = blockIdx.y * a.group;
     const int GC = min(a.group, a.Cin - g0);           // channels of this group (multiple of 8)
     const int GCP = (GC + 31) & ~31;
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgra
         s_sum[i] = 0.f; s_sum[GCP + i] = 0.f;
     }
     __syncthreads();
+    TSTAMP(41);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
     const unsigned ntp = (a.P + 31) / 32;
     const unsigned stride = gridDim.x * DG_WAVES;
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgra
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) gf[ks] = live ? *(const u32x4*)(grow + ks * 16) : u32x4{0u, 0u, 0u, 0u};
         }
+        TSTAMP(42);
         XP cur, nxt;                  // x (needed first, for the mask) is requested one step ahead; y at the start of its own step
         request_x(pp, 0, cur);
         u16* yrow = a.y + pp * a.ldy + g0 + 8 * lh;
@@ -129,6 +133,7 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgra
                 yv[i] = ok ? *(const u32x4*)(yrow + step * 64 + 16 * i) : u32x4{0u, 0u, 0u, 0u};
             }
             if (step + 1 < nsteps) request_x(pp, step + 1, nxt);
+            TSTAMP(43);
             u32x4 outv[4];          // the step's four 16-byte output pieces leave together: the L2 sees whole 128-byte lines
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -177,10 +182,12 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgra
                     outv[2 * t + r] = Vec16<u16>::pack(o);
                 }
             }
+            TSTAMP(44);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (live && step * 64 + 16 * i + 8 * lh < GC) *(u32x4*)(yrow + step * 64 + 16 * i) = outv[i];
             cur = nxt;
+            TSTAMP(45);
         }
     }
     __syncthreads();
@@ -382,3 +389,5 @@ int dense_dgrad_forward(const saunet_conv_desc* d, const void* x, const void* w,
 }
 
 }  // namespace saunet
+
+SAUNET_TIMING_READER(dense_dgrad)
