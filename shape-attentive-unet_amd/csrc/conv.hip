@@ -415,6 +415,49 @@ template <typename T> __global__ __launch_bounds__(256) void channel_sum_kernel(
     for (int c = threadIdx.x; c < C; c += 256) atomicAdd(&out[c], s_red[c]);
 }
 
+// Vector form: 16-byte chunks per lane (whole 128-byte row segments per wave), float partials flushed to double every 64 rows, LDS reduce,
+// one double atomic per channel per block.  CV = channels of the reduction as the kernel sees them: C itself, or -- for dense tensors with
+// fewer channels than a chunk holds (the one-channel side outputs c3/c4/c5, phi) -- the V interleaved "virtual channels" of a flat view,
+// which the last step folds back modulo C.
+template <typename T, int V> __global__ __launch_bounds__(256) void channel_sum_vec_kernel(const T* __restrict__ x, long rows, int CV, int ld, int C,
+                                                                                          long rows_per_block, double* __restrict__ out)
+{
+    extern __shared__ double s_red[];
+    for (int i = threadIdx.x; i < CV; i += 256) s_red[i] = 0.0;
+    __syncthreads();
+    const long p0 = blockIdx.x * rows_per_block, p1 = min(p0 + rows_per_block, rows);
+    const int CH = CV / V;
+    for (int cb = 0; cb < CH; cb += 256) {
+        const int cw = min(256, CH - cb), rl = 256 / cw;
+        const int ch = cb + threadIdx.x % cw, r0 = threadIdx.x / cw;
+        if (r0 >= rl) continue;
+        float fs[V]; double ds[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { fs[j] = 0.f; ds[j] = 0.0; }
+        int cnt = 0;
+        for (long p = p0 + r0; p < p1; p += rl) {
+            float f[V];
+            Vec16<T>::unpack(*(const u32x4*)(x + p * ld + ch * V), f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) fs[j] += f[j];
+            if (++cnt == 64) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) { ds[j] += fs[j]; fs[j] = 0.f; }
+                cnt = 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) atomicAdd(&s_red[ch * V + j], ds[j] + (double)fs[j]);
+    }
+    __syncthreads();
+    if (CV == C) { for (int c = threadIdx.x; c < C; c += 256) atomicAdd(&out[c], s_red[c]); }
+    else if (threadIdx.x < C) {
+        double s = 0.0;
+        for (int j = threadIdx.x; j < CV; j += C) s += s_red[j];
+        atomicAdd(&out[threadIdx.x], s);
+    }
+}
+
 static bool is_pointwise(const saunet_conv_desc* d)
 {
     return d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->transposed && d->Ho == d->H && d->Wo == d->W;
@@ -641,6 +684,23 @@ int saunet_channel_sum(int dtype, const void* x, int64_t pixels, int C, int ld, 
     blocks = (pixels + rpb - 1) / rpb;
     const size_t lds = sizeof(double) * C;
     if (C > 4096) return set_error(SAUNET_UNSUPPORTED, "channel_sum: C=%d", C);
+    {
+        const int V = dtype == SAUNET_BF16 ? 8 : 4;
+        long rows = pixels; int cv = C, ldv = ld;
+        bool vec = ((uintptr_t)x & 15) == 0 && (dtype == SAUNET_BF16 || dtype == SAUNET_F32);
+        if (C % V == 0 && ld % V == 0) { /* whole chunks per pixel */ }
+        else if (C < V && V % C == 0 && ld == C && (pixels * C) % V == 0) { rows = pixels * C / V; cv = V; ldv = V; }      // dense few-channel tensor: flat view
+        else vec = false;
+        if (vec) {
+            long nb = (rows * (cv / V) + 2047) / 2048; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
+            long rp = (rows + nb - 1) / nb; nb = (rows + rp - 1) / rp;
+            const size_t l2 = sizeof(double) * cv;
+            if (dtype == SAUNET_F32) hipLaunchKernelGGL((channel_sum_vec_kernel<float, 4>), dim3((unsigned)nb), dim3(256), l2, st, (const float*)x, rows, cv, ldv, C, rp, out);
+            else hipLaunchKernelGGL((channel_sum_vec_kernel<u16, 8>), dim3((unsigned)nb), dim3(256), l2, st, (const u16*)x, rows, cv, ldv, C, rp, out);
+            SAUNET_CHECK_LAUNCH("channel_sum");
+            return SAUNET_OK;
+        }
+    }
     if (dtype == SAUNET_F32) hipLaunchKernelGGL(channel_sum_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, st, (const float*)x, (long)pixels, C, ld, rpb, out);
     else if (dtype == SAUNET_BF16) hipLaunchKernelGGL(channel_sum_kernel<u16>, dim3((unsigned)blocks), dim3(256), lds, st, (const u16*)x, (long)pixels, C, ld, rpb, out);
     else return set_error(SAUNET_BAD_DTYPE, "channel_sum: dtype %d", dtype);

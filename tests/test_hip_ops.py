@@ -349,3 +349,21 @@ def test_adaptive_avgmax_pool_kat(dtype, pool_type, shape):
     m = S.AdaptiveAvgMaxPool2d(1, pool_type)
     assert m.factor() == (2 if pool_type == "avgmaxc" else 1)
     assert torch.equal(m(xh.detach()), got.detach())
+
+
+@pytest.mark.parametrize("dtype,c,ctot,shape", [(torch.bfloat16, 1, 1, (4, 64, 64)), (torch.bfloat16, 2, 2, (3, 16, 48)), (torch.float32, 4, 4, (2, 64, 64)),
+                                                (torch.bfloat16, 64, 96, (2, 32, 32)), (torch.float32, 3, 3, (2, 16, 16)), (torch.bfloat16, 8, 8, (5, 16, 16)),
+                                                (torch.float32, 1, 1, (3, 16, 16))])
+def test_channel_sum_vector_and_scalar_paths(dtype, c, ctot, shape):
+    """bias-gradient reduction (sum over pixels per channel): 16-byte-chunk path, the flat view of dense few-channel tensors, and the scalar
+    fallback (odd channel counts) against a float64 sum"""
+    import saunet_amd as S
+    HF = S.functional
+    n, h, w = shape
+    torch.manual_seed(c * 7 + h)
+    full = torch.randn(n, ctot, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    t = full[:, :c]
+    got = HF.channel_sum(t)
+    want = t.double().sum((0, 2, 3))
+    assert got.shape == (c,)
+    assert float((got.double() - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max())) * (1 if dtype == torch.float32 else 10)
