@@ -41,7 +41,7 @@ rf = summary(O + "/rf_stats/p_results.db", 1).split("\n")
 rf = "\n".join(l[:230] for l in rf[1:10])
 open(os.path.join(ROOT, "profiles", "%s_roofline_kernel_rocprof.txt" % tag), "w").write(
     "# rocprofv3 --kernel-trace --stats -- python bench.py --roofline-only   (scripts/collect_profiles.sh)\n"
-    "# the probe launches the dominant kernel 35 times (5 warm-up + 30 timed with HIP events on the launch stream)\n" + rf +
+    "# the probe launches the dominant kernel 33 times (3 warm-up + 30 timed with HIP events on the launch stream)\n" + rf +
     "\n# bench.py line of the same run:\n" + json.dumps({"roofline": line}) + "\n")
 open(os.path.join(ROOT, "profiles", "%s_f_step_kernel_stats.txt" % tag), "w").write(
     "# rocprofv3 --kernel-trace --stats -- python bench.py --no-graph --steps 10 --warmup 3 --no-cpu-baseline --no-roofline\n"
