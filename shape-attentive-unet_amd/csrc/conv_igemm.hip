@@ -201,20 +201,31 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void conv_igemm_fwd_
     };
 
     Stage S0, S1;
+    TSTAMP_INIT();
+    TSTAMP(60);
     issue(S0);
     commit(S0, 0);
     __syncthreads();
     if (nk > 1) issue(S0);                       // step 1 in flight
+    TSTAMP(61);
     for (int ks = 0; ks < nk; ks += 2) {
         if (ks + 2 < nk) issue(S1);              // step ks+2
+        TSTAMP(62);
         compute(0);
+        TSTAMP(63);
         if (ks + 1 < nk) commit(S0, 1);
+        TSTAMP(64);
         __syncthreads();
+        TSTAMP(65);
         if (ks + 1 >= nk) break;
         if (ks + 3 < nk) issue(S0);              // step ks+3
+        TSTAMP(66);
         compute(1);
+        TSTAMP(67);
         if (ks + 2 < nk) commit(S1, 0);
+        TSTAMP(68);
         __syncthreads();
+        TSTAMP(69);
     }
 
     // ---- epilogue: statistics, bias, transpose through LDS, coalesced stores
@@ -314,6 +325,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void conv_igemm_fwd_
         }
         if (okv[i]) *(u32x4*)(yg + opixv[i] * a.ldy + colv) = v;
     }
+    TSTAMP(70);
     if (bnb) {   // NT % CH == 0: a thread always owns the same EPC channels -> one LDS atomic per channel per thread
         __syncthreads();
         for (int i = tid; i < 2 * BN; i += NT) s_sum[i] = 0.f;
@@ -644,3 +656,5 @@ int igemm_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const 
 }
 
 }  // namespace saunet
+
+SAUNET_TIMING_READER(conv_igemm)
