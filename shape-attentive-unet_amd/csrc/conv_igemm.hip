@@ -257,12 +257,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void conv_igemm_fwd_
             if (lh == 0) { atomicAdd(&s_sum[col], s); atomicAdd(&s_sq[col], ss); }
         }
     }
+    TSTAMP(71);
     __syncthreads();
+    TSTAMP(72);
     if (do_stats && tid < BN && n0 + tid < a.Cout) {
         const size_t ro = (size_t)(blockIdx.x % a.stat_replicas) * a.stat_rstride;
         atomicAdd(&a.stat_sum[ro + n0 + tid], (double)s_sum[tid]);
         atomicAdd(&a.stat_sumsq[ro + n0 + tid], (double)s_sq[tid]);
     }
+    TSTAMP(73);
     constexpr int CH = BN / EPC;  // 16-byte chunks per output row
     T* __restrict__ yg = (T*)a.y;
     constexpr bool bnb = BNEPI;

@@ -375,6 +375,10 @@ int dense_dgrad_forward(const saunet_conv_desc* d, const void* x, const void* w,
     // low-resolution blocks where the copy would dominate and more blocks are needed to fill the chip
     const long ntp = ((long)a.P + 31) / 32;
     a.group = ntp >= 4096 ? DG_GROUP : (ntp >= 1024 ? 128 : 64);
+    if (const char* e = getenv("SAUNET_DG_GROUP_SMALL")) {      // A/B switch for the small-map heuristic: "<group at ntp>=1024>,<group below>"
+        int g3 = 128, g4 = 64;
+        if (sscanf(e, "%d,%d", &g3, &g4) == 2 && ntp < 4096) a.group = ntp >= 1024 ? g3 : g4;
+    }
     const int groups = (a.Cin + a.group - 1) / a.group;
     const int gcp = ((a.Cin < a.group ? a.Cin : a.group) + 31) & ~31;
     const size_t lds = (size_t)gcp * DG_WPITCH * 2 + sizeof(float) * 6 * gcp;

@@ -75,6 +75,29 @@ def collate(batch):
             "mask": (torch.stack([b["mask"][0] for b in batch]), torch.stack([b["mask"][1] for b in batch]))}
 
 
+class RawSyntheticSlices(torch.utils.data.Dataset):
+    """Un-augmented phantom slices of RAGGED sizes with raw (scanner-like, non-negative) intensities: what AC17Data holds after the 1.25 mm
+    re-scaling and before its per-slice augmentation chain (data/ac17_dataloader.py:133-150) -- the input of augment.DeviceAugmenter."""
+
+    def __init__(self, n, size=256, seed=304):
+        self.n, self.size, self.seed = n, size, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        r = np.random.default_rng(self.seed + 7919 * i)
+        h, w = int(self.size * r.uniform(0.8, 1.25)), int(self.size * r.uniform(0.8, 1.25))
+        img, seg, _ = sdata.synthetic_batch(1, h, w, seed=self.seed + i)
+        raw = img[0, 0].numpy()
+        raw = (raw - raw.min()) * 300.0
+        return {"raw": raw.astype(np.float32), "seg": seg[0].numpy().astype(np.float32)}
+
+
+def collate_raw(batch):
+    return {"raw": [b["raw"] for b in batch], "seg": [b["seg"] for b in batch]}
+
+
 # ------------------------------------------------------------------------------------------------ loops
 def poly_resume_lr(lr0, epoch, num_epoch, lr_pow=0.9):
     return lr0 * ((1.0 - float(epoch - 1) / num_epoch) ** lr_pow)   # train.py:84-88
@@ -91,8 +114,11 @@ def train_one_epoch(sm, loader, optimizers, epoch, args, history, buckets=None, 
     pending = []
     for it, batch in enumerate(loader):
         meters["data_time"].update(time.time() - tic)
-        feed = {"image": batch["image"].to(device, non_blocking=True),
-                "mask": (batch["mask"][0].to(device, non_blocking=True), batch["mask"][1].to(device, non_blocking=True))}
+        if "raw" in batch:      # --augment: crop/pad, flips, rotation, gamma, z-score, elastic deformation and edge maps on the device
+            feed = args.augmenter(batch["raw"], batch["seg"])
+        else:
+            feed = {"image": batch["image"].to(device, non_blocking=True),
+                    "mask": (batch["mask"][0].to(device, non_blocking=True), batch["mask"][1].to(device, non_blocking=True))}
         sm.zero_grad(set_to_none=True)
         loss, (acc, jac) = sm(feed, epoch)
         loss = loss.mean()
@@ -185,6 +211,8 @@ def build_parser():
     p.add_argument("--synthetic", type=int, default=64, help="number of synthetic training slices (no ACDC data mounted)")
     p.add_argument("--size", type=int, default=256)
     p.add_argument("--val_slices", type=int, default=8)
+    p.add_argument("--augment", action="store_true", help="train on raw ragged slices augmented on the GPU (augment.DeviceAugmenter: the loader's "
+                   "crop/flip/rotate/gamma/z-score/elastic chain, train.py:236 + data/ac17_dataloader.py)")
     return p
 
 
@@ -202,7 +230,10 @@ def main(argv=None):
     sm = SegmentationModule(DualLoss(mode="train"), unet, args.num_class)
     optimizers = optim.create_optimizers(unet, args.optimizer, args.lr_encoder, args.beta1, args.weight_decay)
     buckets = dp.GradientBuckets(list(unet.parameters())) if world > 1 else None
-    train_set = SyntheticSlices(args.synthetic, args.size, args.seed)
+    train_set = RawSyntheticSlices(args.synthetic, args.size, args.seed) if args.augment else SyntheticSlices(args.synthetic, args.size, args.seed)
+    if args.augment:
+        from .augment import DeviceAugmenter
+        args.augmenter = DeviceAugmenter(size=args.size, seed=args.seed + 1000 * rank)
     val_set = SyntheticSlices(args.val_slices, args.size, args.seed + 100000)
     args.running_lr_encoder = args.lr_encoder
     history = {"train": {"epoch": [], "loss": [], "acc": [], "jaccard": []}}
@@ -210,8 +241,8 @@ def main(argv=None):
     for epoch in range(args.start_epoch, args.num_epoch + 1):
         idx = dp.shard_indices(len(train_set), rank, world, epoch=epoch, seed=args.seed)
         loader = torch.utils.data.DataLoader(torch.utils.data.Subset(train_set, idx), batch_size=args.batch_size_per_gpu,
-                                             shuffle=False, collate_fn=collate, num_workers=args.workers, drop_last=True,
-                                             pin_memory=True)
+                                             shuffle=False, collate_fn=collate_raw if args.augment else collate, num_workers=args.workers,
+                                             drop_last=True, pin_memory=not args.augment)
         train_one_epoch(sm, loader, optimizers, epoch, args, history, buckets, device)
         if rank == 0:
             iou, dice, vloss = evaluate(sm, val_set, args, device)

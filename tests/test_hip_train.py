@@ -158,3 +158,13 @@ def test_fused_sgd_state_dict_roundtrip_keeps_momentum():
     for g in gs[2:]:
         p.grad = g.clone(); q.grad = g.clone(); b.step(); ref.step()
     assert float((p.detach() - q.detach()).abs().max()) < 1e-5
+
+
+def test_training_with_device_augmentation(tmp_path):
+    """--augment: raw ragged slices -> DeviceAugmenter (crop/pad, flips, rotation, gamma, z-score, elastic deformation, edges on the GPU) -> step."""
+    from saunet_amd import train
+    args = ["--num_epoch", "2", "--batch_size_per_gpu", "4", "--synthetic", "8", "--size", "64", "--val_slices", "2", "--dtype", "f32",
+            "--workers", "0", "--ckpt", str(tmp_path), "--disp_iter", "1", "--lr_encoder", "0.002", "--augment"]
+    hist = train.main(args)
+    assert len(hist["train"]["loss"]) == 2 and all(np.isfinite(hist["train"]["loss"]))
+    assert 0.0 <= hist["train"]["acc"][-1] <= 1.0
