@@ -796,6 +796,19 @@ __global__ __launch_bounds__(256, 2) void conv_tile_wgrad_kernel(TileWgradArgs a
 
     const int li = lane & 15, lg = lane >> 4, nhalf = lg & 1, khalf = lg >> 1;
 
+    // 256 threads stage chunk q = tid + i*256 and 256 % CHX == 0: a thread handles the SAME channel chunk of every halo pixel, so its
+    // prologue coefficients are loaded once per block, not once per chunk per tile
+    static_assert(!ALIGNED || 256 % CHX == 0, "a thread keeps one channel chunk");
+    float pro_s[EPC], pro_t[EPC];
+    if constexpr (ALIGNED) {
+        const int c = ci0 + (tid % CHX) * EPC;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+            const bool ok = has_pro && c + j < a.Cin;
+            pro_s[j] = ok ? a.pro_scale[c + j] : 1.f; pro_t[j] = ok ? a.pro_shift[c + j] : 0.f;
+        }
+    }
+
     TSTAMP_INIT();
     TSTAMP(20);
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
@@ -846,11 +859,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_wgrad_kernel(TileWgradArgs a
                     Vec16<T>::unpack(xreg[i], f);
                     if constexpr (ALIGNED) {
 #pragma unroll
-                        for (int j = 0; j < EPC; j += 4) {
-                            f32x4 s4 = *(const f32x4*)(a.pro_scale + cx[i] + j), t4 = *(const f32x4*)(a.pro_shift + cx[i] + j);
-#pragma unroll
-                            for (int qq = 0; qq < 4; ++qq) f[j + qq] = fmaxf(fmaf(f[j + qq], s4[qq], t4[qq]), relu_lo);
-                        }
+                        for (int j = 0; j < EPC; ++j) f[j] = fmaxf(fmaf(f[j], pro_s[j], pro_t[j]), relu_lo);
                     } else {
 #pragma unroll
                         for (int j = 0; j < EPC; ++j) {
