@@ -484,8 +484,42 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
     TSTAMP(0);
     constexpr bool TWO = BN < 128;      // the 128-wide tile has no registers to spare for a second stage
     constexpr int AHEAD = TWO ? 2 : 1;
-    issue_halo(hregA, hokA);
-    if (TWO && nunits > 1) issue_halo(hregB, hokB);
+    // The block's first n-tile of weights goes to LDS here, before anything else is live in registers: 9 pieces per thread in flight, so the
+    // copy costs about one memory latency per batch (piece by piece inside the unit loop it was one latency PER PIECE: 19k cycles for the 73 KB
+    // of a 128 -> 32 layer, all of it exposed on the small maps -- s_memtime stamps).  The first halo prefetches are issued behind the last
+    // batch's loads and land while the weights are stored.
+    {
+        constexpr int WB = 9;
+        const int n0 = (it0 / ntile) * BN;
+        const int pieces = ncb * 9 * BN * CPR;
+        const int nb = (pieces + NT * WB - 1) / (NT * WB);
+        for (int b = 0; b < nb; ++b) {
+            u32x4 v[WB];
+#pragma unroll
+            for (int u = 0; u < WB; ++u) {
+                const int q = tid + (b * WB + u) * NT;
+                const int ch = q % CPR; int t = q / CPR;
+                const int brow = t % BN; t /= BN;
+                const int tap = t % 9, cb = t / 9;
+                const int c = cb * KC + ch * EPC;
+                v[u] = u32x4{0u, 0u, 0u, 0u};
+                if (q < pieces && n0 + brow < a.Cout && c < a.Cin) v[u] = *(const u32x4*)(wg + ((size_t)(n0 + brow) * 9 + tap) * a.Cin + c);
+            }
+            if (b == nb - 1) {
+                issue_halo(hregA, hokA);
+                if (TWO && nunits > 1) issue_halo(hregB, hokB);
+            }
+#pragma unroll
+            for (int u = 0; u < WB; ++u) {
+                const int q = tid + (b * WB + u) * NT;
+                const int ch = q % CPR; int t = q / CPR;
+                const int brow = t % BN; t /= BN;
+                const int tap = t % 9, cb = t / 9;
+                if (q < pieces) *(u32x4*)(s_w + (cb * 9 + tap) * WTAP + brow * PITCH + ch * 16) = v[u];
+            }
+        }
+        cur_nt = it0 / ntile;
+    }
 
     // Compute cursor (the unit whose MFMAs run): advanced incrementally like the prefetch cursor.
     int c_cb = 0, c_nt = it0 / ntile, c_txi, c_tyi, c_n;
