@@ -1,5 +1,5 @@
 """Per-phase cycle stamps of one kernel launch (profiling build: python -m saunet_amd._build --timing; run with
-SAUNET_HIP_LIB=scripts/_ab/libsaunet_timing.so).  usage: phase_timing.py <case> ; cases: conv2fwd conv2wgrad conv1wgrad conv1dgrad conv1fwd dec3wgrad"""
+SAUNET_HIP_LIB=scripts/_ab/libsaunet_timing.so).  usage: phase_timing.py <case> ; cases: conv2fwd conv2wgrad conv1wgrad conv1dgrad conv1fwd dec3wgrad dec3fwd dec5fwd"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,6 +20,11 @@ elif case in ("conv2wgrad", "conv1wgrad", "dec3wgrad"):
     x = act(cin, h); dy = act(cout, h); w = torch.nn.Parameter(torch.randn(cout, cin, k, k, device="cuda") * 0.03)
     sc = torch.rand(cin, device="cuda") + 0.5; sh = torch.randn(cin, device="cuda") * 0.1
     run = lambda: (HF.GRADS.reset(), HF.conv_wgrad_raw(x, dy, w, 1, k // 2, pro=(sc, sh, True) if case != "dec3wgrad" else None))
+elif case in ("dec3fwd", "dec5fwd"):
+    cin, h, cout = {"dec3fwd": (512, 64, 128), "dec5fwd": (1536, 16, 512)}[case]
+    x = act(cin, h); w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device="cuda") * 0.02)
+    out = HF.new_act(n, cout, h, h, dt, "cuda"); st = torch.zeros(HF.STAT_R, 2, cout, dtype=torch.float64, device="cuda")
+    run = lambda: HF.conv_forward_raw(x, w, None, 1, 1, out=out, stats=st)
 elif case == "conv1fwd":
     unit = "conv_igemm"
     x = act(192, 128); w = torch.nn.Parameter(torch.randn(128, 192, 1, 1, device="cuda") * 0.03)

@@ -545,7 +545,8 @@ int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const voi
     if (igemm_supported(d)) {
         if (epi && (((uintptr_t)epi->bn_x & 15) || epi->ld_bn_x % (d->dtype == SAUNET_BF16 ? 8 : 4)))
             return set_error(SAUNET_BAD_ALIGN, "conv: bn epilogue tensor must be 16-byte aligned");
-        if (tile_fwd_supported(d)) {
+        static const long tile_minpix = getenv("SAUNET_TILE_MINPIX") ? atol(getenv("SAUNET_TILE_MINPIX")) : 0;     // A/B switch for profiling
+        if (tile_fwd_supported(d) && (long)d->N * d->H * d->W >= tile_minpix) {
             if (epi && epi->accumulate) return set_error(SAUNET_UNSUPPORTED, "conv: accumulating BN epilogue is implemented for 1x1 dgrads");
             return tile_forward(d, x, w, bias, ps, psh, y, ssum, ssq, epi, st);
         }

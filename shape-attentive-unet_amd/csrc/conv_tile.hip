@@ -118,12 +118,15 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64, BNEPI ? 1 : 2) void co
     };
 
     int wbuf = 0;
+    TSTAMP_INIT();
+    TSTAMP(10);
     load_w(0, 0);
     for (int cb = 0; cb < ncb; ++cb) {
+        TSTAMP(11);
         // ---- stage the (transformed) halo of this channel block; previous readers are done (barrier at loop end).
         // Batches of HB pieces per thread in a NON-unrolled loop: keeps the index math out of long-lived registers.
         {
-            constexpr int HB = 4, NB = (H_ITERS + HB - 1) / HB;
+            constexpr int HB = 6, NB = (H_ITERS + HB - 1) / HB;
             const int c0 = cb * KC;
 #pragma unroll 1
             for (int b = 0; b < NB; ++b) {
@@ -161,8 +164,10 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64, BNEPI ? 1 : 2) void co
                     if (hl[i] >= 0) *(u32x4*)(s_halo + hl[i]) = hk[i] ? hreg[i] : z;
             }
         }
+        TSTAMP(12);
         store_w(wbuf);
         __syncthreads();
+        TSTAMP(13);
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             // prefetch the next weight tile (next tap, or tap 0 of the next channel block)
@@ -185,12 +190,15 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64, BNEPI ? 1 : 2) void co
 #pragma unroll
                     for (int j = 0; j < TJ; ++j) MmaT<T>::run(af[i], bfr[j], acc[i][j]);
             }
+            TSTAMP(14);
             if (more && tap + 1 < 9) store_w(wbuf ^ 1);   // the next cb's tap-0 tile is stored after its halo
             __syncthreads();
+            TSTAMP(15);
             if (tap + 1 < 9) wbuf ^= 1;
         }
         wbuf ^= 1;
     }
+    TSTAMP(16);
 
     // ---- epilogue (same scheme as the generic kernel)
     float* s_sum = (float*)(smem + 256 * BN * sizeof(T));
