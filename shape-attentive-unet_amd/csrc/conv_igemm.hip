@@ -13,6 +13,7 @@
 // Replaces F.conv2d / F.conv_transpose2d and their autograd backward in the reference
 // (/root/reference/models/models.py:118-123,203-237; attention_blocks.py:179-220; torchvision DenseNet).
 #include "common.h"
+#include <stdlib.h>
 
 namespace saunet {
 
@@ -376,7 +377,7 @@ template <typename T> static int dispatch_fwd(const IgemmArgs& a, int phases, hi
 {
     constexpr int EPC = 16 / sizeof(T);
     // narrow K rows (<= 4 chunks of channels) use the 64-byte-row variant: half the zero padding
-    const bool narrow = a.Cin <= 4 * EPC;
+    const bool narrow = a.kpt == cdiv(a.Cin, 4 * EPC);       // the caller sized the K steps for 64-byte rows
     if (a.Cout <= 32) {
         return narrow ? launch_fwd<T, 256, 32, 64, 32, 4>(a, phases, st) : launch_fwd<T, 256, 32, 64, 32, 8>(a, phases, st);
     } else if (a.Cout <= 64) {
@@ -419,6 +420,10 @@ int igemm_forward(const saunet_conv_desc* d, const void* x, const void* w, const
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return set_error(SAUNET_BAD_ALIGN, "conv: pointers must be 16-byte aligned");
     if (d->dtype == SAUNET_BF16) {
         a.kpt = cdiv(d->Cin, (d->Cin <= 32) ? 32 : 64);
+        // pointwise convs on large maps are memory bound with a short K loop: 32-channel K steps halve the LDS footprint, so twice as many
+        // workgroups are resident per CU to overlap each other's load / epilogue latencies (33.78 -> 33.69 ms/step; env switch for A/B runs)
+        static const long narrow_minpix = getenv("SAUNET_IGEMM_NARROW_MINPIX") ? atol(getenv("SAUNET_IGEMM_NARROW_MINPIX")) : 100000;
+        if (narrow_minpix >= 0 && d->KH == 1 && d->KW == 1 && !d->transposed && a.M >= narrow_minpix && d->Cin > 64) a.kpt = cdiv(d->Cin, 32);
         return dispatch_fwd<u16>(a, phases, st);
     } else if (d->dtype == SAUNET_F32) {
         a.kpt = cdiv(d->Cin, (d->Cin <= 16) ? 16 : 32);
