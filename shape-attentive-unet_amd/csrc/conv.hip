@@ -61,27 +61,29 @@ __global__ void pack_weight_kernel(int mode, const float* __restrict__ w, int Co
 // all packings of one training step in a few launches: blockIdx.y = entry
 template <typename T> __global__ void pack_weight_multi_kernel(saunet_pack_list pl)
 {
+    // 32-bit index arithmetic throughout (an entry has < 2^31 elements; checked on the host): the 64-bit div / mod of the element decode
+    // cost more than the gather itself
     const int e = blockIdx.y;
-    const int mode = pl.mode[e], Co = pl.dims[e][0], Ci = pl.dims[e][1], KH = pl.dims[e][2], KW = pl.dims[e][3];
+    const unsigned mode = pl.mode[e], Co = pl.dims[e][0], Ci = pl.dims[e][1], KH = pl.dims[e][2], KW = pl.dims[e][3];
     const float* __restrict__ w = (const float*)pl.src[e];
     T* __restrict__ out = (T*)pl.dst[e];
-    const long total = (long)Co * Ci * KH * KW;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const unsigned total = Co * Ci * KH * KW;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         float v;
         if (mode == SAUNET_PACK_FWD) {
-            int ci = i % Ci; long t = i / Ci; int kw = t % KW; t /= KW; int kh = t % KH; int co = t / KH;
-            v = w[(((long)co * Ci + ci) * KH + kh) * KW + kw];
+            unsigned ci = i % Ci, t = i / Ci; unsigned kw = t % KW; t /= KW; unsigned kh = t % KH, co = t / KH;
+            v = w[((co * Ci + ci) * KH + kh) * KW + kw];
         } else if (mode == SAUNET_PACK_DGRAD) {
-            int co = i % Co; long t = i / Co; int kw = t % KW; t /= KW; int kh = t % KH; int ci = t / KH;
-            v = w[(((long)co * Ci + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
+            unsigned co = i % Co, t = i / Co; unsigned kw = t % KW; t /= KW; unsigned kh = t % KH, ci = t / KH;
+            v = w[((co * Ci + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
         } else if (mode == SAUNET_PACK_CONVT_FWD) {
-            int ci = i % Ci; long t = i / Ci; int tw = t % 2; t /= 2; int th = t % 2; t /= 2; int co = t % Co; t /= Co;
-            int pw = t % 2, ph = t / 2;
-            int kh = (1 - ph) + 2 * th, kw = (1 - pw) + 2 * tw;
-            v = w[(((long)ci * Co + co) * 4 + kh) * 4 + kw];
+            unsigned ci = i % Ci, t = i / Ci; unsigned tw = t % 2; t /= 2; unsigned th = t % 2; t /= 2; unsigned co = t % Co; t /= Co;
+            unsigned pw = t % 2, ph = t / 2;
+            unsigned kh = (1 - ph) + 2 * th, kw = (1 - pw) + 2 * tw;
+            v = w[((ci * Co + co) * 4 + kh) * 4 + kw];
         } else {
-            int co = i % Co; long t = i / Co; int kw = t % 4; t /= 4; int kh = t % 4; int ci = t / 4;
-            v = w[(((long)ci * Co + co) * 4 + kh) * 4 + kw];
+            unsigned co = i % Co, t = i / Co; unsigned kw = t % 4; t /= 4; unsigned kh = t % 4, ci = t / 4;
+            v = w[((ci * Co + co) * 4 + kh) * 4 + kw];
         }
         Elem<T>::store(out + i, v);
     }
@@ -511,6 +513,7 @@ int saunet_pack_weight_multi(const saunet_pack_list* pl, int dtype, void* stream
     long biggest = 1;
     for (int e = 0; e < pl->count; ++e) {
         const long t = (long)pl->dims[e][0] * pl->dims[e][1] * pl->dims[e][2] * pl->dims[e][3];
+        if (t >= (1L << 31)) return set_error(SAUNET_BAD_SHAPE, "pack_multi: entry %d has %ld elements", e, t);
         if (t > biggest) biggest = t;
     }
     long bx = (biggest + 1023) / 1024; if (bx > 2048) bx = 2048;     // ~4 elements per thread for the largest entry; small entries' extra blocks exit at once
