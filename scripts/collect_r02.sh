@@ -10,7 +10,7 @@ python bench.py --steps 10 --warmup 3 --size 512 --batch 8 --dtype f32 --no-cpu-
 python bench.py --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-roofline > $O/bench_eager.json 2>> $O/bench.err
 python scripts/fwd_micro.py > $O/micro_fwd.txt 2>&1
 python scripts/wgrad_micro.py > $O/micro_wgrad.txt 2>&1
-( export SAUNET_HIP_LIB=scripts/_ab/libsaunet_timing.so; for c in conv2fwd conv2wgrad conv1wgrad dec3wgrad conv1dgrad; do python scripts/phase_timing.py $c 2>&1 | grep -v amdgpu.ids; done ) > $O/phase_timing.txt
+( export SAUNET_HIP_LIB=scripts/_ab/libsaunet_timing.so; for c in conv2fwd conv2wgrad conv1wgrad dec3wgrad conv1dgrad dec3fwd conv1fwd dense3fwd; do python scripts/phase_timing.py $c 2>&1 | grep -v amdgpu.ids; done ) > $O/phase_timing.txt
 bash scripts/collect_profiles.sh > $O/collect_profiles.log 2>&1
 python scripts/make_profiles.py r02 > $O/make_profiles.log 2>&1
 python scripts/prof_by_geometry.py gpurun_out/round_prof/step/p_results.db 15 25 > $O/step_by_geometry.txt

@@ -25,6 +25,15 @@ elif case in ("dec3fwd", "dec5fwd"):
     x = act(cin, h); w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device="cuda") * 0.02)
     out = HF.new_act(n, cout, h, h, dt, "cuda"); st = torch.zeros(HF.STAT_R, 2, cout, dtype=torch.float64, device="cuda")
     run = lambda: HF.conv_forward_raw(x, w, None, 1, 1, out=out, stats=st)
+elif case in ("dense3fwd", "dense4fwd"):
+    unit = "dense_fwd"
+    layers, cin, h = {"dense3fwd": (24, 256, 32), "dense4fwd": (16, 512, 16)}[case]
+    S.set_compute_dtype(dt)
+    block = S.modules._DenseBlock(layers, cin).cuda().train()
+    x = act(cin, h)
+    def run():
+        with torch.no_grad():
+            block(x)
 elif case == "conv1fwd":
     unit = "conv_igemm"
     x = act(192, 128); w = torch.nn.Parameter(torch.randn(128, 192, 1, 1, device="cuda") * 0.03)
@@ -43,7 +52,7 @@ for _ in range(3):
     run()
 torch.cuda.synchronize()
 lib = S.lib.load()
-N = 400
+N = 2000
 buf_ = (ctypes.c_ulonglong * N)()
 getattr(lib, "saunet_debug_timing_" + unit)(buf_, N)
 vals = [(v >> 56, v & 0x00ffffffffffffff) for v in buf_ if v]

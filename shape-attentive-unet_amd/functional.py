@@ -1306,6 +1306,68 @@ def relu(x):
 
 
 # ------------------------------------------------------------------------------------------------ DenseNet
+# Opt-in (SAUNET_DENSE_PERSIST=1): measured at the bench geometry (hipGraph, scripts/dense_fwd_micro.py) the persistent block forward runs
+# 49.3 us / layer on block 3 against 53.5 for the per-layer launches and 47.5 against 42.9 on block 4 -- a wash, see DESIGN.md section 9 --
+# so the default stays with the launches that need no co-residency assumption.
+DENSE_PERSIST = os.environ.get("SAUNET_DENSE_PERSIST", "0") == "1"
+DENSE_PERSIST_MAXPIX = int(os.environ.get("SAUNET_DENSE_PERSIST_MAXPIX", "65536"))
+
+
+def _dense_persistent_ok(x0, c0, growth, nl, params):
+    """The whole-block persistent forward (csrc/dense_fwd.hip) serves the low-resolution training blocks in bf16 storage.  It is a kernel
+    with device-wide barriers: it is not used when several processes may share the device (torch.distributed initialised with more than
+    one rank -- the data-parallel test rig runs two ranks on one GPU), where two such launches could starve each other."""
+    if not (DENSE_PERSIST and x0.is_cuda and x0.dtype == torch.bfloat16):
+        return False
+    n, _, h, w = x0.shape
+    if h % 8 or w % 16 or c0 % 32 or growth != 32 or nl > L.DENSE_MAX_LAYERS or c0 + growth * nl > 1024 or n * h * w > DENSE_PERSIST_MAXPIX:
+        return False
+    if any(tuple(params[6 * l + 2].shape[2:]) != (1, 1) or params[6 * l + 2].shape[0] != 128 or tuple(params[6 * l + 5].shape[1:]) != (128, 3, 3)
+           for l in range(nl)):
+        return False
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        return False
+    return True
+
+
+def _dense_block_forward_persistent(buf, stats, c0, nl, params, bufs, cfgs):
+    """One launch for all layers of the block; returns what the per-layer loop saves for backward: [z1, BNParams(norm1), BNParams(norm2)] * nl."""
+    n, ctot, h, w = buf.shape
+    dev = buf.device
+    d = L.DenseFwdDesc()
+    d.dtype, d.N, d.H, d.W, d.c0, d.nl, d.ldbuf = L.dtype_code(buf), n, h, w, c0, nl, ld_of(buf)
+    d.stat_reps, d.stat_rstride = stats.shape[0], stats.stride(0)
+    d.buf, d.stats = buf.data_ptr(), stats.data_ptr()
+    PACKS.generation += 1                       # running statistics change through raw pointers (as in bn_finalize)
+    saved, keep = [], []
+    for l in range(nl):
+        n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
+        n1rm, n1rv, n2rm, n2rv = bufs[4 * l:4 * l + 4]
+        mom, eps = cfgs[l]
+        cin = c0 + 32 * l
+        w1p, w2p = PACKS.get(c1w, L.PACK_FWD, buf.dtype), PACKS.get(c2w, L.PACK_FWD, buf.dtype)
+        z1 = new_act(n, 128, h, w, buf.dtype, dev)
+        p1, p2 = BNParams(cin, dev), BNParams(128, dev)
+        st2 = new_stats(128, dev)
+        e = d.layer[l]
+        e.w1, e.w2 = w1p.data_ptr(), w2p.data_ptr()
+        e.gamma1, e.beta1, e.rmean1, e.rvar1 = n1w.data_ptr(), n1b.data_ptr(), n1rm.data_ptr(), n1rv.data_ptr()
+        e.gamma2, e.beta2, e.rmean2, e.rvar2 = n2w.data_ptr(), n2b.data_ptr(), n2rm.data_ptr(), n2rv.data_ptr()
+        e.z1, e.p1, e.p2, e.st2 = z1.data_ptr(), p1.buf.data_ptr(), p2.buf.data_ptr(), st2.data_ptr()
+        e.st2_reps, e.st2_rstride = st2.shape[0], st2.stride(0)
+        e.eps, e.momentum = float(eps), float(mom)
+        saved += [z1, p1.buf, p2.buf]
+        keep += [w1p, w2p, st2]
+    sync = torch.empty(2048, dtype=torch.int32, device=dev)
+    L.call("saunet_dense_block_forward", C.byref(d), sync.data_ptr(), L.stream())
+    global LAST_DENSE_SYNC
+    LAST_DENSE_SYNC = sync          # word 1: abort flag (tests assert it stayed 0); word 32 * 17: root counter of the barrier
+    return saved
+
+
+LAST_DENSE_SYNC = None
+
+
 class _DenseBlock(torch.autograd.Function):
     """One DenseNet block: L x [BN-ReLU-conv1x1(->128)-BN-ReLU-conv3x3(->32)] over a growing concat.
 
@@ -1332,7 +1394,12 @@ class _DenseBlock(torch.autograd.Function):
         if training:
             bn_stats(buf[:, :c0], stats[:, :, :c0])
         saved = []
-        for l in range(nl):
+        if training and _dense_persistent_ok(x0, c0, growth, nl, params):
+            saved = _dense_block_forward_persistent(buf, stats, c0, nl, params, bufs, cfgs)
+            nl_loop = 0
+        else:
+            nl_loop = nl
+        for l in range(nl_loop):
             n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
             n1rm, n1rv, n2rm, n2rv = bufs[4 * l:4 * l + 4]
             mom, eps = cfgs[l]
