@@ -1,4 +1,4 @@
-"""Run ONE conv geometry a few times (for rocprofv3 PMC passes): python scripts/one_kernel.py conv2|conv1|res1|dgrad1 [reps]"""
+"""Run ONE conv geometry a few times (for rocprofv3 PMC passes): python scripts/one_kernel.py conv2|conv1|res1|dec2..dec5|center|mrfup5|mrfup3 [reps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,7 +15,27 @@ elif which == "res1":
     cin, h, cout, k, pro = 64, 256, 64, 3, False
 elif which == "dec3":
     cin, h, cout, k, pro = 512, 64, 128, 3, False
+elif which == "dec2":
+    cin, h, cout, k, pro = 256, 128, 64, 3, False
+elif which == "dec4":
+    cin, h, cout, k, pro = 1024, 32, 256, 3, False
+elif which == "dec5":
+    cin, h, cout, k, pro = 1536, 16, 512, 3, False
+elif which == "center":                       # conv3x3_bn_relu(1024, 512) on the 8x8 map (im2col + pointwise path)
+    cin, h, cout, k, pro = 1024, 8, 512, 3, False
+elif which == "mrfup5":                       # dec5.mrf.up: ConvTranspose2d(512, 512, 4, 2, 1) 8x8 -> 16x16
+    cin, h, cout, k, pro = 512, 8, 512, 4, False
+elif which == "mrfup3":                       # dec3.mrf.up: ConvTranspose2d(128, 128, 4, 2, 1) 32x32 -> 64x64
+    cin, h, cout, k, pro = 128, 32, 128, 4, False
 x = torch.randn(n, cin, h, h, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+if k == 4:                                    # transposed convolution: weight [Cin, Cout, 4, 4], output 2h x 2h
+    w = torch.nn.Parameter(torch.randn(cin, cout, 4, 4, device="cuda") * 0.03)
+    out = HF.new_act(n, cout, 2 * h, 2 * h, dt, "cuda")
+    st = torch.zeros(HF.STAT_R, 2, cout, dtype=torch.float64, device="cuda")
+    for _ in range(reps):
+        HF.conv_forward_raw(x, w, None, 2, 1, transposed=True, out=out, stats=st)
+    torch.cuda.synchronize()
+    sys.exit(0)
 w = torch.nn.Parameter(torch.randn(cout, cin, k, k, device="cuda") * 0.03)
 sc = torch.rand(cin, device="cuda") + 0.5; sh = torch.randn(cin, device="cuda") * 0.1
 out = HF.new_act(n, cout, h, h, dt, "cuda")

@@ -49,6 +49,19 @@ template <int CPR> __device__ __forceinline__ int swz_off(int r, int c)
 
 constexpr int TILE = 16, HPITCH = 18, NPIX = HPITCH * HPITCH;
 
+// Halo tile of the tile kernel: [18 x 18 pixels][CPR chunks of 16 B], chunk index XOR-swizzled.  gfx950 serves a ds_read_b128 in four
+// groups of 16 lanes -- {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32 -- over 64 four-byte banks, i.e. the 16 lanes of a group must
+// hit 16 different 16-byte bank groups.  An A-fragment group takes pixels x..x+3, x+12..x+15 of one halo row and x+4..x+11 of the NEXT row:
+// with 128-byte pixels (CPR = 8) the bank group is 8*(x & 1) + swizzled chunk, so the swizzle key must be distinct over 8 consecutive
+// same-parity columns REGARDLESS of the row: key = (x >> 1) & 7.  (Keyed by the linear pixel index, as the weight tiles still are, the row
+// pitch of 18 shifted the second row's keys onto the first row's: 2 of 8 bank groups collided, SQ_LDS_BANK_CONFLICT = 25-31 % of the LDS
+// cycles of the decoder convolutions.)
+template <int CPR> __device__ __forceinline__ int swz_halo(int hy, int hx, int c)
+{
+    if constexpr (CPR == 8) return (((hy * HPITCH + hx) << 3) + (c ^ ((hx >> 1) & 7))) * 16;
+    else return swz_off<CPR>(hy * HPITCH + hx, c);
+}
+
 template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI>
 __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64, BNEPI ? 1 : 2) void conv3x3_tile_fwd_kernel(TileArgs a)
 {
@@ -79,11 +92,11 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64, BNEPI ? 1 : 2) void co
     const int ncb = (a.Cin + KC - 1) / KC;
 
     // A-fragment rows of this lane
-    int pbase[TI];
+    int prow[TI], pcol[TI];
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         int row = wm0 + i * 32 + lr;
-        pbase[i] = (row >> 4) * HPITCH + (row & 15);
+        prow[i] = row >> 4; pcol[i] = row & 15;
     }
 
     f32x16 acc[TI][TJ];
@@ -141,7 +154,7 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64, BNEPI ? 1 : 2) void co
                     const bool inr = q < NPIX * CPR;
                     const bool ok = inr && c < a.Cin && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                     hk[i] = ok; hc[i] = ok ? c : 0;
-                    hl[i] = inr ? swz_off<CPR>(pix, ch) : -1;
+                    hl[i] = inr ? swz_halo<CPR>(hy, hx, ch) : -1;
                     hreg[i] = *(const u32x4*)(xg + (ok ? (size_t)(iy * a.W + ix) * a.ldx + c : (size_t)0));
                 }
                 if (has_pro) {
@@ -175,14 +188,14 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64, BNEPI ? 1 : 2) void co
             if (more) load_w(tap + 1 < 9 ? cb : cb + 1, tap + 1 < 9 ? tap + 1 : 0);
             const int kh = tap / 3, kw = tap - kh * 3;
             const unsigned char* sb = s_w + wbuf * WB_BYTES;
-            int apix[TI];
+            int ay[TI], ax[TI];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) apix[i] = pbase[i] + kh * HPITCH + kw;
+            for (int i = 0; i < TI; ++i) { ay[i] = prow[i] + kh; ax[i] = pcol[i] + kw; }
 #pragma unroll
             for (int s = 0; s < CPR / 2; ++s) {
                 u32x4 af[TI], bfr[TJ];
 #pragma unroll
-                for (int i = 0; i < TI; ++i) af[i] = *(const u32x4*)(s_halo + swz_off<CPR>(apix[i], 2 * s + lh));
+                for (int i = 0; i < TI; ++i) af[i] = *(const u32x4*)(s_halo + swz_halo<CPR>(ay[i], ax[i], 2 * s + lh));
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) bfr[j] = *(const u32x4*)(sb + swz_off<CPR>(wn0 + j * 32 + lr, 2 * s + lh));
 #pragma unroll
@@ -340,6 +353,8 @@ template <typename T> static int dispatch_tile_fwd(const TileArgs& a, hipStream_
 // transformed and written to LDS.  LDS rows are padded (pitch = row bytes + 16) instead of XOR-swizzled, so every
 // fragment address is  lane_base + compile-time immediate  (no address VALU in the 9-tap x 4-substep MFMA loop).
 // Used when 9 * Cin_padded * BN weights fit next to one halo (DenseNet conv2 fwd/dgrad, the shape-stream ResBlocks).
+constexpr int res_halo_rowb(int cpr) { return ((HPITCH * (cpr * 16 + 16) + 255) / 256) * 256; }
+
 template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI>
 __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_kernel(TileArgs a)
 {
@@ -347,7 +362,11 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
     constexpr int EPC = 16 / sizeof(T);
     constexpr int KC = CPR * EPC;
     constexpr int PITCH = CPR * 16 + 16;
-    constexpr int HALO_BYTES = NPIX * PITCH;
+    // halo rows start on multiples of 256 B: with the odd chunk pitch (9 or 5 chunks per pixel) 16 consecutive columns then hit 16 different
+    // 16-byte bank groups whichever of the two halo rows of an A-fragment lane group they sit in (see swz_halo above); packed rows (18 pixels =
+    // 162 chunks = 2 mod 16) made columns x+12, x+13 of one row collide with x+4, x+5 of the next
+    constexpr int ROWB = res_halo_rowb(CPR);
+    constexpr int HALO_BYTES = HPITCH * ROWB;
     constexpr int WTAP = BN * PITCH;                 // one (cb, tap) weight tile
     constexpr int H_ITERS = (NPIX * CPR + NT - 1) / NT;
     constexpr int TI = WM / 32, TJ = WN / 32;
@@ -472,7 +491,7 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
                 for (int j = 0; j < EPC; ++j) f[j] = fmaxf(fmaf(f[j], sc[j], sh[j]), relu_lo);
                 v = Vec16<T>::pack(f);
             }
-            if (q < NPIX * CPR) *(u32x4*)(s_halo + (q / CPR) * PITCH + chunk * 16) = hok[i] ? v : z;
+            if (q < NPIX * CPR) *(u32x4*)(s_halo + (phyx[i] & 0xff) * ROWB + (phyx[i] >> 8) * PITCH + chunk * 16) = hok[i] ? v : z;
         }
     };
 
@@ -482,7 +501,7 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         const int row = wm0 + i * 32 + lr;
-        abase[i] = ((row >> 4) * HPITCH + (row & 15)) * PITCH + lh * 16;
+        abase[i] = (row >> 4) * ROWB + (row & 15) * PITCH + lh * 16;
     }
 #pragma unroll
     for (int j = 0; j < TJ; ++j) bbase[j] = (wn0 + j * 32 + lr) * PITCH + lh * 16;
@@ -577,7 +596,7 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
         const unsigned char* wb = s_w + c_cb * 9 * WTAP;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int aoff = ((tap / 3) * HPITCH + (tap % 3)) * PITCH;
+            const int aoff = (tap / 3) * ROWB + (tap % 3) * PITCH;
 #pragma unroll
             for (int s = 0; s < CPR / 2; ++s) {
                 u32x4 af[TI], bfr[TJ];
@@ -689,7 +708,7 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
 
 template <typename T, int BN, int WM, int WN, int CPR> static constexpr int res_lds_bytes(int ncb)
 {
-    return NPIX * (CPR * 16 + 16) + ncb * 9 * BN * (CPR * 16 + 16);
+    return HPITCH * res_halo_rowb(CPR) + ncb * 9 * BN * (CPR * 16 + 16);
 }
 
 template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI> static int launch_res_fwd_i(const TileArgs& a_in, hipStream_t st)
@@ -698,7 +717,7 @@ template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI> static int la
     constexpr int NT = (256 / WM) * (BN / WN) * 64;
     constexpr int EPC = 16 / sizeof(T);
     const int ncb = (a.Cin + CPR * EPC - 1) / (CPR * EPC);
-    constexpr int HALO_B = NPIX * (CPR * 16 + 16), EPI_B = 256 * BN * (int)sizeof(T);
+    constexpr int HALO_B = HPITCH * res_halo_rowb(CPR), EPI_B = 256 * BN * (int)sizeof(T);
     int lds = (HALO_B > EPI_B ? HALO_B : EPI_B) + ncb * 9 * BN * (CPR * 16 + 16);
     a.lds_acc_off = lds; lds += 2 * BN * 4 + 2 * ncb * CPR * EPC * 4;      // accumulators + the prologue scale/shift vectors
     auto kern = conv3x3_res_fwd_kernel<T, BN, WM, WN, CPR, BNEPI>;
@@ -721,7 +740,7 @@ template <typename T> static int dispatch_res_fwd(const TileArgs& a, hipStream_t
     const int ncb = (a.Cin + cpr * EPC - 1) / (cpr * EPC);
     const int pitch = cpr * 16 + 16;
     const int bn = a.Cout <= 32 ? 32 : (a.Cout <= 64 ? 64 : 128);
-    const long halo_b = (long)NPIX * pitch, epi_b = 256L * bn * sizeof(T);
+    const long halo_b = (long)HPITCH * res_halo_rowb(cpr), epi_b = 256L * bn * sizeof(T);
     long lds = (halo_b > epi_b ? halo_b : epi_b) + (long)ncb * 9 * bn * pitch + 2 * bn * 4 + 2L * ncb * cpr * EPC * 4;
     *handled = lds <= 154 * 1024 && (a.tiles_x * a.tiles_y * a.N) >= 32;   // even at one tile per block a single bulk weight load beats nine dependent per-tap loads
     if (!*handled) return SAUNET_OK;
