@@ -50,7 +50,9 @@ constexpr int DF_TR = 8, DF_TW = 16, DF_NPX = DF_TR * DF_TW;            // pixel
 constexpr int DF_HR = DF_TR + 2, DF_HC = DF_TW + 2, DF_NH = DF_HR * DF_HC;
 constexpr int DF_KCH = 128;                                               // conv1 weight chunk (channels)
 constexpr int DF_W1P = DF_KCH + 8;                                        // u16 pitch of a weight-chunk row (272 B: rows 4 banks apart)
-constexpr int DF_HP = 128 + 8;                                            // u16 pitch of a halo row
+constexpr int DF_HP = 128 + 8;                                            // u16 pitch of a halo pixel (17 chunks of 16 B: odd)
+constexpr int DF_HROW = ((DF_HC * DF_HP * 2 + 255) / 256) * 128;          // u16 pitch of a halo ROW: a multiple of 256 B, so the two halo rows an MFMA
+                                                                          // fragment lane group touches do not collide (see swz_halo in conv_tile.hip)
 constexpr int DF_W2P = 9 * 128 + 8;                                       // u16 pitch of a conv2 weight row (2320 B)
 constexpr int DF_CMAX = 1024;                                             // concat channels kept in LDS (mean / var / scale / shift)
 constexpr unsigned DF_SPIN_LIMIT = 1u << 22;
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(DF_THREADS, 1) void dense_block_fwd_kernel(DenseFwd
     unsigned char* s_big = (unsigned char*)(s_sum + 256);
     u16* s_w1 = (u16*)s_big;                       // conv1: [3][128][W1P]
     u16* s_halo = (u16*)s_big;                     // conv2: [NH][HP]
-    u16* s_w2 = s_halo + DF_NH * DF_HP;            // conv2: [32][W2P]
+    u16* s_w2 = s_halo + DF_HR * DF_HROW;          // conv2: [32][W2P]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     const int nblk = gridDim.x, bid = blockIdx.x;
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(DF_THREADS, 1) void dense_block_fwd_kernel(DenseFwd
                             for (int j = 0; j < 8; ++j) f[j] = fmaxf(fmaf(f[j], sc2[j], sh2[j]), 0.f);
                             o = Vec16<u16>::pack(f);
                         }
-                        *(u32x4*)(s_halo + hp * DF_HP + ch * 8) = o;
+                        *(u32x4*)(s_halo + (hp / DF_HC) * DF_HROW + (hp % DF_HC) * DF_HP + ch * 8) = o;
                     }
                 }
             }
@@ -443,11 +445,11 @@ __global__ __launch_bounds__(DF_THREADS, 1) void dense_block_fwd_kernel(DenseFwd
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const int hbase = (2 * wave + (lr >> 4)) * DF_HC + (lr & 15);       // halo pixel of this lane's output pixel, tap (0,0)
+            const int hbase = (2 * wave + (lr >> 4)) * DF_HROW + (lr & 15) * DF_HP;       // halo element offset of this lane's output pixel, tap (0,0)
             const u16* wrow = s_w2 + lr * DF_W2P + lh * 8;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                const u16* hrow = s_halo + (hbase + (tap / 3) * DF_HC + (tap % 3)) * DF_HP + lh * 8;
+                const u16* hrow = s_halo + hbase + (tap / 3) * DF_HROW + (tap % 3) * DF_HP + lh * 8;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
                     const u32x4 wf = *(const u32x4*)(wrow + tap * 128 + ks * 16);
@@ -522,7 +524,7 @@ int saunet_dense_block_forward(const saunet_dense_fwd_desc* d, void* sync_ws, vo
         return set_error(SAUNET_LAUNCH_FAILED, "dense_block_forward: cannot query the device");
     const int blocks = a.ntiles < cus ? a.ntiles : cus;            // one workgroup per CU: all of them are resident, the grid barrier cannot starve
     const size_t lds_small = sizeof(float) * (4 * DF_CMAX + 256);
-    const size_t big1 = (size_t)3 * 128 * DF_W1P * 2, big2 = ((size_t)DF_NH * DF_HP + (size_t)32 * DF_W2P) * 2;
+    const size_t big1 = (size_t)3 * 128 * DF_W1P * 2, big2 = ((size_t)DF_HR * DF_HROW + (size_t)32 * DF_W2P) * 2;
     const size_t lds = lds_small + (big1 > big2 ? big1 : big2);
     static bool attr_set = false;
     if (!attr_set) {
