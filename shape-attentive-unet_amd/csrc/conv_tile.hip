@@ -11,6 +11,7 @@
 //
 // MFMA: mfma_f32_32x32x16_bf16 (bf16 storage) / mfma_f32_32x32x2_f32 (float32 storage, exact f32).
 #include "common.h"
+#include <stdlib.h>
 
 namespace saunet {
 
@@ -341,7 +342,14 @@ template <typename T> static int dispatch_tile_fwd(const TileArgs& a, hipStream_
     // low-resolution maps with many channels (center, dec5: 32 pixel tiles): 64-channel output tiles double the number of
     // workgroups instead of leaving half of the CUs idle; the halo re-reads come from the L2
     const long blocks128 = (long)a.tiles_x * a.tiles_y * a.N * ((a.Cout + 127) / 128);
-    if (a.Cout <= 64 || (blocks128 < 256 && !a.epi.bn_x))
+    // two resident workgroups per CU hide the fragment-read latency that one four-wave workgroup per CU exposes (MFMA pipe 19-28 % busy on
+    // dec4 / dec5): below 512 workgroups the output-channel tile is halved (dec4 233 -> 196 us with 64-wide tiles, dec5 259 -> 233 us with 32-wide
+    // ones; the extra halo re-reads come from the L2).  Environment overrides for A/B runs.
+    static const long t128 = getenv("SAUNET_TILE_T128") ? atol(getenv("SAUNET_TILE_T128")) : 512;
+    static const long t64 = getenv("SAUNET_TILE_T64") ? atol(getenv("SAUNET_TILE_T64")) : 512;
+    const long blocks64 = (long)a.tiles_x * a.tiles_y * a.N * ((a.Cout + 63) / 64);
+    if (!a.epi.bn_x && blocks64 < t64) return narrow ? launch_tile_fwd<T, 32, 64, 32, 4>(a, st) : launch_tile_fwd<T, 32, 64, 32, 8>(a, st);
+    if (a.Cout <= 64 || (blocks128 < t128 && !a.epi.bn_x))
         return narrow ? launch_tile_fwd<T, 64, 64, 64, 4>(a, st) : launch_tile_fwd<T, 64, 64, 64, 8>(a, st);
     return narrow ? launch_tile_fwd<T, 128, 128, 64, 4>(a, st) : launch_tile_fwd<T, 128, 128, 64, 8>(a, st);
 }
