@@ -29,6 +29,7 @@ elif case in ("dense3fwd", "dense4fwd"):
     unit = "dense_fwd"
     layers, cin, h = {"dense3fwd": (24, 256, 32), "dense4fwd": (16, 512, 16)}[case]
     S.set_compute_dtype(dt)
+    HF.DENSE_PERSIST = True                       # the persistent whole-block forward is opt-in
     block = S.modules._DenseBlock(layers, cin).cuda().train()
     x = act(cin, h)
     def run():
