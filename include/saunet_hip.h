@@ -92,6 +92,18 @@ int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const voi
 int saunet_conv2d_wgrad(const saunet_conv_desc* d, const void* x, const void* dy,
                         const float* pro_scale, const float* pro_shift, float* dw,
                         void* workspace, int64_t workspace_bytes, void* stream);
+/* The same with the cross-workgroup reduction of the tiled kernels DEFERRED: when the shape runs on them only the per-group partial
+ * gradients are written to `workspace` and *pending describes the reduction still to do (pending->groups > 0; the workspace must stay
+ * untouched until saunet_wgrad_reduce_multi has run); otherwise the gradient is complete on return and pending->groups == 0.
+ * saunet_wgrad_reduce_multi performs up to SAUNET_WGRAD_REDUCE_MAX pending reductions in ONE launch (dw[i] += sum over groups, no atomics)
+ * -- a DenseNet block's backward issues two weight gradients per layer, i.e. 116 tiny reduce launches per step otherwise. */
+#define SAUNET_WGRAD_REDUCE_MAX 64
+typedef struct saunet_wgrad_pending { const float* ws; float* dw; int64_t wsize; int32_t groups, reserved; } saunet_wgrad_pending;
+typedef struct saunet_wgrad_reduce_list { int32_t count, reserved; saunet_wgrad_pending item[SAUNET_WGRAD_REDUCE_MAX]; } saunet_wgrad_reduce_list;
+int saunet_conv2d_wgrad_deferred(const saunet_conv_desc* d, const void* x, const void* dy,
+                                 const float* pro_scale, const float* pro_shift, float* dw,
+                                 void* workspace, int64_t workspace_bytes, saunet_wgrad_pending* pending, void* stream);
+int saunet_wgrad_reduce_multi(const saunet_wgrad_reduce_list* l, void* stream);
 /* bytes of caller-owned scratch saunet_conv2d_wgrad needs for this shape (0 = none; <0 = saunet_status).
  * The tiled kernels write per-block partial gradients there with plain stores and reduce them afterwards
  * (cross-XCD float atomics on the same addresses are ~10x more expensive than the stores + one reduce pass). */

@@ -28,7 +28,8 @@ bool tile_wgrad_unaligned_supported(const saunet_conv_desc* d);
 // on the shape-stream layers (scalar 2-byte global loads dominate) -> kept off until the staging is made cooperative
 constexpr bool kUnalignedTileWgrad = false;
 int tile_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw,
-               void* ws, size_t ws_bytes, size_t* need, bool aligned, hipStream_t st);
+               void* ws, size_t ws_bytes, size_t* need, bool aligned, hipStream_t st, saunet_wgrad_pending* pend = nullptr);
+int wgrad_reduce_multi(const saunet_wgrad_reduce_list* l, hipStream_t st);
 int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps, const float* psh,
                  void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st);
 
@@ -624,15 +625,31 @@ int64_t saunet_conv2d_wgrad_workspace(const saunet_conv_desc* d)
 int saunet_conv2d_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw,
                         void* workspace, int64_t workspace_bytes, void* stream)
 {
+    return saunet_conv2d_wgrad_deferred(d, x, dy, ps, psh, dw, workspace, workspace_bytes, nullptr, stream);
+}
+
+int saunet_wgrad_reduce_multi(const saunet_wgrad_reduce_list* l, void* stream)
+{
+    if (l->count < 1 || l->count > SAUNET_WGRAD_REDUCE_MAX) return set_error(SAUNET_BAD_SHAPE, "wgrad_reduce_multi: %d entries", l->count);
+    for (int e = 0; e < l->count; ++e)
+        if (!l->item[e].ws || !l->item[e].dw || l->item[e].wsize < 1 || l->item[e].groups < 1)
+            return set_error(SAUNET_BAD_SHAPE, "wgrad_reduce_multi: entry %d is empty", e);
+    return wgrad_reduce_multi(l, (hipStream_t)stream);
+}
+
+int saunet_conv2d_wgrad_deferred(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw,
+                                 void* workspace, int64_t workspace_bytes, saunet_wgrad_pending* pending, void* stream)
+{
     hipStream_t st = (hipStream_t)stream;
+    if (pending) { pending->ws = nullptr; pending->dw = nullptr; pending->wsize = 0; pending->groups = 0; pending->reserved = 0; }
     saunet_conv_desc flat;
     if (is_pointwise(d) && dense_pointwise_rows(d, &flat)) d = &flat;     // pixels are just rows for a 1x1 conv: any map shape tiles
     if (igemm_supported(d)) {
-        if (tile_wgrad_supported(d)) return tile_wgrad(d, x, dy, ps, psh, dw, workspace, (size_t)workspace_bytes, nullptr, true, st);
+        if (tile_wgrad_supported(d)) return tile_wgrad(d, x, dy, ps, psh, dw, workspace, (size_t)workspace_bytes, nullptr, true, st, pending);
         return igemm_wgrad(d, x, dy, ps, psh, dw, st);
     }
     if (kUnalignedTileWgrad && tile_wgrad_unaligned_supported(d))
-        return tile_wgrad(d, x, dy, ps, psh, dw, workspace, (size_t)workspace_bytes, nullptr, false, st);
+        return tile_wgrad(d, x, dy, ps, psh, dw, workspace, (size_t)workspace_bytes, nullptr, false, st, pending);
     if (!is_pointwise(d)) return set_error(SAUNET_UNSUPPORTED, "wgrad: %dx%d Cin=%d Cout=%d has no kernel", d->KH, d->KW, d->Cin, d->Cout);
     const int nW = d->Cin * d->Cout;
     PwWgradArgs a{x, dy, dw, ps, psh, (long)d->N * d->H * d->W, d->Cin, d->Cout, d->ldx, d->ldy, d->pro_relu, 0, (long)d->Cin, 1, 32};

@@ -791,6 +791,7 @@ struct TileWgradArgs {
     int tiles_x, tiles_y, ntiles, ncit;   // tiles per row / column, total, number of ci tiles
     long sM, sN;
     float* ws; long wsize;                 // per-group partial gradients [groups][wsize] (plain stores, reduced afterwards)
+    saunet_wgrad_pending* pend;            // non-null: do not launch the reduction, describe it here (saunet_wgrad_reduce_multi runs it later)
 };
 
 // one ds_read_b64_tr_b16: every 16-lane group reads a [4 rows][16 cols] block of 16-bit elements (each lane
@@ -1071,6 +1072,11 @@ template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KS
     if (a.ws == nullptr || ws_bytes < bytes) return set_error(SAUNET_BAD_SHAPE, "wgrad: workspace %zu < %zu bytes", ws_bytes, bytes);
     dim3 grid(groups, ncot * a.ncit);
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, a);
+    if (a.pend) {
+        a.pend->ws = a.ws; a.pend->dw = a.dw; a.pend->wsize = a.wsize; a.pend->groups = groups; a.pend->reserved = 0;
+        SAUNET_CHECK_LAUNCH("conv_tile_wgrad");
+        return SAUNET_OK;
+    }
     long rb = (a.wsize + 255) / 256; if (rb > 2048) rb = 2048;
     int gsl = 1;                       // group slices: enough blocks to fill the chip even for small weight tensors
     while (rb * gsl < 512 && gsl * 8 < groups) gsl *= 2;
@@ -1117,10 +1123,44 @@ bool tile_wgrad_supported(const saunet_conv_desc* d)
     return !d->transposed && (k3 || k1) && d->stride == 1 && d->H % TILE == 0 && d->W % TILE == 0 && d->Ho == d->H && d->Wo == d->W;
 }
 
+// all pending reductions of a list in ONE launch: blockIdx.y = entry, dw[i] += sum over the groups of ws[g][i] (no atomics: deterministic)
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(saunet_wgrad_reduce_list l)
+{
+    const saunet_wgrad_pending& e = l.item[blockIdx.y];
+    const float* __restrict__ ws = e.ws;
+    float* __restrict__ dw = e.dw;
+    const long wsize = e.wsize;
+    const int groups = e.groups;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < wsize; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        int g = 0;
+        for (; g + 8 <= groups; g += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(g + u) * wsize + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; g < groups; ++g) s += ws[(size_t)g * wsize + i];
+        dw[i] += s;
+    }
+}
+
+int wgrad_reduce_multi(const saunet_wgrad_reduce_list* l, hipStream_t st)
+{
+    long biggest = 1;
+    for (int e = 0; e < l->count; ++e) if (l->item[e].wsize > biggest) biggest = l->item[e].wsize;
+    long bx = (biggest + 1023) / 1024; if (bx > 256) bx = 256; if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)bx, l->count), dim3(256), 0, st, *l);
+    SAUNET_CHECK_LAUNCH("wgrad_reduce_multi");
+    return SAUNET_OK;
+}
+
 int tile_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw,
-               void* ws, size_t ws_bytes, size_t* need, bool aligned, hipStream_t st)
+               void* ws, size_t ws_bytes, size_t* need, bool aligned, hipStream_t st, saunet_wgrad_pending* pend)
 {
     TileWgradArgs a;
+    a.pend = pend;
     a.ws = (float*)ws;
     a.x = x; a.dy = dy; a.dw = dw; a.pro_scale = ps; a.pro_shift = psh; a.pro_relu = d->pro_relu;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Cout = d->Cout; a.lddy = d->ldy;

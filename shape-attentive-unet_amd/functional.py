@@ -398,6 +398,7 @@ class SideStream:
 
 WGRAD_SIDE = SideStream()
 DENSE_WGRAD_DEFER = os.environ.get("SAUNET_DENSE_WGRAD_DEFER", "")
+DENSE_WGRAD_BATCH_REDUCE = os.environ.get("SAUNET_DENSE_WGRAD_BATCH_REDUCE", "1") != "0"   # A/B switch: per-conv reduce launches when "0"
 
 
 class _ShapeOnly:
@@ -410,7 +411,9 @@ class _ShapeOnly:
         return self.shape.numel()
 
 
-def conv_wgrad_raw(x, dy, weight, stride, pad, transposed=False, pro=None):
+def conv_wgrad_raw(x, dy, weight, stride, pad, transposed=False, pro=None, pending=None):
+    """pending: optional list collecting the deferred cross-workgroup reductions of the tiled kernels (flush_wgrad_reductions runs them in
+    one launch); the returned gradient is complete only after that flush."""
     x = nhwc(x); dy = nhwc(dy)
     if (WGRAD_SIDE.enabled and x.is_cuda and isinstance(weight, torch.nn.Parameter)   # leaf weights only: nothing in the
             and (WGRAD_SIDE.max_pixels <= 0 or x.shape[0] * x.shape[2] * x.shape[3] <= WGRAD_SIDE.max_pixels)):
@@ -423,10 +426,22 @@ def conv_wgrad_raw(x, dy, weight, stride, pad, transposed=False, pro=None):
             t.record_stream(side)
         WGRAD_SIDE.mark()
         return dw
-    return _conv_wgrad_impl(x, dy, weight, stride, pad, transposed, pro)
+    return _conv_wgrad_impl(x, dy, weight, stride, pad, transposed, pro, pending)
 
 
-def _conv_wgrad_impl(x, dy, weight, stride, pad, transposed=False, pro=None):
+def flush_wgrad_reductions(pending):
+    """dw += sum over groups of the partial gradients, for every entry collected by conv_wgrad_raw(..., pending=list): ONE launch per 64."""
+    for i in range(0, len(pending), L.WGRAD_REDUCE_MAX):
+        chunk = pending[i:i + L.WGRAD_REDUCE_MAX]
+        lst = L.WgradReduceList()
+        lst.count = len(chunk)
+        for j, (p, _ws, _dw) in enumerate(chunk):
+            lst.item[j] = p
+        L.call("saunet_wgrad_reduce_multi", C.byref(lst), L.stream())
+    del pending[:]
+
+
+def _conv_wgrad_impl(x, dy, weight, stride, pad, transposed=False, pro=None, pending=None):
     if transposed and pro is None and weight.shape[2:] == (4, 4) and weight.shape[1] % 8 == 0 and weight.shape[0] % 8 == 0:
         # ConvTranspose2d(k=4, s=2, p=1):  dW[ci][co][kh][kw] = sum x[n,ih,iw,ci] * dy[n, 2ih-1+kh, 2iw-1+kw, co]  is the weight
         # gradient of a POINTWISE conv from im2col(dy; k=4, s=2, p=1) (K order kh,kw,co) to x: one gather pass over dy,
@@ -451,6 +466,13 @@ def _conv_wgrad_impl(x, dy, weight, stride, pad, transposed=False, pro=None):
     if need < 0:
         raise RuntimeError("saunet_conv2d_wgrad_workspace failed (%d)" % need)
     ws = torch.empty(need // 4, dtype=torch.float32, device=x.device) if need > 0 else None
+    if pending is not None and ws is not None:
+        pd = L.WgradPending()
+        L.call("saunet_conv2d_wgrad_deferred", C.byref(d), x.data_ptr(), dy.data_ptr(), L.ptr(pro[0]) if pro else None,
+               L.ptr(pro[1]) if pro else None, dw.data_ptr(), L.ptr(ws), need, C.byref(pd), L.stream())
+        if pd.groups > 0:
+            pending.append((pd, ws, dw))        # the workspace and the gradient stay alive until the flush
+        return dw
     L.call("saunet_conv2d_wgrad", C.byref(d), x.data_ptr(), dy.data_ptr(), L.ptr(pro[0]) if pro else None,
            L.ptr(pro[1]) if pro else None, dw.data_ptr(), L.ptr(ws), need, L.stream())
     return dw
@@ -1453,6 +1475,7 @@ class _DenseBlock(torch.autograd.Function):
         # queue per process, which could not be re-checked against RCCL with one GPU per rank.
         defer = buf.is_cuda and DENSE_WGRAD_DEFER == "1" and not torch.cuda.is_current_stream_capturing()
         deferred = []
+        pend = [] if (buf.is_cuda and DENSE_WGRAD_BATCH_REDUCE and not WGRAD_SIDE.enabled) else None   # the 2 x L partial-gradient reductions: one launch
         for l in reversed(range(nl)):
             n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
             z1, p1b, p2b = saved[3 * l:3 * l + 3]
@@ -1463,12 +1486,12 @@ class _DenseBlock(torch.autograd.Function):
             correct(cin, cin + growth)
             dz2 = dbuf[:, cin:cin + growth]
             if not defer:
-                dw2 = conv_wgrad_raw(z1, dz2, c2w, 1, 1, pro=(p2.scale, p2.shift, True))
+                dw2 = conv_wgrad_raw(z1, dz2, c2w, 1, 1, pro=(p2.scale, p2.shift, True), pending=pend)
             s2 = new_stats(z1.shape[1], dev)
             da2 = conv_dgrad_raw(dz2, c2w, z1.shape, 1, 1, bn_epi=(z1, p2, True, s2))
             dz1, _, dg2, db2 = bn_backward(da2, z1, p2, True, count, training, dx=da2, presums=s2)
             if not defer:
-                dw1 = conv_wgrad_raw(xin, dz1, c1w, 1, 0, pro=(p1.scale, p1.shift, True))
+                dw1 = conv_wgrad_raw(xin, dz1, c1w, 1, 0, pro=(p1.scale, p1.shift, True), pending=pend)
             else:
                 dw1 = dw2 = None
                 deferred.append((l, z1, dz2, dz1, xin, p1, p2, c1w, c2w))
@@ -1490,6 +1513,8 @@ class _DenseBlock(torch.autograd.Function):
                         t.record_stream(side)
             buf.record_stream(side); dbuf.record_stream(side)
             WGRAD_SIDE.mark()
+        if pend:
+            flush_wgrad_reductions(pend)
         correct(0, c0)
         dx0 = dbuf[:, :c0] if ctx.needs_input_grad[0] else None
         return (dx0, None, None) + tuple(grads) + (None,) * (4 * nl)

@@ -45,6 +45,17 @@ class DenseFwdDesc(C.Structure):
                [("buf", C.c_void_p), ("stats", C.c_void_p), ("layer", DenseFwdLayer * DENSE_MAX_LAYERS)]
 
 
+WGRAD_REDUCE_MAX = 64
+
+
+class WgradPending(C.Structure):
+    _fields_ = [("ws", C.c_void_p), ("dw", C.c_void_p), ("wsize", C.c_int64), ("groups", C.c_int32), ("reserved", C.c_int32)]
+
+
+class WgradReduceList(C.Structure):
+    _fields_ = [("count", C.c_int32), ("reserved", C.c_int32), ("item", WgradPending * WGRAD_REDUCE_MAX)]
+
+
 class TensorList(C.Structure):
     _fields_ = [("count", C.c_int32), ("ptrs", (C.c_void_p * 96) * 4), ("numel", C.c_int64 * 96)]
 
@@ -59,6 +70,8 @@ _SIGS = {
     "saunet_conv2d_forward_ex": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(BnEpilogue), vp],
     "saunet_conv2d_wgrad": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i64, vp],
     "saunet_conv2d_wgrad_workspace": [C.POINTER(ConvDesc)],
+    "saunet_conv2d_wgrad_deferred": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i64, C.POINTER(WgradPending), vp],
+    "saunet_wgrad_reduce_multi": [C.POINTER(WgradReduceList), vp],
     "saunet_channel_sum": [i32, vp, i64, i32, i32, vp, vp],
     "saunet_bn_stats": [i32, vp, i64, i32, i32, vp, vp, i32, i32, vp],
     "saunet_sum_replicas": [vp, i32, i32, i32, vp],
