@@ -367,3 +367,25 @@ def test_channel_sum_vector_and_scalar_paths(dtype, c, ctot, shape):
     want = t.double().sum((0, 2, 3))
     assert got.shape == (c,)
     assert float((got.double() - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max())) * (1 if dtype == torch.float32 else 10)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_deferred_wgrad_reduction_matches_the_immediate_one(dtype):
+    """saunet_conv2d_wgrad_deferred + saunet_wgrad_reduce_multi (several pending reductions in one launch) against saunet_conv2d_wgrad."""
+    import saunet_amd as S
+    HF = S.functional
+    torch.manual_seed(3)
+    cases = [(2, 64, 32, 32, 32, 3), (2, 96, 32, 32, 128, 1), (1, 128, 16, 48, 32, 3)]
+    pend, deferred, immediate = [], [], []
+    for (n, cin, h, w, cout, k) in cases:
+        x = torch.randn(n, cin, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(n, cout, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+        wt = torch.nn.Parameter(torch.randn(cout, cin, k, k, device="cuda") * 0.05)
+        immediate.append(HF.conv_wgrad_raw(x, dy, wt, 1, k // 2).clone())
+        deferred.append(HF.conv_wgrad_raw(x, dy, wt, 1, k // 2, pending=pend))
+    assert len(pend) == len(cases), "the tiled kernels should have left one pending reduction per case"
+    HF.flush_wgrad_reductions(pend)
+    torch.cuda.synchronize()
+    assert not pend
+    for a, b in zip(deferred, immediate):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
