@@ -744,6 +744,64 @@ def conv_bn_act(x, weight, bias, bn, relu=True, residual=None, stride=1, padding
                             transposed, relu, bn.momentum, bn.eps, bn.training, group, sync_bufs, out, pool)
 
 
+class _BasicBlock(torch.autograd.Function):
+    """relu(bn2(conv2(relu(bn1(conv1(x))))) + x), 3x3 stride-1 convolutions (models/resnet.py:30-60, the shape stream's res1-3), with bn1 + ReLU
+    applied in conv2's operand load: the activated intermediate is never materialised (forward: one read + one write of the full-resolution
+    tensor less) and bn1's backward reduction rides in conv2's data-gradient epilogue (one two-tensor pass less).  Single-process statistics
+    only: SynchronizedBatchNorm across ranks keeps the unfused path (it needs the all-reduce between reduce and apply)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, mom1, eps1, mom2, eps2, training):
+        x = nhwc(x)
+        c = w1.shape[0]
+        st1 = new_stats(c, x.device) if training else None
+        z1 = conv_forward_raw(x, w1, None, 1, 1, stats=st1)
+        count = z1.shape[0] * z1.shape[2] * z1.shape[3]
+        p1 = bn_finalize(st1, count, g1, b1, rm1, rv1, mom1, eps1, training)
+        st2 = new_stats(c, x.device) if training else None
+        z2 = conv_forward_raw(z1, w2, None, 1, 1, pro=(p1.scale, p1.shift, True), stats=st2)
+        p2 = bn_finalize(st2, count, g2, b2, rm2, rv2, mom2, eps2, training)
+        y = affine_act(z2, p2.scale, p2.shift, True, x)
+        ctx.save_for_backward(x, w1, w2, z1, z2, p1.buf, p2.buf)
+        ctx.cfg = (training, count)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, z1, z2, p1b, p2b = ctx.saved_tensors
+        training, count = ctx.cfg
+        p1 = BNParams.__new__(BNParams); p1.buf = p1b
+        p2 = BNParams.__new__(BNParams); p2.buf = p2b
+        dz2, dres, dg2, db2 = bn_backward(dy, z2, p2, True, count, training, x, want_dres=True)
+        dw2 = conv_wgrad_raw(z1, dz2, w2, 1, 1, pro=(p1.scale, p1.shift, True))
+        s1 = new_stats(z1.shape[1], z1.device)
+        da1 = conv_dgrad_raw(dz2, w2, z1.shape, 1, 1, bn_epi=(z1, p1, True, s1))
+        dz1, _, dg1, db1 = bn_backward(da1, z1, p1, True, count, training, dx=da1, presums=s1)
+        dw1 = conv_wgrad_raw(x, dz1, w1, 1, 1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_dgrad_raw(dz1, w1, x.shape, 1, 1)
+            copy_channels(dres, dx, accumulate=True)
+        return dx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None, None
+
+
+# Opt-in (SAUNET_FUSED_BASIC_BLOCK=1).  Measured twice (rounds 1 and 2, same-box A/B): the three full-resolution passes it saves (0.3 ms) are lost
+# to the slower prologue / epilogue variants of the 64-, 32- and 16-channel kernels it needs instead -- 33.45 -> 33.86 ms per step.
+FUSED_BASIC_BLOCK = os.environ.get("SAUNET_FUSED_BASIC_BLOCK", "0") == "1"
+
+
+def basic_block(x, conv1, bn1, conv2, bn2):
+    """BasicBlock forward; the fused form when it applies (training or grad mode on the GPU, batch statistics local to this process)."""
+    synced = getattr(bn1, "sync", False) and bn1.training and torch.distributed.is_available() and torch.distributed.is_initialized() \
+        and torch.distributed.get_world_size() > 1
+    if not FUSED_BASIC_BLOCK or synced or not x.is_cuda or not (bn1.training or torch.is_grad_enabled()) or bn1.training != bn2.training:
+        out = conv_bn_act(x, conv1.weight, None, bn1, relu=True, padding=1)
+        return conv_bn_act(out, conv2.weight, None, bn2, relu=True, residual=x, padding=1)
+    _bump(bn1); _bump(bn2)
+    return _BasicBlock.apply(x, conv1.weight, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, conv2.weight, bn2.weight, bn2.bias,
+                             bn2.running_mean, bn2.running_var, bn1.momentum, bn1.eps, bn2.momentum, bn2.eps, bn1.training)
+
+
 class _BNAct(torch.autograd.Function):
     """Stand-alone BatchNorm (+ReLU) over a materialised tensor; optional precomputed statistics."""
 

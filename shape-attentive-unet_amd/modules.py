@@ -109,8 +109,7 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = HF.conv_bn_act(x, self.conv1.weight, None, self.bn1, relu=True, padding=1)
-        return HF.conv_bn_act(out, self.conv2.weight, None, self.bn2, relu=True, residual=x, padding=1)
+        return HF.basic_block(x, self.conv1, self.bn1, self.conv2, self.bn2)
 
 
 class GatedSpatialConv2d(nn.Conv2d):

@@ -68,3 +68,41 @@ def test_module_matches_reference_fixture(name):
     for i, t in enumerate(ys):
         ok, err, sc = close(t.float().cpu().numpy(), gold["eval.out%d" % i], tol, 1e-6)
         assert ok, "%s eval out%d err %.3g scale %.3g" % (name, i, err, sc)
+
+
+def test_fused_basic_block_matches_the_unfused_path():
+    """functional._BasicBlock (bn1 + ReLU in conv2's operand load, opt-in) against the two conv_bn_act calls it replaces: output, input
+    gradient, parameter gradients and running statistics, float32 storage."""
+    import saunet_amd as S
+    HF = S.functional
+    S.set_compute_dtype(torch.float32)
+    torch.manual_seed(11)
+    blk = S.BasicBlock(32, 32).cuda().train()
+    with torch.no_grad():
+        for m in blk.modules():
+            if hasattr(m, "running_mean") and m.weight is not None and m.weight.dim() == 1:
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+    state0 = {k: v.clone() for k, v in blk.state_dict().items()}
+    x0 = torch.randn(2, 32, 32, 48, device="cuda").contiguous(memory_format=torch.channels_last)
+    cot = torch.randn(2, 32, 32, 48, device="cuda")
+    res = {}
+    saved = HF.FUSED_BASIC_BLOCK
+    try:
+        for mode in (True, False):
+            HF.FUSED_BASIC_BLOCK = mode
+            blk.load_state_dict(state0); HF.notify_params_changed(); blk.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            y = blk(x)
+            (y * cot).sum().backward()
+            torch.cuda.synchronize()
+            res[mode] = (y.detach().clone(), x.grad.clone(), {k: v.grad.clone() for k, v in blk.named_parameters()},
+                         {k: v.clone() for k, v in blk.state_dict().items() if "running" in k})
+    finally:
+        HF.FUSED_BASIC_BLOCK = saved
+    (ya, dxa, ga, ra), (yb, dxb, gb, rb) = res[True], res[False]
+    def rel(a, b): return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert rel(ya, yb) < 1e-4 and rel(dxa, dxb) < 2e-4
+    for k in ga:
+        assert rel(ga[k], gb[k]) < 2e-4, k
+    for k in ra:
+        assert rel(ra[k], rb[k]) < 1e-5, k
