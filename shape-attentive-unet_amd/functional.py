@@ -1395,8 +1395,8 @@ DENSE_PERSIST_MAXPIX = int(os.environ.get("SAUNET_DENSE_PERSIST_MAXPIX", "65536"
 
 def _dense_persistent_ok(x0, c0, growth, nl, params):
     """The whole-block persistent forward (csrc/dense_fwd.hip) serves the low-resolution training blocks in bf16 storage.  It is a kernel
-    with device-wide barriers: it is not used when several processes may share the device (torch.distributed initialised with more than
-    one rank -- the data-parallel test rig runs two ranks on one GPU), where two such launches could starve each other."""
+    with device-wide barriers: it is not used when several ranks share ONE device (SAUNET_SHARE_GPU=1, the data-parallel test rig), where two
+    such launches could starve each other; one rank per GPU is fine."""
     if not (DENSE_PERSIST and x0.is_cuda and x0.dtype == torch.bfloat16):
         return False
     n, _, h, w = x0.shape
@@ -1405,8 +1405,9 @@ def _dense_persistent_ok(x0, c0, growth, nl, params):
     if any(tuple(params[6 * l + 2].shape[2:]) != (1, 1) or params[6 * l + 2].shape[0] != 128 or tuple(params[6 * l + 5].shape[1:]) != (128, 3, 3)
            for l in range(nl)):
         return False
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-        return False
+    if os.environ.get("SAUNET_SHARE_GPU") == "1" and torch.distributed.is_available() and torch.distributed.is_initialized() \
+            and torch.distributed.get_world_size() > 1:
+        return False                      # the test rig's several ranks on ONE device (dp.init_from_env): two such launches could starve each other
     return True
 
 

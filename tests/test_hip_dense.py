@@ -112,3 +112,37 @@ def test_persistent_block_forward_matches_the_per_layer_launches(layers, cin, sh
     assert rel_l2(dxa, dxb) < 0.1, rel_l2(dxa, dxb)
     for k in ga:
         assert rel_l2(ga[k], gb[k]) < 0.1, (k, rel_l2(ga[k], gb[k]))
+
+
+def test_whole_network_with_the_persistent_block_forward():
+    """SAUNet forward + backward in bf16 storage with the opt-in persistent dense-block forward against the default per-layer launches: same
+    loss to bf16 noise, every parameter gradient strongly aligned (the two paths round the same tensors; they differ in summation order and in
+    the ReLU masks that flips near zero), abort word clear."""
+    import saunet_amd as S
+    from oracle import saunet_ref as R, weights as Wt
+    HF = S.functional
+    S.set_compute_dtype(torch.bfloat16)
+    sd = Wt.make_state_dict(R.state_dict_spec(), 21)
+    img, seg, edge = Wt.synthetic_batch(2, 128, 128, seed=77)
+    feed = {"image": img.cuda(), "mask": (seg.cuda(), edge.cuda())}
+    saved, out = HF.DENSE_PERSIST, {}
+    try:
+        for mode in (False, True):
+            HF.DENSE_PERSIST = mode
+            HF.LAST_DENSE_SYNC = None
+            net = S.SAUNet(num_classes=4).cuda()
+            net.load_state_dict(sd, strict=False); HF.notify_params_changed()
+            sm = S.SegmentationModule(S.DualLoss(mode="train"), net, 4).train()
+            loss, _ = sm(feed, 1)
+            loss.backward(); torch.cuda.synchronize()
+            if mode:
+                assert HF.LAST_DENSE_SYNC is not None and int(HF.LAST_DENSE_SYNC.cpu()[1]) == 0
+            out[mode] = (float(loss), {k: v.grad.float().clone() for k, v in net.named_parameters() if v.grad is not None})
+    finally:
+        HF.DENSE_PERSIST = saved
+        S.set_compute_dtype(torch.float32)
+    (la, ga), (lb, gb) = out[False], out[True]
+    assert abs(la - lb) < 2e-2 * abs(la), (la, lb)
+    num = sum(float((ga[k] * gb[k]).sum()) for k in ga)
+    den = (sum(float(ga[k].pow(2).sum()) for k in ga) * sum(float(gb[k].pow(2).sum()) for k in gb)) ** 0.5
+    assert num / den > 0.98, num / den
