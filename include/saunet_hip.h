@@ -104,6 +104,26 @@ int saunet_conv2d_wgrad_deferred(const saunet_conv_desc* d, const void* x, const
                                  const float* pro_scale, const float* pro_shift, float* dw,
                                  void* workspace, int64_t workspace_bytes, saunet_wgrad_pending* pending, void* stream);
 int saunet_wgrad_reduce_multi(const saunet_wgrad_reduce_list* l, void* stream);
+/* Weight gradients of up to SAUNET_WGRAD_GROUP_MAX stride-1 convolutions of ONE geometry (same N x H x W map, same kernel size 1x1 pad 0 or
+ * 3x3 pad 1, same dtype; per-problem channel counts, operands, prologue vectors and gradient buffers) in ONE launch (+ one reduction launch
+ * when the pixel tiles are split over several workgroups).  A DenseNet block's backward (torchvision _DenseBlock as used at
+ * /root/reference/models/models.py:306-313) defers the two weight gradients of each of its 6-24 layers to the end of the block: on the
+ * low-resolution blocks one layer's problem has 32-128 pixel tiles, and filling 256 CUs took 32-128 pixel groups each writing a full partial
+ * gradient; all layers together fill the chip with 2-8 groups.  dw[i] is complete on return; it is STORED when one workgroup owns the
+ * whole problem and ACCUMULATED (dw += sum of partials) otherwise, so hand in zeroed buffers.
+ * saunet_conv2d_wgrad_grouped_workspace: bytes of scratch the call needs (>= 0), or a negative saunet_status when the geometry is not
+ * served by the tiled kernels (the caller then issues saunet_conv2d_wgrad per problem). */
+#define SAUNET_WGRAD_GROUP_MAX 32
+typedef struct saunet_wgrad_group_item {
+    const void* x; const void* dy; float* dw; const float* pro_scale; const float* pro_shift;
+    int32_t Cin, ldx, Cout, lddy;
+} saunet_wgrad_group_item;
+typedef struct saunet_wgrad_group {
+    int32_t dtype, N, H, W, KH, pad, pro_relu, count;
+    saunet_wgrad_group_item item[SAUNET_WGRAD_GROUP_MAX];
+} saunet_wgrad_group;
+int64_t saunet_conv2d_wgrad_grouped_workspace(const saunet_wgrad_group* g);
+int saunet_conv2d_wgrad_grouped(const saunet_wgrad_group* g, void* workspace, int64_t workspace_bytes, void* stream);
 /* bytes of caller-owned scratch saunet_conv2d_wgrad needs for this shape (0 = none; <0 = saunet_status).
  * The tiled kernels write per-block partial gradients there with plain stores and reduce them afterwards
  * (cross-XCD float atomics on the same addresses are ~10x more expensive than the stores + one reduce pass). */
@@ -192,6 +212,13 @@ int saunet_bn_backward_coeff(int C, const double* sums, int sums_replicas, int s
                              float* dgamma, float* dbeta, int training, void* stream);
 int saunet_bn_backward_correct(int dtype, void* dx, int lddx, const void* x, int ldx, const float* A, const float* B,
                                const float* xhat_scale, const float* xhat_shift, int64_t pixels, int C, void* stream);
+/* `coeff` of one consumer (all C channels it normalises; training mode) and `correct` of the channel chunk [c_lo, c_hi) (<= 256 channels of
+ * those C) in ONE launch: inside a dense block's backward the two always follow each other.  A_in/B_in -> A_out/B_out are distinct
+ * (ping-pong) buffers; dx / x point at the chunk's first channel; xhat_scale / xhat_shift are indexed by absolute channel. */
+int saunet_bn_backward_coeff_correct(int dtype, int C, const double* sums, int sums_replicas, int sums_rstride, double count, const float* scale,
+                                     const float* A_in, const float* B_in, float* A_out, float* B_out, float* dgamma, float* dbeta,
+                                     void* dx, int lddx, const void* x, int ldx, int c_lo, int c_hi,
+                                     const float* xhat_scale, const float* xhat_shift, int64_t pixels, void* stream);
 
 /* ---- resampling / pooling ------------------------------------------------------------------
  * F.interpolate(mode='bilinear', align_corners=True) models/models.py:337-356,372-374,386-389;

@@ -30,6 +30,8 @@ constexpr bool kUnalignedTileWgrad = false;
 int tile_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw,
                void* ws, size_t ws_bytes, size_t* need, bool aligned, hipStream_t st, saunet_wgrad_pending* pend = nullptr);
 int wgrad_reduce_multi(const saunet_wgrad_reduce_list* l, hipStream_t st);
+bool tile_wgrad_grouped_supported(const saunet_wgrad_group* s);
+int tile_wgrad_grouped(const saunet_wgrad_group* s, void* ws, size_t ws_bytes, size_t* need, hipStream_t st);
 int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps, const float* psh,
                  void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st);
 
@@ -626,6 +628,18 @@ int saunet_conv2d_wgrad(const saunet_conv_desc* d, const void* x, const void* dy
                         void* workspace, int64_t workspace_bytes, void* stream)
 {
     return saunet_conv2d_wgrad_deferred(d, x, dy, ps, psh, dw, workspace, workspace_bytes, nullptr, stream);
+}
+
+int64_t saunet_conv2d_wgrad_grouped_workspace(const saunet_wgrad_group* g)
+{
+    size_t need = 0;
+    int rc = tile_wgrad_grouped(g, nullptr, 0, &need, nullptr);
+    return rc == SAUNET_OK ? (int64_t)need : (int64_t)rc;
+}
+
+int saunet_conv2d_wgrad_grouped(const saunet_wgrad_group* g, void* workspace, int64_t workspace_bytes, void* stream)
+{
+    return tile_wgrad_grouped(g, workspace, (size_t)workspace_bytes, nullptr, (hipStream_t)stream);
 }
 
 int saunet_wgrad_reduce_multi(const saunet_wgrad_reduce_list* l, void* stream)

@@ -822,8 +822,10 @@ template <typename T, bool ALIGNED> __device__ __forceinline__ u32x4 load_chunk(
     }
 }
 
+// body shared by the single-problem and the grouped launch: (gx, ngroups) = pixel-tile group of this block (tiles gx, gx + ngroups, ...; its
+// partial gradient goes to ws[gx]), by = channel tile
 template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KSPLIT, bool ALIGNED>
-__global__ __launch_bounds__(256, 2) void conv_tile_wgrad_kernel(TileWgradArgs a)
+__device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const int gx, const int ngroups, const int by, unsigned char* smem)
 {
     constexpr int EPC = 16 / sizeof(T);
     constexpr int PAD = KS / 2;
@@ -838,7 +840,6 @@ __global__ __launch_bounds__(256, 2) void conv_tile_wgrad_kernel(TileWgradArgs a
     constexpr int CHY = CO_T / EPC, CHX = CI_T / EPC;
     constexpr int YI = (NPY * CHY + 255) / 256, XI = (NPX * CHX + 255) / 256;
     constexpr int XB = XI > 6 ? (XI + 1) / 2 : XI;   // stage the halo in two batches when it is large (VGPR budget)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* s_y = smem;
     unsigned char* s_x = smem + NPY * PY;
 
@@ -847,7 +848,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_wgrad_kernel(TileWgradArgs a
     constexpr int CWAVES = (CO_T / WM) * (CI_T / WN);
     const int cwave = wave % CWAVES, kwave = wave / CWAVES;       // channel sub-tile / K (tile row) slice of this wave
     const int wm0 = (cwave / (CI_T / WN)) * WM, wn0 = (cwave % (CI_T / WN)) * WN;
-    const int cot = blockIdx.y / a.ncit, cit = blockIdx.y - cot * a.ncit;
+    const int cot = by / a.ncit, cit = by - cot * a.ncit;
     const int co0 = cot * CO_T, ci0 = cit * CI_T;
     const T* __restrict__ xg = (const T*)a.x;
     const T* __restrict__ dyg = (const T*)a.dy;
@@ -881,7 +882,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_wgrad_kernel(TileWgradArgs a
 
     TSTAMP_INIT();
     TSTAMP(20);
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = gx; tile < a.ntiles; tile += ngroups) {
         int bt = tile;
         const int txi = bt % a.tiles_x; bt /= a.tiles_x;
         const int tyi = bt % a.tiles_y; const int n = bt / a.tiles_y;
@@ -1020,11 +1021,46 @@ __global__ __launch_bounds__(256, 2) void conv_tile_wgrad_kernel(TileWgradArgs a
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         int co = co0 + wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (co < a.Cout && ci < a.Cin) a.ws[(size_t)blockIdx.x * a.wsize + (size_t)co * a.sM + (size_t)ci * a.sN + t] = acc[m][nn][t][r];
+                        if (co < a.Cout && ci < a.Cin) a.ws[(size_t)gx * a.wsize + (size_t)co * a.sM + (size_t)ci * a.sN + t] = acc[m][nn][t][r];
                     }
                 }
             }
         }
+}
+
+template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KSPLIT, bool ALIGNED>
+__global__ __launch_bounds__(256, 2) void conv_tile_wgrad_kernel(TileWgradArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    tile_wgrad_body<T, KS, TR, CO_T, CI_T, WM, WN, KSPLIT, ALIGNED>(a, blockIdx.x, gridDim.x, blockIdx.y, smem);
+}
+
+// ---- grouped launch: the weight gradients of up to SAUNET_WGRAD_GROUP_MAX convolutions of ONE geometry (same map, same kernel size; per-problem
+// channel counts, operands and prologue vectors) in one grid.  A DenseNet block's backward defers the two weight gradients of every layer to
+// the end of the block: on the low-resolution blocks a single layer's problem has 32-128 pixel tiles and needed 32-128 pixel groups to fill
+// the chip (each writing a full partial gradient: the partials outweighed the activations); all layers together fill it with 2-8 groups.
+struct GWItem { const void* x; const void* dy; float* dw; const float* ps; const float* psh; float* ws; int Cin, ldx, Cout, lddy, ncit, blk0; };
+struct GroupedWgradArgs {
+    int N, H, W, pro_relu, tiles_x, tiles_y, ntiles, groups, count, taps;
+    GWItem item[SAUNET_WGRAD_GROUP_MAX];
+};
+
+template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KSPLIT>
+__global__ __launch_bounds__(256, 2) void conv_tile_wgrad_grouped_kernel(GroupedWgradArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int p = 0;
+    while (p + 1 < g.count && (int)blockIdx.x >= g.item[p + 1].blk0) ++p;
+    const GWItem& it = g.item[p];
+    TileWgradArgs a;
+    a.x = it.x; a.dy = it.dy; a.dw = it.dw; a.pro_scale = it.ps; a.pro_shift = it.psh;
+    a.N = g.N; a.H = g.H; a.W = g.W; a.Cin = it.Cin; a.ldx = it.ldx; a.Cout = it.Cout; a.lddy = it.lddy; a.pro_relu = g.pro_relu;
+    a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.ntiles = g.ntiles; a.ncit = it.ncit;
+    a.sM = (long)it.Cin * g.taps; a.sN = g.taps;
+    a.ws = it.ws; a.wsize = (long)it.Cout * it.Cin * g.taps; a.pend = nullptr;
+    const int local = (int)blockIdx.x - it.blk0;
+    const int by = local / g.groups, gx = local - by * g.groups;
+    tile_wgrad_body<T, KS, TR, CO_T, CI_T, WM, WN, KSPLIT, true>(a, gx, g.groups, by, smem);
 }
 
 // dw[i] += sum_g ws[g][i]; blockIdx.y takes a slice of the groups (atomics only between slices)
@@ -1154,6 +1190,107 @@ int wgrad_reduce_multi(const saunet_wgrad_reduce_list* l, hipStream_t st)
     hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)bx, l->count), dim3(256), 0, st, *l);
     SAUNET_CHECK_LAUNCH("wgrad_reduce_multi");
     return SAUNET_OK;
+}
+
+template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KSPLIT>
+static int launch_tile_wgrad_grouped(GroupedWgradArgs& g, const saunet_wgrad_group* src, void* ws, size_t ws_bytes, size_t* need, hipStream_t st)
+{
+    constexpr int PAD = KS / 2;
+    constexpr int NPX = (TR + 2 * PAD) * (TILE + 2 * PAD), NPY = TR * TILE;
+    constexpr int PY_RAW = CO_T * (int)sizeof(T), PX_RAW = CI_T * (int)sizeof(T);
+    constexpr int PY = sizeof(T) == 2 ? ((PY_RAW % 128 == 64) ? PY_RAW : PY_RAW + 64) : PY_RAW;
+    constexpr int PX = sizeof(T) == 2 ? ((PX_RAW % 128 == 64) ? PX_RAW : PX_RAW + 64) : PX_RAW;
+    constexpr int LDS_MAIN = NPY * PY + NPX * PX;
+    constexpr int LDS_RED = KSPLIT > 1 ? (KSPLIT - 1) * 16 * 64 * 4 : 0;
+    constexpr int LDS = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
+    auto kern = conv_tile_wgrad_grouped_kernel<T, KS, TR, CO_T, CI_T, WM, WN, KSPLIT>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    g.tiles_y = g.H / TR; g.tiles_x = g.W / TILE; g.ntiles = g.N * g.tiles_y * g.tiles_x;
+    long chan_tiles = 0, welems = 0;
+    for (int i = 0; i < g.count; ++i) {
+        g.item[i].ncit = cdiv(g.item[i].Cin, CI_T);
+        chan_tiles += (long)cdiv(g.item[i].Cout, CO_T) * g.item[i].ncit;
+        welems += (long)g.item[i].Cout * g.item[i].Cin * g.taps;
+    }
+    // pixel groups: fill the chip (two resident workgroups per CU) with as few partial gradients as possible
+    static const long target = getenv("SAUNET_WGRAD_GROUP_BLOCKS") ? atol(getenv("SAUNET_WGRAD_GROUP_BLOCKS")) : 640;
+    int groups = 1;
+    while (groups * 2 <= g.ntiles && chan_tiles * groups * 2 <= target) groups *= 2;
+    g.groups = groups;
+    const size_t bytes = groups > 1 ? (size_t)groups * welems * sizeof(float) : 0;
+    if (need) { *need = bytes; return SAUNET_OK; }
+    if (bytes && (ws == nullptr || ws_bytes < bytes)) return set_error(SAUNET_BAD_SHAPE, "grouped wgrad: workspace %zu < %zu bytes", ws_bytes, bytes);
+    long blk = 0; float* wsp = (float*)ws;
+    for (int i = 0; i < g.count; ++i) {
+        g.item[i].blk0 = (int)blk;
+        blk += (long)cdiv(g.item[i].Cout, CO_T) * g.item[i].ncit * groups;
+        const long wsize = (long)g.item[i].Cout * g.item[i].Cin * g.taps;
+        if (groups > 1) { g.item[i].ws = wsp; wsp += (size_t)groups * wsize; }
+        else g.item[i].ws = g.item[i].dw;            // one group: the block owns the whole problem and stores the gradient itself
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blk), dim3(256), LDS, st, g);
+    SAUNET_CHECK_LAUNCH("conv_tile_wgrad_grouped");
+    if (groups > 1) {
+        for (int i0 = 0; i0 < g.count; i0 += SAUNET_WGRAD_REDUCE_MAX) {
+            saunet_wgrad_reduce_list l; l.reserved = 0;
+            l.count = g.count - i0 < SAUNET_WGRAD_REDUCE_MAX ? g.count - i0 : SAUNET_WGRAD_REDUCE_MAX;
+            for (int i = 0; i < l.count; ++i) {
+                const GWItem& it = g.item[i0 + i];
+                l.item[i].ws = it.ws; l.item[i].dw = it.dw; l.item[i].wsize = (long)it.Cout * it.Cin * g.taps; l.item[i].groups = groups; l.item[i].reserved = 0;
+            }
+            if (int rc = wgrad_reduce_multi(&l, st)) return rc;
+        }
+    }
+    return SAUNET_OK;
+}
+
+bool tile_wgrad_grouped_supported(const saunet_wgrad_group* s)
+{
+    if (s->count < 1 || s->count > SAUNET_WGRAD_GROUP_MAX) return false;
+    if (s->dtype != SAUNET_BF16 && s->dtype != SAUNET_F32) return false;
+    const int epc = s->dtype == SAUNET_BF16 ? 8 : 4;
+    const long P = (long)s->N * s->H * s->W;
+    if (s->KH == 3) { if (s->pad != 1 || s->H % TILE || s->W % TILE) return false; }
+    else if (s->KH == 1) { if (s->pad != 0 || P % 256) return false; }
+    else return false;
+    for (int i = 0; i < s->count; ++i) {
+        const saunet_wgrad_group_item& it = s->item[i];
+        if (it.Cin % epc || it.Cout % epc || it.ldx % epc || it.lddy % epc || it.Cin < epc || it.Cout < 8) return false;
+        if (((uintptr_t)it.x | (uintptr_t)it.dy) & 15) return false;
+        if (!it.x || !it.dy || !it.dw) return false;
+    }
+    return true;
+}
+
+// need != nullptr: only compute the workspace size
+int tile_wgrad_grouped(const saunet_wgrad_group* s, void* ws, size_t ws_bytes, size_t* need, hipStream_t st)
+{
+    if (!tile_wgrad_grouped_supported(s)) return set_error(SAUNET_UNSUPPORTED, "grouped wgrad: geometry not on the tiled kernels");
+    GroupedWgradArgs g;
+    g.N = s->N; g.H = s->H; g.W = s->W; g.pro_relu = s->pro_relu; g.count = s->count; g.taps = s->KH * s->KH;
+    if (s->KH == 1) { g.N = (int)((long)s->N * s->H * s->W / 256); g.H = g.W = 16; }       // pixels are just rows for a 1x1 conv
+    bool small = true;
+    for (int i = 0; i < s->count; ++i) {
+        const saunet_wgrad_group_item& it = s->item[i];
+        g.item[i].x = it.x; g.item[i].dy = it.dy; g.item[i].dw = it.dw; g.item[i].ps = it.pro_scale; g.item[i].psh = it.pro_shift; g.item[i].ws = nullptr;
+        g.item[i].Cin = it.Cin; g.item[i].ldx = it.ldx; g.item[i].Cout = it.Cout; g.item[i].lddy = it.lddy; g.item[i].ncit = 0; g.item[i].blk0 = 0;
+        if ((long)it.Cout * it.Cin > 64 * 128) small = false;
+    }
+    for (int i = s->count; i < SAUNET_WGRAD_GROUP_MAX; ++i) g.item[i] = GWItem{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
+    if (s->dtype == SAUNET_BF16) {
+        if (s->KH == 3) {
+            if (small) return launch_tile_wgrad_grouped<u16, 3, 16, 32, 32, 32, 32, 4>(g, s, ws, ws_bytes, need, st);
+            return launch_tile_wgrad_grouped<u16, 3, 8, 64, 64, 32, 32, 1>(g, s, ws, ws_bytes, need, st);
+        }
+        if (small) return launch_tile_wgrad_grouped<u16, 1, 16, 64, 64, 64, 64, 4>(g, s, ws, ws_bytes, need, st);
+        return launch_tile_wgrad_grouped<u16, 1, 8, 128, 128, 64, 64, 1>(g, s, ws, ws_bytes, need, st);
+    }
+    if (s->KH == 3) {
+        if (small) return launch_tile_wgrad_grouped<float, 3, 16, 32, 32, 32, 32, 4>(g, s, ws, ws_bytes, need, st);
+        return launch_tile_wgrad_grouped<float, 3, 8, 64, 64, 32, 32, 1>(g, s, ws, ws_bytes, need, st);
+    }
+    return launch_tile_wgrad_grouped<float, 1, 8, 64, 64, 32, 32, 1>(g, s, ws, ws_bytes, need, st);
 }
 
 int tile_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw,

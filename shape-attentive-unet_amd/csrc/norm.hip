@@ -385,6 +385,58 @@ __global__ __launch_bounds__(256) void bn_bwd_correct_kernel(T* __restrict__ dx,
     }
 }
 
+// bn_bwd_coeff + bn_bwd_correct of the NEXT chunk in one launch (training mode).  Inside a dense block's backward the coefficient kernel of
+// layer l is always followed by the correction of the gradient chunk that layer l-1 consumes: the chunk's A / B only need this layer's two sums
+// for those few channels, so every correcting block derives them itself (CW channels x replicas, one batched round trip) while the last
+// blocks of the grid do the coefficient update for all C channels.  A / B are ping-pong buffers (a correcting block must not read a value
+// the coefficient blocks have already updated).
+struct CoeffCorrectArgs {
+    int C; const double* sums; int reps, rstride; double count; const float* scale;
+    const float* A_in; const float* B_in; float* A_out; float* B_out; float* dgamma; float* dbeta;
+    void* dx; int lddx; const void* x; int ldx; int c_lo, CW; const float* xs; const float* xt; long P; long rpb; int nb_correct;
+};
+
+template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_coeff_correct_kernel(CoeffCorrectArgs a)
+{
+    if ((int)blockIdx.x >= a.nb_correct) {
+        const int c = ((int)blockIdx.x - a.nb_correct) * 256 + threadIdx.x;
+        if (c >= a.C) return;
+        const double s1 = rep_sum(a.sums, a.reps, a.rstride, c), s2 = rep_sum(a.sums, a.reps, a.rstride, a.C + c);
+        a.dbeta[c] = (float)s1; a.dgamma[c] = (float)s2;
+        const float sc = a.scale[c];
+        a.A_out[c] = a.A_in[c] + sc * (float)(s1 / a.count); a.B_out[c] = a.B_in[c] + sc * (float)(s2 / a.count);
+        return;
+    }
+    __shared__ float s_ab[4][256];
+    for (int t = threadIdx.x; t < a.CW; t += 256) {
+        const int c = a.c_lo + t;
+        const double s1 = rep_sum(a.sums, a.reps, a.rstride, c), s2 = rep_sum(a.sums, a.reps, a.rstride, a.C + c);
+        const float sc = a.scale[c];
+        s_ab[0][t] = a.A_in[c] + sc * (float)(s1 / a.count); s_ab[1][t] = a.B_in[c] + sc * (float)(s2 / a.count);
+        s_ab[2][t] = a.xs[c]; s_ab[3][t] = a.xt[c];
+    }
+    __syncthreads();
+    const long p0 = blockIdx.x * a.rpb, p1 = min(p0 + a.rpb, a.P);
+    const int CH = a.CW / V;
+    T* dx = (T*)a.dx; const T* x = (const T*)a.x;
+    for (int cb = 0; cb < CH; cb += 256) {
+        const int cw = min(256, CH - cb), rl = 256 / cw;
+        const int ch = cb + threadIdx.x % cw, r0 = threadIdx.x / cw;
+        if (r0 >= rl) continue;
+        float av[V], bv[V], sv[V], tv[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { av[j] = s_ab[0][ch * V + j]; bv[j] = s_ab[1][ch * V + j]; sv[j] = s_ab[2][ch * V + j]; tv[j] = s_ab[3][ch * V + j]; }
+        for (long p = p0 + r0; p < p1; p += rl) {
+            float d[V], xv[V];
+            ChunkIO<T, V>::load(dx + p * a.lddx + ch * V, d);
+            ChunkIO<T, V>::load(x + p * a.ldx + ch * V, xv);
+#pragma unroll
+            for (int j = 0; j < V; ++j) d[j] -= av[j] + bv[j] * fmaf(xv[j], sv[j], tv[j]);
+            ChunkIO<T, V>::store(dx + p * a.lddx + ch * V, d);
+        }
+    }
+}
+
 static inline long rows_per_block(long P, int C, int V, int* blocks)
 {
     // enough blocks to fill the chip, each with a few thousand elements per thread at most
@@ -527,6 +579,29 @@ int saunet_bn_backward_coeff(int C, const double* sums, int sums_replicas, int s
     hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, sums, sums_replicas < 1 ? 1 : sums_replicas, sums_rstride,
                        count, scale, A, B, dgamma, dbeta, training);
     SAUNET_CHECK_LAUNCH("bn_backward_coeff");
+    return SAUNET_OK;
+}
+
+int saunet_bn_backward_coeff_correct(int dtype, int C, const double* sums, int sums_replicas, int sums_rstride, double count, const float* scale,
+                                     const float* A_in, const float* B_in, float* A_out, float* B_out, float* dgamma, float* dbeta,
+                                     void* dx, int lddx, const void* x, int ldx, int c_lo, int c_hi,
+                                     const float* xhat_scale, const float* xhat_shift, int64_t pixels, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int CW = c_hi - c_lo;
+    if (C < 1 || c_lo < 0 || c_hi > C || CW < 1 || CW > 256) return set_error(SAUNET_BAD_SHAPE, "bn_backward_coeff_correct: chunk [%d, %d) of %d channels", c_lo, c_hi, C);
+    if (A_in == A_out || B_in == B_out) return set_error(SAUNET_BAD_SHAPE, "bn_backward_coeff_correct: A / B must be ping-pong buffers");
+    const bool vec = vec_ok(dtype, CW, {lddx, ldx}, {dx, x});
+    int blocks; const int V = vec ? (dtype == SAUNET_BF16 ? 8 : 4) : 1;
+    CoeffCorrectArgs a{C, sums, sums_replicas < 1 ? 1 : sums_replicas, sums_rstride, count, scale, A_in, B_in, A_out, B_out, dgamma, dbeta,
+                       dx, lddx, x, ldx, c_lo, CW, xhat_scale, xhat_shift, (long)pixels, 0, 0};
+    a.rpb = rows_per_block(pixels, CW, V, &blocks);
+    a.nb_correct = blocks;
+    const int total = blocks + (C + 255) / 256;
+#define CALL(TT, VV) hipLaunchKernelGGL((bn_bwd_coeff_correct_kernel<TT, VV>), dim3(total), dim3(256), 0, st, a)
+    DISPATCH_TV(dtype, vec, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("bn_backward_coeff_correct");
     return SAUNET_OK;
 }
 

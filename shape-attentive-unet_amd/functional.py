@@ -441,6 +441,43 @@ def flush_wgrad_reductions(pending):
     del pending[:]
 
 
+DENSE_WGRAD_GROUPED = os.environ.get("SAUNET_DENSE_WGRAD_GROUPED", "1") != "0"   # A/B switch: per-layer weight-gradient launches when "0"
+DENSE_COEFF_CORRECT = os.environ.get("SAUNET_DENSE_COEFF_CORRECT", "1") != "0"   # A/B switch: separate coeff / correct launches when "0"
+
+
+def conv_wgrad_grouped(problems, ksize, pad, pro_relu):
+    """Weight gradients of several stride-1 convolutions over the SAME map geometry in ONE launch (saunet_conv2d_wgrad_grouped).
+    problems: list of (x, dy, weight, (pro_scale, pro_shift) or None).  Returns the list of gradients, or None when the geometry is not
+    served by the tiled kernels (the caller then falls back to one conv_wgrad_raw per problem)."""
+    if not problems:
+        return []
+    x0 = nhwc(problems[0][0])
+    out = []
+    for i0 in range(0, len(problems), L.WGRAD_GROUP_MAX):
+        chunk = problems[i0:i0 + L.WGRAD_GROUP_MAX]
+        g = L.WgradGroup()
+        g.dtype, g.N, g.H, g.W = L.dtype_code(x0), x0.shape[0], x0.shape[2], x0.shape[3]
+        g.KH, g.pad, g.pro_relu, g.count = ksize, pad, 1 if pro_relu else 0, len(chunk)
+        dws, keep = [], []
+        for i, (x, dy, weight, pro) in enumerate(chunk):
+            x = nhwc(x); dy = nhwc(dy)
+            dw = GRADS.take(weight.numel(), x.device).view(weight.shape)
+            it = g.item[i]
+            it.x, it.dy, it.dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
+            it.pro_scale, it.pro_shift = (pro[0].data_ptr(), pro[1].data_ptr()) if pro is not None else (None, None)
+            it.Cin, it.ldx, it.Cout, it.lddy = x.shape[1], ld_of(x), dy.shape[1], ld_of(dy)
+            dws.append(dw); keep.append((x, dy))
+        need = L.load().saunet_conv2d_wgrad_grouped_workspace(C.byref(g))
+        if need < 0:
+            if out:
+                raise RuntimeError("grouped weight gradient: chunk %d of one geometry is unsupported (%d)" % (i0, need))
+            return None
+        ws = torch.empty(max(need, 4) // 4, dtype=torch.float32, device=x0.device)
+        L.call("saunet_conv2d_wgrad_grouped", C.byref(g), ws.data_ptr(), need, L.stream())
+        out += dws
+    return out
+
+
 def _conv_wgrad_impl(x, dy, weight, stride, pad, transposed=False, pro=None, pending=None):
     if transposed and pro is None and weight.shape[2:] == (4, 4) and weight.shape[1] % 8 == 0 and weight.shape[0] % 8 == 0:
         # ConvTranspose2d(k=4, s=2, p=1):  dW[ci][co][kh][kw] = sum x[n,ih,iw,ci] * dy[n, 2ih-1+kh, 2iw-1+kw, co]  is the weight
@@ -1518,7 +1555,10 @@ class _DenseBlock(torch.autograd.Function):
         dt = L.dtype_code(buf)
         # "linear" BN backward: every consumer adds s*g into dbuf from its dgrad epilogue; the -(A + B*xhat) terms
         # are accumulated per channel and applied ONCE per 32-channel chunk right before that chunk is consumed
-        AB = torch.zeros(2, ctot, dtype=torch.float32, device=dev)
+        # two (A, B) pairs: saunet_bn_backward_coeff_correct reads one and writes the other (ping-pong)
+        ABB = GRADS.take(4 * ctot, dev).view(2, 2, ctot) if buf.is_cuda else torch.zeros(2, 2, ctot, dtype=torch.float32, device=dev)
+        AB = ABB[0]
+        merged = training and DENSE_COEFF_CORRECT and buf.is_cuda      # coeff of layer l + correct of chunk l-1 in one launch
 
         def correct(lo, hi):
             if training:
@@ -1535,6 +1575,10 @@ class _DenseBlock(torch.autograd.Function):
         defer = buf.is_cuda and DENSE_WGRAD_DEFER == "1" and not torch.cuda.is_current_stream_capturing()
         deferred = []
         pend = [] if (buf.is_cuda and DENSE_WGRAD_BATCH_REDUCE and not WGRAD_SIDE.enabled) else None   # the 2 x L partial-gradient reductions: one launch
+        # default: both weight gradients of every layer are deferred to the end of the block and issued as two GROUPED launches (every layer's
+        # dz1 / corrected gradient chunk stays alive until then: 24 x 8 MB at block 3 -- nothing against 288 GB)
+        grouped = buf.is_cuda and DENSE_WGRAD_GROUPED and not defer and not WGRAD_SIDE.enabled
+        wg1, wg2 = [], []
         for l in reversed(range(nl)):
             n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
             z1, p1b, p2b = saved[3 * l:3 * l + 3]
@@ -1542,14 +1586,21 @@ class _DenseBlock(torch.autograd.Function):
             p2 = BNParams.__new__(BNParams); p2.buf = p2b
             cin = c0 + growth * l
             xin = buf[:, :cin]
-            correct(cin, cin + growth)
+            if not merged:
+                correct(cin, cin + growth)       # (merged: done by the previous iteration's coeff launch; the last chunk has no consumer in the block)
             dz2 = dbuf[:, cin:cin + growth]
-            if not defer:
+            if grouped:
+                wg2.append((l, z1, dz2, c2w, (p2.scale, p2.shift)))
+                dw2 = None
+            elif not defer:
                 dw2 = conv_wgrad_raw(z1, dz2, c2w, 1, 1, pro=(p2.scale, p2.shift, True), pending=pend)
             s2 = new_stats(z1.shape[1], dev)
             da2 = conv_dgrad_raw(dz2, c2w, z1.shape, 1, 1, bn_epi=(z1, p2, True, s2))
             dz1, _, dg2, db2 = bn_backward(da2, z1, p2, True, count, training, dx=da2, presums=s2)
-            if not defer:
+            if grouped:
+                wg1.append((l, xin, dz1, c1w, (p1.scale, p1.shift)))
+                dw1 = None
+            elif not defer:
                 dw1 = conv_wgrad_raw(xin, dz1, c1w, 1, 0, pro=(p1.scale, p1.shift, True), pending=pend)
             else:
                 dw1 = dw2 = None
@@ -1557,8 +1608,17 @@ class _DenseBlock(torch.autograd.Function):
             s1 = new_stats(cin, dev)
             conv_dgrad_raw(dz1, c1w, (n, cin, h, w), 1, 0, out=dbuf[:, :cin], bn_epi=(xin, p1, True, s1, True))
             dgb = torch.empty(2, cin, dtype=torch.float32, device=dev)
-            L.call("saunet_bn_backward_coeff", cin, s1.data_ptr(), s1.shape[0], s1.stride(0), float(count), p1.scale.data_ptr(), AB[0].data_ptr(), AB[1].data_ptr(),
-                   dgb[0].data_ptr(), dgb[1].data_ptr(), 1 if training else 0, L.stream())
+            if merged and l > 0:
+                nxt = ABB[1] if AB.data_ptr() == ABB[0].data_ptr() else ABB[0]
+                lo = cin - growth
+                d_, x_ = dbuf[:, lo:cin], buf[:, lo:cin]
+                L.call("saunet_bn_backward_coeff_correct", dt, cin, s1.data_ptr(), s1.shape[0], s1.stride(0), float(count), p1.scale.data_ptr(),
+                       AB[0].data_ptr(), AB[1].data_ptr(), nxt[0].data_ptr(), nxt[1].data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
+                       d_.data_ptr(), ld_of(d_), x_.data_ptr(), ld_of(x_), lo, cin, xh[0].data_ptr(), xh[1].data_ptr(), P, L.stream())
+                AB = nxt
+            else:
+                L.call("saunet_bn_backward_coeff", cin, s1.data_ptr(), s1.shape[0], s1.stride(0), float(count), p1.scale.data_ptr(), AB[0].data_ptr(), AB[1].data_ptr(),
+                       dgb[0].data_ptr(), dgb[1].data_ptr(), 1 if training else 0, L.stream())
             grads[6 * l:6 * l + 6] = [dgb[0], dgb[1], dw1, dg2, db2, dw2]
         if defer:
             main = torch.cuda.current_stream(dev)
@@ -1572,6 +1632,13 @@ class _DenseBlock(torch.autograd.Function):
                         t.record_stream(side)
             buf.record_stream(side); dbuf.record_stream(side)
             WGRAD_SIDE.mark()
+        if grouped:
+            for plist, slot, ks, pd in ((wg2, 5, 3, 1), (wg1, 2, 1, 0)):
+                dws = conv_wgrad_grouped([(x_, dy_, w_, pro_) for (_l, x_, dy_, w_, pro_) in plist], ks, pd, True)
+                if dws is None:        # geometry off the tiled kernels (maps that are not multiples of the 16-pixel tile): per-layer launches
+                    dws = [conv_wgrad_raw(x_, dy_, w_, 1, pd, pro=(pro_[0], pro_[1], True), pending=pend) for (_l, x_, dy_, w_, pro_) in plist]
+                for (l_, *_rest), dw_ in zip(plist, dws):
+                    grads[6 * l_ + slot] = dw_
         if pend:
             flush_wgrad_reductions(pend)
         correct(0, c0)

@@ -56,6 +56,18 @@ class WgradReduceList(C.Structure):
     _fields_ = [("count", C.c_int32), ("reserved", C.c_int32), ("item", WgradPending * WGRAD_REDUCE_MAX)]
 
 
+WGRAD_GROUP_MAX = 32
+
+
+class WgradGroupItem(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("pro_scale", C.c_void_p), ("pro_shift", C.c_void_p),
+                ("Cin", C.c_int32), ("ldx", C.c_int32), ("Cout", C.c_int32), ("lddy", C.c_int32)]
+
+
+class WgradGroup(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in "dtype N H W KH pad pro_relu count".split()] + [("item", WgradGroupItem * WGRAD_GROUP_MAX)]
+
+
 class TensorList(C.Structure):
     _fields_ = [("count", C.c_int32), ("ptrs", (C.c_void_p * 96) * 4), ("numel", C.c_int64 * 96)]
 
@@ -72,6 +84,8 @@ _SIGS = {
     "saunet_conv2d_wgrad_workspace": [C.POINTER(ConvDesc)],
     "saunet_conv2d_wgrad_deferred": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i64, C.POINTER(WgradPending), vp],
     "saunet_wgrad_reduce_multi": [C.POINTER(WgradReduceList), vp],
+    "saunet_conv2d_wgrad_grouped_workspace": [C.POINTER(WgradGroup)],
+    "saunet_conv2d_wgrad_grouped": [C.POINTER(WgradGroup), vp, i64, vp],
     "saunet_channel_sum": [i32, vp, i64, i32, i32, vp, vp],
     "saunet_bn_stats": [i32, vp, i64, i32, i32, vp, vp, i32, i32, vp],
     "saunet_sum_replicas": [vp, i32, i32, i32, vp],
@@ -84,6 +98,7 @@ _SIGS = {
                                  vp, i32, vp, i32, vp, vp, i64, i32, vp],
     "saunet_bn_backward_coeff": [i32, vp, i32, i32, f64, vp, vp, vp, vp, vp, i32, vp],
     "saunet_bn_backward_correct": [i32, vp, i32, vp, i32, vp, vp, vp, vp, i64, i32, vp],
+    "saunet_bn_backward_coeff_correct": [i32, i32, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp, vp, i64, vp],
     "saunet_bilinear_forward": [i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp],
     "saunet_bilinear_backward": [i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp],
     "saunet_im2col": [i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp],

@@ -146,3 +146,49 @@ def test_whole_network_with_the_persistent_block_forward():
     num = sum(float((ga[k] * gb[k]).sum()) for k in ga)
     den = (sum(float(ga[k].pow(2).sum()) for k in ga) * sum(float(gb[k].pow(2).sum()) for k in gb)) ** 0.5
     assert num / den > 0.98, num / den
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ksize,shape,chans", [(1, (4, 16, 16), [(64, 128), (96, 128), (160, 128), (288, 128)]),      # conv1 of a block: growing Cin
+                                               (3, (4, 32, 32), [(128, 32)] * 5),                                      # conv2 of a block
+                                               (1, (8, 32, 32), [(64, 32), (32, 32)]),                                 # "small" 1x1 configuration
+                                               (3, (2, 16, 48), [(64, 64), (128, 96)])])                               # larger 3x3 tiles, non-square map
+def test_grouped_weight_gradients_match_the_per_problem_launches(dtype, ksize, shape, chans):
+    """saunet_conv2d_wgrad_grouped (all weight gradients of a dense block in one launch) against saunet_conv2d_wgrad per problem and a float64
+    torch reference: operands are channel SLICES of wider buffers, every problem has its own BN+ReLU prologue."""
+    import saunet_amd as S
+    HF = S.functional
+    n, h, w = shape
+    torch.manual_seed(ksize * 1000 + len(chans))
+    pad = ksize // 2
+    wide = max(c for c, _ in chans) + 32
+    buf = torch.randn(n, wide, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    problems, refs = [], []
+    for cin, cout in chans:
+        dyw = torch.randn(n, cout + 16, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+        x, dy = buf[:, :cin], dyw[:, 16:]
+        weight = torch.nn.Parameter(torch.empty(cout, cin, ksize, ksize, device="cuda"))
+        sc = torch.empty(cin, device="cuda").uniform_(0.5, 1.5); sh = torch.empty(cin, device="cuda").uniform_(-0.5, 0.5)
+        problems.append((x, dy, weight, (sc, sh)))
+        a = torch.relu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+        refs.append(torch.nn.grad.conv2d_weight(a, weight.shape, dy.double(), padding=pad))
+    HF.GRADS.reset()
+    got = HF.conv_wgrad_grouped(problems, ksize, pad, True)
+    assert got is not None
+    single = [HF.conv_wgrad_raw(x, dy, wt, 1, pad, pro=(p[0], p[1], True)) for (x, dy, wt, p) in problems]
+    torch.cuda.synchronize()
+    tol = 2e-5 if dtype == torch.float32 else 2e-3      # bf16: the prologue output is rounded to bf16 before the MFMA in both paths
+    for g, s, r in zip(got, single, refs):
+        assert rel(g, r) < (1e-4 if dtype == torch.float32 else 1e-2), rel(g, r)
+        assert rel(g, s) < tol, rel(g, s)
+
+
+def test_grouped_weight_gradients_refuse_untiled_maps():
+    """maps that are not multiples of the 16-pixel tile are not served by the grouped launch: the wrapper reports it (None) and the dense
+    block falls back to per-layer launches (covered by test_dense_block_fwd_bwd's 16 x 48 / small cases through the whole block)"""
+    import saunet_amd as S
+    HF = S.functional
+    x = torch.randn(2, 32, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(2, 32, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
+    wt = torch.nn.Parameter(torch.empty(32, 32, 3, 3, device="cuda"))
+    assert HF.conv_wgrad_grouped([(x, dy, wt, None)], 3, 1, False) is None
