@@ -85,6 +85,30 @@ typedef struct saunet_bn_epilogue {
 int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                              const float* pro_scale, const float* pro_shift, void* y,
                              double* stat_sum, double* stat_sumsq, const saunet_bn_epilogue* epi, void* stream);
+/* Consumer-side BatchNorm finalize: y = conv(relu?(BN(x)), w) where the BatchNorm coefficients are derived INSIDE the convolution kernel from
+ * the raw batch statistics its producer accumulated -- no saunet_bn_finalize launch in between (a DenseNet layer is then two launches
+ * instead of four; torchvision _DenseLayer norm1/norm2 as used at /root/reference/models/models.py:306-313).
+ *   channels [c_lo, Cin): mean / variance from (sum, sumsq, count) exactly as saunet_bn_finalize computes them (float64), and -- by one
+ *       workgroup -- written to xhat (rows xs = invstd, xt = -mean*invstd, mean, invstd, biased variance) for later consumers of the same
+ *       channels (a dense block's concat channels are normalised by up to 24 later norm1 layers: same statistics, different gamma / beta);
+ *   channels [0, c_lo): read from xhat.
+ * One workgroup also writes what saunet_bn_finalize would have returned -- params [4][Cin] = scale, shift, mean, invstd (the backward pass
+ * needs them) -- and updates running_mean / running_var (momentum, unbiased variance) for all Cin channels.  Training mode only. */
+typedef struct saunet_bn_prologue {
+    const double* sum; const double* sumsq;    /* accumulators indexed by input channel, replicated like saunet_conv_desc.stat_* */
+    int32_t replicas, rstride;
+    double count;
+    float eps, momentum;
+    int32_t c_lo, ld_xhat;
+    float* xhat;                                /* [5][ld_xhat]; may be NULL when c_lo == 0 and nobody else needs the rows */
+    const float* gamma; const float* beta;      /* [Cin] */
+    float* params;                              /* [4][Cin] out */
+    float* running_mean; float* running_var;    /* [Cin] in/out, may be NULL */
+} saunet_bn_prologue;
+int saunet_conv2d_forward_bnpro(const saunet_conv_desc* d, const void* x, const void* w_packed, const float* bias,
+                                const saunet_bn_prologue* pro, void* y, double* stat_sum, double* stat_sumsq, void* stream);
+/* the xhat rows of C channels from their statistics (the channels a dense block starts with): xhat[5][ld] as above */
+int saunet_bn_xhat(int C, const double* sum, const double* sumsq, int replicas, int rstride, double count, float eps, float* xhat, int ld, void* stream);
 /* dw[...] += sum_pixels dy (x) prologue(x).  dw is the float32 gradient in the PARAMETER's own
  * layout ([Co,Ci,kh,kw], or [Ci,Co,4,4] when d->transposed); it must be zero-initialised by the
  * caller (split-K partial sums are added atomically).  replaces autograd's convolution_backward

@@ -125,6 +125,73 @@ struct FastDiv {
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// sum over the replicated accumulators (saunet_bn_epilogue.sums_replicas): 8 loads in flight at a time -- these are pure latency chains
+// (one thread per channel), a one-load-per-iteration loop costs 16 memory round trips
+__device__ __forceinline__ double rep_sum(const double* __restrict__ s, int reps, int rstride, int i)
+{
+    double v = 0.0;
+    int r = 0;
+    for (; r + 8 <= reps; r += 8) {
+        double t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = s[(size_t)(r + j) * rstride + i];
+        v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    for (; r < reps; ++r) v += s[(size_t)r * rstride + i];
+    return v;
+}
+
+// the same for the (sum, sum of squares) pair of one channel: both accumulators' replicas travel together (two round trips, not four)
+__device__ __forceinline__ void rep_sum2(const double* __restrict__ a, const double* __restrict__ b, int reps, int rstride, int i, double& sa, double& sb)
+{
+    double va = 0.0, vb = 0.0;
+    int r = 0;
+    for (; r + 8 <= reps; r += 8) {
+        double t[8], u[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { t[j] = a[(size_t)(r + j) * rstride + i]; u[j] = b[(size_t)(r + j) * rstride + i]; }
+        va += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        vb += ((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]));
+    }
+    for (; r < reps; ++r) { va += a[(size_t)r * rstride + i]; vb += b[(size_t)r * rstride + i]; }
+    sa = va; sb = vb;
+}
+
+// Consumer-side BatchNorm finalize (saunet_bn_prologue): fills s_pro[0 .. cpad) = scale and s_pro[cpad .. 2*cpad) = shift of the input
+// channels (zero beyond Cin) with the arithmetic of bn_finalize_kernel; `writer` (one workgroup of the launch) also publishes the xhat rows
+// of the channels finalised here, the [4][Cin] parameter block the backward pass reads and the running statistics.
+template <int NT> __device__ __forceinline__ void bn_prologue_fill(const saunet_bn_prologue& p, int Cin, int cpad, float* s_pro, bool writer)
+{
+    for (int c = threadIdx.x; c < cpad; c += NT) {
+        float sc = 0.f, sh = 0.f;
+        if (c < Cin) {
+            float mean, is, var;
+            if (c >= p.c_lo) {
+                double s1, s2;
+                rep_sum2(p.sum, p.sumsq, p.replicas, p.rstride, c, s1, s2);
+                const double m = s1 / p.count;
+                double v = s2 / p.count - m * m;
+                if (v < 0.0) v = 0.0;
+                mean = (float)m; is = (float)(1.0 / sqrt(v + (double)p.eps)); var = (float)v;
+                if (writer && p.xhat) {
+                    p.xhat[c] = is; p.xhat[p.ld_xhat + c] = -mean * is; p.xhat[2 * p.ld_xhat + c] = mean; p.xhat[3 * p.ld_xhat + c] = is;
+                    p.xhat[4 * p.ld_xhat + c] = var;
+                }
+            } else { mean = p.xhat[2 * p.ld_xhat + c]; is = p.xhat[3 * p.ld_xhat + c]; var = p.xhat[4 * p.ld_xhat + c]; }
+            sc = p.gamma[c] * is; sh = p.beta[c] - mean * sc;
+            if (writer) {
+                p.params[c] = sc; p.params[Cin + c] = sh; p.params[2 * Cin + c] = mean; p.params[3 * Cin + c] = is;
+                if (p.running_mean) {
+                    const double unb = p.count > 1.0 ? (double)var * p.count / (p.count - 1.0) : (double)var;
+                    p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
+                    p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unb;
+                }
+            }
+        }
+        s_pro[c] = sc; s_pro[cpad + c] = sh;
+    }
+}
+
 // ---- phase timing (profiling builds only: python -m saunet_amd._build --timing -> scripts/_ab/libsaunet_timing.so) -------------------
 // TSTAMP(slot) records (slot, s_memtime) from thread 0 of ONE block into a per-translation-unit device array that
 // saunet_debug_timing_<unit>() copies out; scripts/phase_timing.py prints the per-phase cycle deltas.  This is how the serialised

@@ -19,7 +19,7 @@ bool dense_dgrad3_supported(const saunet_conv_desc* d, const float* bias, const 
 int dense_dgrad3_forward(const saunet_conv_desc* d, const void* x, const void* w, void* y, const saunet_bn_epilogue* epi, hipStream_t st);
 bool igemm_supported(const saunet_conv_desc* d);
 int igemm_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps, const float* psh,
-                  void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st);
+                  void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st, const saunet_bn_prologue* bnp = nullptr);
 int igemm_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw, hipStream_t st);
 bool tile_fwd_supported(const saunet_conv_desc* d);
 bool tile_wgrad_supported(const saunet_conv_desc* d);
@@ -33,7 +33,8 @@ int wgrad_reduce_multi(const saunet_wgrad_reduce_list* l, hipStream_t st);
 bool tile_wgrad_grouped_supported(const saunet_wgrad_group* s);
 int tile_wgrad_grouped(const saunet_wgrad_group* s, void* ws, size_t ws_bytes, size_t* need, hipStream_t st);
 int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps, const float* psh,
-                 void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st);
+                 void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st, const saunet_bn_prologue* bnp = nullptr);
+int bn_prologue_finalize(const saunet_bn_prologue* p, int Cin, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------- packing
 template <typename T>
@@ -605,6 +606,29 @@ int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const voi
     else return set_error(SAUNET_BAD_DTYPE, "conv: dtype %d", d->dtype);
     SAUNET_CHECK_LAUNCH("pointwise_fwd");
     return SAUNET_OK;
+}
+
+int saunet_conv2d_forward_bnpro(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const saunet_bn_prologue* pro,
+                                void* y, double* ssum, double* ssq, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!pro || !pro->gamma || !pro->beta || !pro->params || !pro->sum || !pro->sumsq || pro->count < 1.0 || pro->c_lo < 0 || pro->c_lo > d->Cin ||
+        (pro->c_lo > 0 && (!pro->xhat || pro->ld_xhat < d->Cin)) || (pro->running_mean == nullptr) != (pro->running_var == nullptr))
+        return set_error(SAUNET_BAD_SHAPE, "conv_bnpro: incomplete BatchNorm prologue descriptor");
+    if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->ldx < d->Cin || d->ldy < d->Cout)
+        return set_error(SAUNET_BAD_SHAPE, "conv: bad shape N=%d Cin=%d ldx=%d Cout=%d ldy=%d", d->N, d->Cin, d->ldx, d->Cout, d->ldy);
+    saunet_bn_prologue p = *pro;
+    if (p.replicas < 1) p.replicas = 1;
+    static const bool fuse = !(getenv("SAUNET_BNPRO_FUSED") && getenv("SAUNET_BNPRO_FUSED")[0] == '0');      // A/B switch
+    if (fuse && !d->transposed && igemm_supported(d)) {
+        int ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+        if (ho != d->Ho || wo != d->Wo) return set_error(SAUNET_BAD_SHAPE, "conv: Ho/Wo %dx%d != %dx%d", d->Ho, d->Wo, ho, wo);
+        if (tile_fwd_supported(d)) return tile_forward(d, x, w, bias, nullptr, nullptr, y, ssum, ssq, nullptr, st, &p);
+        return igemm_forward(d, x, w, bias, nullptr, nullptr, y, ssum, ssq, nullptr, st, &p);
+    }
+    // kernels that take ready-made coefficients: finalise with one small launch, then the ordinary forward
+    if (int rc = bn_prologue_finalize(&p, d->Cin, st)) return rc;
+    return saunet_conv2d_forward_ex(d, x, w, bias, p.params, p.params + d->Cin, y, ssum, ssq, nullptr, stream);
 }
 
 int64_t saunet_conv2d_wgrad_workspace(const saunet_conv_desc* d)

@@ -29,6 +29,7 @@ struct IgemmArgs {
     int Mh, Mw;       // row decode: m -> (n, q, r) with q < Mh, r < Mw
     int kpt;          // K-steps per tap = ceil(Cin / KC)
     saunet_bn_epilogue epi;   // epi.bn_x == nullptr: plain store
+    saunet_bn_prologue bnp;   // bnp.gamma != nullptr: the prologue coefficients are derived in the kernel from the producer's statistics
 };
 
 template <typename T> struct Mma;
@@ -94,7 +95,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void conv_igemm_fwd_
         } else { rbase[i] = 0; rih[i] = -(1 << 28); riw[i] = -(1 << 28); }
     }
     const int sgn = a.transposed ? -1 : 1;
-    const bool has_pro = a.pro_scale != nullptr;
+    const bool has_pro = a.pro_scale != nullptr || a.bnp.gamma != nullptr;
 
     const int nk = taps * a.kpt;
     const float relu_lo = a.pro_relu ? 0.f : -__builtin_inff();
@@ -103,10 +104,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void conv_igemm_fwd_
     // every commit).  LDS reads retire on lgkmcnt.
     float* s_pro = (float*)(smem + 2 * STAGE);
     const int cpad = a.kpt * KC;
-    if (has_pro) {
-        for (int i = tid; i < cpad; i += NT) { s_pro[i] = i < a.Cin ? a.pro_scale[i] : 0.f; s_pro[cpad + i] = i < a.Cin ? a.pro_shift[i] : 0.f; }
-        __syncthreads();
-    }
 
     // Two register stages: the loads of K-step k+2 are issued before the MFMAs of step k, and only converted
     // (BN+ReLU prologue, zero padding) and written to LDS after the MFMAs of step k+1 -- a load has two MFMA phases to land.
@@ -205,6 +202,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void conv_igemm_fwd_
     TSTAMP_INIT();
     TSTAMP(60);
     issue(S0);
+    // the prologue vectors are fetched BEHIND the first operand loads: their round trip (two dependent ones to the statistic replicas with a
+    // consumer-side BatchNorm finalize) overlaps the operands' instead of preceding it
+    if (a.bnp.gamma != nullptr) {
+        bn_prologue_fill<NT>(a.bnp, a.Cin, cpad, s_pro, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
+        __syncthreads();
+    } else if (has_pro) {
+        for (int i = tid; i < cpad; i += NT) { s_pro[i] = i < a.Cin ? a.pro_scale[i] : 0.f; s_pro[cpad + i] = i < a.Cin ? a.pro_shift[i] : 0.f; }
+        __syncthreads();
+    }
     commit(S0, 0);
     __syncthreads();
     if (nk > 1) issue(S0);                       // step 1 in flight
@@ -353,7 +359,7 @@ static int launch_fwd_i(const IgemmArgs& a, int phases, hipStream_t st)
     constexpr int STAGE = (BM + BN) * CPR * 16;
     constexpr int EPI = BM * BN * (int)sizeof(T) + 2 * BN * 4;
     constexpr int EPC_ = 16 / (int)sizeof(T);
-    const int pro_bytes = a.pro_scale ? 2 * a.kpt * CPR * EPC_ * 4 : 0;      // prologue scale/shift vectors behind the two stages
+    const int pro_bytes = (a.pro_scale || a.bnp.gamma) ? 2 * a.kpt * CPR * EPC_ * 4 : 0;      // prologue scale/shift vectors behind the two stages
     const int LDS = (2 * STAGE + pro_bytes > EPI) ? 2 * STAGE + pro_bytes : EPI;
     auto kern = conv_igemm_fwd_kernel<T, BM, BN, WM, WN, CPR, BNEPI>;
     static int attr_lds = 0;
@@ -400,9 +406,10 @@ bool igemm_supported(const saunet_conv_desc* d)
 }
 
 int igemm_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps,
-                  const float* psh, void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st)
+                  const float* psh, void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st, const saunet_bn_prologue* bnp)
 {
     IgemmArgs a;
+    if (bnp) a.bnp = *bnp; else a.bnp.gamma = nullptr;
     if (epi) { a.epi = *epi; if (a.epi.sums_replicas < 1) a.epi.sums_replicas = 1; } else a.epi.bn_x = nullptr;
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.pro_scale = ps; a.pro_shift = psh; a.stat_sum = ssum; a.stat_sumsq = ssq;
     a.stat_replicas = d->stat_replicas > 1 ? d->stat_replicas : 1; a.stat_rstride = d->stat_rstride;

@@ -24,6 +24,7 @@ struct TileArgs {
     int tiles_x, tiles_y;   // H/16, W/16
     saunet_bn_epilogue epi;
     int lds_acc_off;        // resident kernel: byte offset of the block-lifetime accumulators in LDS
+    saunet_bn_prologue bnp; // bnp.gamma != nullptr: the prologue coefficients are derived in the kernel (resident kernel only)
 };
 
 template <typename T> struct MmaT;
@@ -393,7 +394,7 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
     const int ntile = a.tiles_x * a.tiles_y * a.N;
     const int nnt = (a.Cout + BN - 1) / BN;
     const T* __restrict__ wg = (const T*)a.w;
-    const bool has_pro = a.pro_scale != nullptr;
+    const bool has_pro = a.pro_scale != nullptr || a.bnp.gamma != nullptr;
     const float relu_lo = a.pro_relu ? 0.f : -__builtin_inff();
     const int chunk = tid % CPR;
 
@@ -410,10 +411,8 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
     // loop: vmcnt retires in order, so waiting for a scale/shift load issued after the halo prefetch drains the whole prefetch queue
     // (s_waitcnt vmcnt(0) right before the commit -- the prefetch then overlaps nothing).  LDS reads count on lgkmcnt instead.
     float* s_pro = s_acc + 2 * BN;                       // [2][ncb * KC]
-    if (has_pro) {
-        const int cpad = ncb * KC;
-        for (int i = tid; i < cpad; i += NT) { s_pro[i] = i < a.Cin ? a.pro_scale[i] : 0.f; s_pro[cpad + i] = i < a.Cin ? a.pro_shift[i] : 0.f; }
-    }
+    // (filled further down, behind the weight copy and the first halo prefetches: the fill's own loads -- with a consumer-side BatchNorm finalize
+    // two dependent round trips to the statistic replicas -- then overlap those instead of delaying them)
     auto flush_acc = [&](int nt) {
         __syncthreads();
         const int n0f = nt * BN;
@@ -554,6 +553,11 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
             }
         }
         cur_nt = it0 / ntile;
+    }
+    if (a.bnp.gamma != nullptr) bn_prologue_fill<NT>(a.bnp, a.Cin, ncb * KC, s_pro, blockIdx.x == 0);
+    else if (has_pro) {
+        const int cpad = ncb * KC;
+        for (int i = tid; i < cpad; i += NT) { s_pro[i] = i < a.Cin ? a.pro_scale[i] : 0.f; s_pro[cpad + i] = i < a.Cin ? a.pro_shift[i] : 0.f; }
     }
 
     // Compute cursor (the unit whose MFMAs run): advanced incrementally like the prefetch cursor.
@@ -766,10 +770,13 @@ bool tile_fwd_supported(const saunet_conv_desc* d)
            d->Ho == d->H && d->Wo == d->W;
 }
 
+int bn_prologue_finalize(const saunet_bn_prologue* p, int Cin, hipStream_t st);
+
 int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps, const float* psh,
-                 void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st)
+                 void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st, const saunet_bn_prologue* bnp)
 {
     TileArgs a;
+    if (bnp) a.bnp = *bnp; else a.bnp.gamma = nullptr;
     if (epi) { a.epi = *epi; if (a.epi.sums_replicas < 1) a.epi.sums_replicas = 1; } else a.epi.bn_x = nullptr;
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.pro_scale = ps; a.pro_shift = psh; a.stat_sum = ssum; a.stat_sumsq = ssq;
     a.stat_replicas = d->stat_replicas > 1 ? d->stat_replicas : 1; a.stat_rstride = d->stat_rstride;
@@ -777,8 +784,15 @@ int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const 
     a.pro_relu = d->pro_relu; a.act_relu = d->epi_relu; a.tiles_y = d->H / TILE; a.tiles_x = d->W / TILE;
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return set_error(SAUNET_BAD_ALIGN, "conv: pointers must be 16-byte aligned");
     bool handled = false;
-    if (d->dtype == SAUNET_BF16) { int rc = dispatch_res_fwd<u16>(a, st, &handled); if (handled) return rc; return dispatch_tile_fwd<u16>(a, st); }
-    if (d->dtype == SAUNET_F32) { int rc = dispatch_res_fwd<float>(a, st, &handled); if (handled) return rc; return dispatch_tile_fwd<float>(a, st); }
+    // only the resident kernel derives the BatchNorm coefficients itself: in front of the tile kernel they are finalised by their own launch
+    auto unfuse = [&]() -> int {
+        if (!bnp) return SAUNET_OK;
+        if (int rc = bn_prologue_finalize(bnp, d->Cin, st)) return rc;
+        a.pro_scale = bnp->params; a.pro_shift = bnp->params + d->Cin; a.bnp.gamma = nullptr;
+        return SAUNET_OK;
+    };
+    if (d->dtype == SAUNET_BF16) { int rc = dispatch_res_fwd<u16>(a, st, &handled); if (handled) return rc; if ((rc = unfuse())) return rc; return dispatch_tile_fwd<u16>(a, st); }
+    if (d->dtype == SAUNET_F32) { int rc = dispatch_res_fwd<float>(a, st, &handled); if (handled) return rc; if ((rc = unfuse())) return rc; return dispatch_tile_fwd<float>(a, st); }
     return set_error(SAUNET_BAD_DTYPE, "conv: dtype %d", d->dtype);
 }
 
@@ -1213,10 +1227,22 @@ static int launch_tile_wgrad_grouped(GroupedWgradArgs& g, const saunet_wgrad_gro
         chan_tiles += (long)cdiv(g.item[i].Cout, CO_T) * g.item[i].ncit;
         welems += (long)g.item[i].Cout * g.item[i].Cin * g.taps;
     }
-    // pixel groups: fill the chip (two resident workgroups per CU) with as few partial gradients as possible
-    static const long target = getenv("SAUNET_WGRAD_GROUP_BLOCKS") ? atol(getenv("SAUNET_WGRAD_GROUP_BLOCKS")) : 640;
-    int groups = 1;
-    while (groups * 2 <= g.ntiles && chan_tiles * groups * 2 <= target) groups *= 2;
+    // pixel groups: ONE co-resident wave of workgroups (a grid of 1.1x the resident capacity runs as long as one of 2x), each with an equal
+    // share of the pixel tiles
+    static int capacity = 0;
+    if (capacity == 0) {
+        int per_cu = 0, dev = 0; hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, LDS) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+        capacity = per_cu * prop.multiProcessorCount;
+        (void)hipGetLastError();
+    }
+    static const long target_env = getenv("SAUNET_WGRAD_GROUP_BLOCKS") ? atol(getenv("SAUNET_WGRAD_GROUP_BLOCKS")) : 0;
+    const long target = target_env > 0 ? target_env : capacity;
+    long groups_l = target / chan_tiles;
+    if (groups_l > g.ntiles) groups_l = g.ntiles;
+    if (groups_l < 1) groups_l = 1;
+    const int groups = (int)groups_l;
     g.groups = groups;
     const size_t bytes = groups > 1 ? (size_t)groups * welems * sizeof(float) : 0;
     if (need) { *need = bytes; return SAUNET_OK; }

@@ -74,20 +74,26 @@ __global__ void sum_replicas_kernel(double* __restrict__ base, int n, int reps, 
     base[i] = s;
 }
 
-// sum over the replicated accumulators (saunet_bn_epilogue.sums_replicas): 8 loads in flight at a time -- these kernels are
-// pure latency chains (one thread per channel), a one-load-per-iteration loop costs 16 memory round trips
-__device__ __forceinline__ double rep_sum(const double* __restrict__ s, int reps, int rstride, int i)
+// xhat rows (saunet_bn_prologue.xhat) of C channels straight from their statistics
+__global__ void bn_xhat_kernel(int C, const double* __restrict__ sum, const double* __restrict__ sq, int reps, int rstride, double count, float eps,
+                               float* __restrict__ xhat, int ld)
 {
-    double v = 0.0;
-    int r = 0;
-    for (; r + 8 <= reps; r += 8) {
-        double t[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = s[(size_t)(r + j) * rstride + i];
-        v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-    }
-    for (; r < reps; ++r) v += s[(size_t)r * rstride + i];
-    return v;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double s1 = rep_sum(sum, reps, rstride, c), s2 = rep_sum(sq, reps, rstride, c);
+    const double m = s1 / count;
+    double v = s2 / count - m * m;
+    if (v < 0.0) v = 0.0;
+    const float mean = (float)m, is = (float)(1.0 / sqrt(v + (double)eps));
+    xhat[c] = is; xhat[ld + c] = -mean * is; xhat[2 * ld + c] = mean; xhat[3 * ld + c] = is; xhat[4 * ld + c] = (float)v;
+}
+
+// the `writer` part of bn_prologue_fill on its own: used in front of convolution kernels that do not derive the coefficients themselves
+__global__ __launch_bounds__(256) void bn_prologue_finalize_kernel(saunet_bn_prologue p, int Cin, float* __restrict__ scratch)
+{
+    // scratch: [2][cpad] never read (the fill wants a destination); chunked so any Cin works with one workgroup
+    extern __shared__ float s_tmp[];
+    bn_prologue_fill<256>(p, Cin, Cin, s_tmp, true);
 }
 
 __global__ void bn_finalize_kernel(int C, const double* __restrict__ sum, const double* __restrict__ sq, int reps, int rstride, double count,
@@ -469,6 +475,15 @@ using namespace saunet;
         else return set_error(SAUNET_BAD_DTYPE, "dtype %d", (dtype));                     \
     } while (0)
 
+namespace saunet {
+int bn_prologue_finalize(const saunet_bn_prologue* p, int Cin, hipStream_t st)
+{
+    hipLaunchKernelGGL(bn_prologue_finalize_kernel, dim3(1), dim3(256), sizeof(float) * 2 * Cin, st, *p, Cin, nullptr);
+    SAUNET_CHECK_LAUNCH("bn_prologue_finalize");
+    return SAUNET_OK;
+}
+}  // namespace saunet
+
 extern "C" {
 
 int saunet_sum_replicas(double* base, int n, int replicas, int rstride, void* stream)
@@ -491,6 +506,14 @@ int saunet_bn_stats(int dtype, const void* x, int64_t pixels, int C, int ld, dou
     DISPATCH_TV(dtype, vec, CALL);
 #undef CALL
     SAUNET_CHECK_LAUNCH("bn_stats");
+    return SAUNET_OK;
+}
+
+int saunet_bn_xhat(int C, const double* sum, const double* sumsq, int replicas, int rstride, double count, float eps, float* xhat, int ld, void* stream)
+{
+    if (C < 1 || !sum || !sumsq || !xhat || ld < C) return set_error(SAUNET_BAD_SHAPE, "bn_xhat: C=%d ld=%d", C, ld);
+    hipLaunchKernelGGL(bn_xhat_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, sum, sumsq, replicas < 1 ? 1 : replicas, rstride, count, eps, xhat, ld);
+    SAUNET_CHECK_LAUNCH("bn_xhat");
     return SAUNET_OK;
 }
 

@@ -323,6 +323,35 @@ def conv_forward_raw(x, weight, bias, stride, pad, transposed=False, pro=None, o
     return out
 
 
+def conv_forward_bnpro(x, weight, stride, pad, bn_stats_in, count, c_lo, xhat, gamma, beta, rmean, rvar, momentum, eps, params, out=None, stats=None):
+    """y = conv(relu(BN(x)), weight) with the BatchNorm coefficients derived inside the convolution kernel from the raw statistics
+    `bn_stats_in` ([R, 2, >=Cin] float64 accumulators of x's channels) -- saunet_conv2d_forward_bnpro: no finalize launch.  Channels below
+    c_lo take their normalisation from the `xhat` rows ([5, ld]); `params` ([4, Cin] float32) receives scale / shift / mean / invstd."""
+    _check_dev(x)
+    x = nhwc(x)
+    cout, cin_w, kh, kw = weight.shape
+    if cin_w != x.shape[1]:
+        raise RuntimeError("conv: weight expects %d input channels, got %d" % (cin_w, x.shape[1]))
+    ho, wo = conv_out_hw(x.shape[2], x.shape[3], kh, kw, stride, pad, False)
+    if out is None:
+        out = new_act(x.shape[0], cout, ho, wo, x.dtype, x.device)
+    wp = PACKS.get(weight, L.PACK_FWD, x.dtype)
+    d = _desc(x, cout, ld_of(out), ho, wo, kh, kw, stride, pad, False, True)
+    if stats is not None:
+        d.stat_replicas, d.stat_rstride = stats.shape[0], stats.stride(0)
+    p = L.BnPrologue()
+    p.sum, p.sumsq = bn_stats_in[0, 0].data_ptr(), bn_stats_in[0, 1].data_ptr()
+    p.replicas, p.rstride, p.count, p.eps, p.momentum = bn_stats_in.shape[0], bn_stats_in.stride(0), float(count), float(eps), float(momentum)
+    p.c_lo, p.ld_xhat, p.xhat = c_lo, (xhat.stride(0) if xhat is not None else 0), L.ptr(xhat)
+    p.gamma, p.beta, p.params, p.running_mean, p.running_var = gamma.data_ptr(), beta.data_ptr(), params.data_ptr(), L.ptr(rmean), L.ptr(rvar)
+    L.call("saunet_conv2d_forward_bnpro", C.byref(d), x.data_ptr(), wp.data_ptr(), None, C.byref(p), out.data_ptr(),
+           stats[0, 0].data_ptr() if stats is not None else None, stats[0, 1].data_ptr() if stats is not None else None, L.stream())
+    return out
+
+
+DENSE_BNPRO = os.environ.get("SAUNET_DENSE_BNPRO", "1") != "0"    # A/B switch: per-layer saunet_bn_finalize launches when "0"
+
+
 def igemm_ok(t, cin, cout):
     """mirror of igemm_supported() in csrc/conv_igemm.hip: is this (view, Cin, Cout) on the MFMA path?"""
     epc = 8 if t.dtype == torch.bfloat16 else 4
@@ -1517,6 +1546,28 @@ class _DenseBlock(torch.autograd.Function):
             nl_loop = 0
         else:
             nl_loop = nl
+        # training on the GPU: BatchNorm coefficients are derived inside the consuming convolution (saunet_conv2d_forward_bnpro) -- two
+        # launches per layer instead of four; the per-channel normalisation of the concat channels (xh rows: xs, xt, mean, invstd, var) is
+        # published by the first kernel that needs it and reused by every later norm1
+        bnpro = training and DENSE_BNPRO and buf.is_cuda and nl_loop > 0
+        xh = GRADS.take(5 * ctot, dev).view(5, ctot) if buf.is_cuda else torch.zeros(5, ctot, dtype=torch.float32, device=dev)
+        if bnpro:
+            PACKS.generation += 1                  # running statistics change through raw pointers (as in bn_finalize)
+            L.call("saunet_bn_xhat", c0, stats[0, 0].data_ptr(), stats[0, 1].data_ptr(), stats.shape[0], stats.stride(0), float(count), float(cfgs[0][1]),
+                   xh.data_ptr(), xh.stride(0), L.stream())
+            for l in range(nl_loop):
+                n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
+                n1rm, n1rv, n2rm, n2rv = bufs[4 * l:4 * l + 4]
+                mom, eps = cfgs[l]
+                cin = c0 + growth * l
+                p1, p2 = BNParams(cin, dev), BNParams(c1w.shape[0], dev)
+                st2 = new_stats(c1w.shape[0], dev)
+                z1 = conv_forward_bnpro(buf[:, :cin], c1w, 1, 0, stats, count, cin - growth if l > 0 else cin, xh, n1w, n1b, n1rm, n1rv, mom, eps,
+                                        p1.buf, stats=st2)
+                conv_forward_bnpro(z1, c2w, 1, 1, st2, count, 0, None, n2w, n2b, n2rm, n2rv, mom, eps, p2.buf, out=buf[:, cin:cin + growth],
+                                   stats=stats[:, :, cin:cin + growth])
+                saved += [z1, p1.buf, p2.buf]
+            nl_loop = 0
         for l in range(nl_loop):
             n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
             n1rm, n1rv, n2rm, n2rv = bufs[4 * l:4 * l + 4]
@@ -1530,8 +1581,7 @@ class _DenseBlock(torch.autograd.Function):
                              stats=stats[:, :, cin:cin + growth] if training else None)
             saved += [z1, p1.buf, p2.buf]
         # xhat = x*xs + xt for every concat channel (gamma=1, beta=0): what the deferred backward correction needs
-        xh = torch.zeros(2, ctot, dtype=torch.float32, device=dev)
-        if training:
+        if training and not bnpro:
             one, zero = _const_vec(ctot, dev, 1.0), _const_vec(ctot, dev, 0.0)
             L.call("saunet_bn_finalize", ctot, stats[0, 0].data_ptr(), stats[0, 1].data_ptr(), stats.shape[0], stats.stride(0), float(count),
                    None, one.data_ptr(), zero.data_ptr(),

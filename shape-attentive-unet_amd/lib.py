@@ -27,6 +27,12 @@ class BnEpilogue(C.Structure):
                 ("mean", C.c_void_p), ("invstd", C.c_void_p), ("sums", C.c_void_p), ("sums_replicas", C.c_int32), ("sums_rstride", C.c_int32)]
 
 
+class BnPrologue(C.Structure):
+    _fields_ = [("sum", C.c_void_p), ("sumsq", C.c_void_p), ("replicas", C.c_int32), ("rstride", C.c_int32), ("count", C.c_double),
+                ("eps", C.c_float), ("momentum", C.c_float), ("c_lo", C.c_int32), ("ld_xhat", C.c_int32), ("xhat", C.c_void_p),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("params", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p)]
+
+
 class PackList(C.Structure):
     _fields_ = [("count", C.c_int32), ("mode", C.c_int32 * 64), ("dims", (C.c_int32 * 4) * 64), ("src", C.c_void_p * 64),
                 ("dst", C.c_void_p * 64)]
@@ -80,6 +86,8 @@ _SIGS = {
     "saunet_conv2d_forward": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "saunet_dense_block_forward": [C.POINTER(DenseFwdDesc), vp, vp],
     "saunet_conv2d_forward_ex": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(BnEpilogue), vp],
+    "saunet_conv2d_forward_bnpro": [C.POINTER(ConvDesc), vp, vp, vp, C.POINTER(BnPrologue), vp, vp, vp, vp],
+    "saunet_bn_xhat": [i32, vp, vp, i32, i32, f64, f32, vp, i32, vp],
     "saunet_conv2d_wgrad": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i64, vp],
     "saunet_conv2d_wgrad_workspace": [C.POINTER(ConvDesc)],
     "saunet_conv2d_wgrad_deferred": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i64, C.POINTER(WgradPending), vp],
