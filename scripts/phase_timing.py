@@ -35,20 +35,29 @@ elif case in ("dense3fwd", "dense4fwd"):
     def run():
         with torch.no_grad():
             block(x)
-elif case == "conv1fwd":
+elif case in ("conv1fwd", "conv1fwd3", "conv1fwd4"):
     unit = "conv_igemm"
-    x = act(192, 128); w = torch.nn.Parameter(torch.randn(128, 192, 1, 1, device="cuda") * 0.03)
-    sc = torch.rand(192, device="cuda") + 0.5; sh = torch.randn(192, device="cuda") * 0.1
-    out = HF.new_act(n, 128, 128, 128, dt, "cuda"); st = torch.zeros(HF.STAT_R, 2, 128, dtype=torch.float64, device="cuda")
+    ci_, h_ = {"conv1fwd": (192, 128), "conv1fwd3": (640, 32), "conv1fwd4": (768, 16)}[case]
+    x = act(ci_, h_); w = torch.nn.Parameter(torch.randn(128, ci_, 1, 1, device="cuda") * 0.03)
+    sc = torch.rand(ci_, device="cuda") + 0.5; sh = torch.randn(ci_, device="cuda") * 0.1
+    out = HF.new_act(n, 128, h_, h_, dt, "cuda"); st = torch.zeros(HF.STAT_R, 2, 128, dtype=torch.float64, device="cuda")
     run = lambda: HF.conv_forward_raw(x, w, None, 1, 0, pro=(sc, sh, True), out=out, stats=st)
-elif case == "conv1dgrad":
+elif case in ("conv1dgrad", "conv1dgrad3", "conv1dgrad4"):
     unit = "dense_dgrad"
-    cin, ctot, h = 192, 256, 128
+    cin, ctot, h = {"conv1dgrad": (192, 256, 128), "conv1dgrad3": (640, 1024, 32), "conv1dgrad4": (768, 1024, 16)}[case]
     buf = act(ctot, h); dbuf = act(ctot, h); g = act(128, h)
     w = torch.nn.Parameter(torch.randn(128, cin, 1, 1, device="cuda") * 0.05)
     p = HF.BNParams(cin, "cuda"); p.buf[0].uniform_(0.5, 1.5); p.buf[1].normal_(0, 0.3); p.buf[2].normal_(0, 0.3); p.buf[3].uniform_(0.5, 1.5)
     sums = torch.zeros(HF.STAT_R, 2, cin, dtype=torch.float64, device="cuda")
     run = lambda: HF.conv_dgrad_raw(g, w, (n, cin, h, h), 1, 0, out=dbuf[:, :cin], bn_epi=(buf[:, :cin], p, True, sums, True))
+elif case in ("conv2dgrad", "conv2dgrad3", "conv2dgrad4"):
+    unit = "dense_dgrad"
+    h = {"conv2dgrad": 128, "conv2dgrad3": 32, "conv2dgrad4": 16}[case]
+    dbuf = act(256, h); z1 = act(128, h)
+    w = torch.nn.Parameter(torch.randn(32, 128, 3, 3, device="cuda") * 0.05)
+    p = HF.BNParams(128, "cuda"); p.buf[0].uniform_(0.5, 1.5); p.buf[1].normal_(0, 0.3); p.buf[2].normal_(0, 0.3); p.buf[3].uniform_(0.5, 1.5)
+    sums = torch.zeros(HF.STAT_R, 2, 128, dtype=torch.float64, device="cuda")
+    run = lambda: HF.conv_dgrad_raw(dbuf[:, 64:96], w, z1.shape, 1, 1, bn_epi=(z1, p, True, sums))
 for _ in range(3):
     run()
 torch.cuda.synchronize()

@@ -29,7 +29,8 @@ for ev in prof.events():
     if ev.name in ("aten::copy_", "aten::fill_", "aten::add_", "aten::add", "aten::clone", "aten::mul", "aten::sum"):
         tot[ev.name] += 1
         st = [f for f in (ev.stack or []) if ("repo" in f or "saunet" in f) and "tiny_op_sites" not in f]
-        sites[(ev.name, st[0][-90:] if st else "(no python frame: autograd thread)")] += 1
+        shp = str([tuple(x) for x in (ev.input_shapes or []) if x])[:70]
+        sites[(ev.name, (st[0][-90:] if st else "(autograd thread) shapes " + shp))] += 1
 print(dict(tot))
 for (name, site), n in sorted(sites.items(), key=lambda kv: -kv[1])[:50]:
     print("%4d  %-12s %s" % (n, name, site))

@@ -21,6 +21,7 @@
 //     LDS atomic per channel per wave tile and one float64 atomic per channel per block.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace saunet {
 
@@ -47,6 +48,29 @@ __device__ __forceinline__ float half_wave_sum(float v)
     return v;
 }
 
+// keep + (send of the partner lane under the DPP permutation CTRL)
+template <int CTRL> __device__ __forceinline__ float dpp_exchange_add(float keep, float send)
+{
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xf, 0xf, true));
+}
+// TRANSPOSING reduction of the two BN-backward sums of 8 channels over the 16 lanes (pixels) of a DPP row: every stage pairs two values, a lane
+// keeps one of the pair and receives the partner lane's copy of the same one, so the 16 inputs shrink 8 -> 4 -> 2 -> 1 while the lanes
+// spread over the outputs: 15 DPP adds (+ 30 selects) instead of the 80 DPP adds of sixteen separate 5-step reductions -- a DPP add issues
+// every 8 cycles per wave, an LDS float atomic costs ~12 cycles per active lane (scripts/probes/valu_probe.hip).  Stage order = row_mirror,
+// row_half_mirror, quad_perm xor 1, quad_perm xor 2, so that the lanes a later stage pairs made the same choices in all earlier stages.
+// Result: lane l of the row holds the 16-lane partial sum of  (l & 8 ? e2 : e1)[4 * ((l >> 1) & 1) + 2 * (l & 1) + ((l >> 2) & 1)].
+__device__ __forceinline__ float row_transpose_sum(const float (&e1)[8], const float (&e2)[8], bool s0, bool s1, bool s2, bool s3)
+{
+    float w0[8], w1[4], w2[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w0[j] = dpp_exchange_add<0x140>(s0 ? e2[j] : e1[j], s0 ? e1[j] : e2[j]);                 // row_mirror
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w1[k] = dpp_exchange_add<0x141>(s1 ? w0[2 * k + 1] : w0[2 * k], s1 ? w0[2 * k] : w0[2 * k + 1]);   // row_half_mirror
+#pragma unroll
+    for (int k = 0; k < 2; ++k) w2[k] = dpp_exchange_add<0xB1>(s2 ? w1[2 * k + 1] : w1[2 * k], s2 ? w1[2 * k] : w1[2 * k + 1]);    // quad_perm [1,0,3,2]
+    return dpp_exchange_add<0x4E>(s3 ? w2[1] : w2[0], s3 ? w2[0] : w2[1]);                                                // quad_perm [2,3,0,1]
+}
+
 constexpr int DG_GROUP = 256;          // channels per block (weights of one group live in LDS: 256 rows x 272 B)
 constexpr int DG_WPITCH = 136;         // u16 per LDS weight row: 128 + 8 pad -> 16 consecutive rows hit 16 different 16-byte bank groups
 constexpr int DG_WAVES = 4;
@@ -58,11 +82,17 @@ constexpr int DG_WAVES = 4;
 // one v_permlane32_swap per value pair trades runs with the partner lane (same pixel, other half-wave) so that a lane owns
 // 8 CONSECUTIVE channels twice per tile: x / y are then read and written as 16-byte pieces (measured 5.4 TB/s for this
 // row-piece pattern against 3.8 TB/s with 8-byte pieces; scripts/probes/rowpiece_probe.hip).  The four output pieces of a
-// step are stored together so the L2 merges them into whole lines.  Measured (rocprofv3 PMC, Cin = 192 probe): FETCH_SIZE x 2 =
-// 540 MB, WRITE_SIZE = 204 MB against 537 + 201 MB algorithmic -- no re-reads; 206 us = 3.6 TB/s (the generic kernel: 411 us).
-// (A one-load-per-line "touch" prefetch of the next tile's g rows was tried: the lines were evicted again before use and
-// every g byte was fetched twice, 1.23x the algorithmic reads -- removed.)
-__global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgradArgs a)
+// step are stored together so the L2 merges them into whole lines.
+// Round 3 (s_memtime stamps + scripts/probes/valu_probe.hip): a 64-channel step cost 9.3-9.7k cycles whether its operands came from HBM
+// (block 1) or the L2 (block 4) -- the kernel was bound by its own instruction stream, not by bandwidth:
+//   * every load sat under an exec-mask branch (`ok ? load : 0`), so the compiler could not count the vmcnt queue and waited vmcnt(0) in
+//     front of the first MFMA of every step, i.e. for the y / next-x requests just issued: all loads are unconditional now (clamped
+//     addresses, results discarded by the epilogue's `ok` tests and the guarded stores);
+//   * `cur = nxt` register-set copies waited vmcnt(0) as well: the step sequence is written out per step (NS = steps per group is a
+//     template parameter), each step a fixed set of registers, the hand-over copies sit where everything they wait for is old;
+//   * the two BN-backward sums took 320 DPP adds (8 cycles each per wave) + 128 lane-atomics on LDS (12 cycles per lane) per step:
+//     replaced by the transposing row reduction above (60 DPP adds) into REGISTER accumulators that live for the wave's lifetime.
+template <int NS> __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgradArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char d_smem[];
     TSTAMP_INIT();
@@ -72,14 +102,13 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgra
     const int GCP = (GC + 31) & ~31;
     u16* s_w = (u16*)d_smem;                             // [GCP][DG_WPITCH]
     float* s_par = (float*)(d_smem + (size_t)GCP * DG_WPITCH * 2);   // [4][GCP] scale, shift, invstd, -mean*invstd
-    float* s_sum = s_par + 4 * GCP;                      // [2][GCP]
     constexpr int NT = DG_WAVES * 64;
     for (int i0 = threadIdx.x; i0 < GCP * 16; i0 += NT * 8) {     // 8 loads in flight per thread: the copy costs ~2 memory latencies
         u32x4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * NT, r = i >> 4, ch = i & 15;
-            if (i < GCP * 16) v[u] = *(const u32x4*)(a.w + (size_t)min(g0 + r, a.Cin - 1) * 128 + ch * 8);
+            const int i = min(i0 + u * NT, GCP * 16 - 1), r = i >> 4, ch = i & 15;
+            v[u] = *(const u32x4*)(a.w + (size_t)min(g0 + r, a.Cin - 1) * 128 + ch * 8);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -92,62 +121,87 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgra
         const float is = ok ? a.invstd[g0 + i] : 0.f;
         s_par[i] = ok ? a.scale[g0 + i] : 0.f; s_par[GCP + i] = ok ? a.shift[g0 + i] : 0.f;
         s_par[2 * GCP + i] = is; s_par[3 * GCP + i] = ok ? -a.mean[g0 + i] * is : 0.f;
-        s_sum[i] = 0.f; s_sum[GCP + i] = 0.f;
     }
     __syncthreads();
     TSTAMP(41);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
     const unsigned ntp = (a.P + 31) / 32;
     const unsigned stride = gridDim.x * DG_WAVES;
-    const int nsteps = (GCP + 63) / 64;                  // 64-channel steps in the group
 
-    // x / y pieces of one 64-channel step: piece i (tile t = i >> 1, run r = i & 1) = channels step*64 + 32t + 16r + 8*lh .. +8
+    // x / y pieces of one 64-channel step: piece i (tile t = i >> 1, run r = i & 1) = channels step*64 + 32t + 16r + 8*lh .. +8.
+    // Pieces past the group's last channel read the group's last piece, rows past the last pixel the last pixel.
     struct XP { u32x4 x[4]; };
-    auto request_x = [&](size_t pp, int step, XP& o) {
-        const u16* xr = a.x + pp * a.ldx + g0 + step * 64 + 8 * lh;
+    auto request_x = [&](size_t pp, int step, XP& o, int lh8) {
+        const u16* xr = a.x + pp * a.ldx + g0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool ok = step * 64 + 16 * i + 8 * lh < GC;
-            o.x[i] = ok ? *(const u32x4*)(xr + 16 * i) : u32x4{0u, 0u, 0u, 0u};
-        }
+        for (int i = 0; i < 4; ++i) o.x[i] = *(const u32x4*)(xr + min(step * 64 + 16 * i + lh8, GC - 8));
     };
+    u32x4 gf[8];
+    auto request_g = [&](size_t pp) {
+        const u16* grow = a.g + pp * a.ldg + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) gf[ks] = *(const u32x4*)(grow + ks * 16);
+    };
+    XP xa, xb;                        // x (needed first, for the mask) is requested one step ahead; y at the start of its own step
+    // the two BN-backward sums stay in registers for the wave's whole lifetime: red[step][2t + r] = the lane's transposed partial sum
+    // (row_transpose_sum) of the 8 channels of MFMA tile t, run pair r
+    float red[NS][4];
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[i][k] = 0.f;
+    const bool sd0 = lane & 8, sd1 = lane & 4, sd2 = lane & 1, sd3 = lane & 2;
+    {
+        const unsigned tp0 = min(blockIdx.x * DG_WAVES + wave, ntp - 1);
+        const size_t pp0 = min(tp0 * 32u + lr, a.P - 1);
+        request_g(pp0);
+        request_x(pp0, 0, xa, 8 * lh);
+    }
     for (unsigned tp = blockIdx.x * DG_WAVES + wave; tp < ntp; tp += stride) {
         const unsigned p = tp * 32u + lr;
         const bool live = p < a.P;
         const size_t pp = live ? p : a.P - 1;
-        u32x4 gf[8];
-        {
-            const u16* grow = a.g + pp * a.ldg + lh * 8;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) gf[ks] = live ? *(const u32x4*)(grow + ks * 16) : u32x4{0u, 0u, 0u, 0u};
-        }
+        const size_t ppn = tp + stride < ntp ? min((tp + stride) * 32u + lr, a.P - 1) : pp;      // the wave's next tile (this one again when there is none: cache hits)
         TSTAMP(42);
-        XP cur, nxt;                  // x (needed first, for the mask) is requested one step ahead; y at the start of its own step
-        request_x(pp, 0, cur);
         u16* yrow = a.y + pp * a.ldy + g0 + 8 * lh;
-        for (int step = 0; step < nsteps; ++step) {
+        const u16* yrow0 = a.y + pp * a.ldy + g0;
+        // the weight fragments are re-read from LDS for every tile ON PURPOSE: with the steps written out their addresses are tile-invariant
+        // and the compiler would hoist all 16 x NS fragments out of the tile loop (64 registers per step: spills); this makes the base opaque
+        int wlane = (lr * DG_WPITCH + lh * 8) * 2;
+        asm volatile("" : "+v"(wlane));
+        int plane = 8 * lh;                  // (the same for the per-channel parameter rows)
+        asm volatile("" : "+v"(plane));
+        // One 64-channel step.  On the tile's LAST step the x request is the next tile's first one and the next tile's g fragments are
+        // requested as soon as the last MFMA has read the current ones (both MFMA tiles first, then the two epilogues cover the request).
+        auto do_step = [&](auto step_c, XP& cur, XP& nxt) {
+            constexpr int step = decltype(step_c)::value;
+            constexpr bool LAST = step + 1 == NS;
             u32x4 yv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool ok = a.accumulate && step * 64 + 16 * i + 8 * lh < GC;
-                yv[i] = ok ? *(const u32x4*)(yrow + step * 64 + 16 * i) : u32x4{0u, 0u, 0u, 0u};
+            for (int i = 0; i < 4; ++i) yv[i] = u32x4{0u, 0u, 0u, 0u};
+            if (a.accumulate) {        // wave-uniform
+#pragma unroll
+                for (int i = 0; i < 4; ++i) yv[i] = *(const u32x4*)(yrow0 + min(step * 64 + 16 * i + plane, GC - 8));
             }
-            if (step + 1 < nsteps) request_x(pp, step + 1, nxt);
+            request_x(LAST ? ppn : pp, LAST ? 0 : step + 1, nxt, plane);
             TSTAMP(43);
             u32x4 outv[4];          // the step's four 16-byte output pieces leave together: the L2 sees whole 128-byte lines
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int ct = step * 64 + 32 * t;           // first channel of this MFMA tile inside the group
-                if (ct >= GCP) continue;
+            auto mma = [&](auto t_c) -> f32x16 {
+                constexpr int t = decltype(t_c)::value;
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                const u16* wrow = s_w + (ct + lr) * DG_WPITCH + lh * 8;
+                const u16* wrow = (const u16*)((const unsigned char*)s_w + wlane) + min(step * 64 + 32 * t, GCP - 32) * DG_WPITCH;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
                     const u32x4 wf = *(const u32x4*)(wrow + ks * 16);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, gf[ks]), acc, 0, 0, 0);
                 }
+                return acc;
+            };
+            auto epilogue = [&](auto t_c, const f32x16& acc) {
+                constexpr int t = decltype(t_c)::value;
+                constexpr int ct = step * 64 + 32 * t;       // first channel of this MFMA tile inside the group
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     // runs 2r (A) and 2r+1 (B) -> this lane's 8 consecutive channels cl .. cl+7
@@ -159,43 +213,83 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgra
                     }
                     const int cl = ct + 16 * r + 8 * lh;
                     const bool ok = live && cl < GC;
-                    float xf[8], yf[8], o[8];
+                    const int cp = min(ct + 16 * r + plane, GCP - 8);             // parameter rows of channels past the group: any valid address
+                    float xf[8], yf[8], o[8], e1[8], e2[8];
                     Vec16<u16>::unpack(cur.x[2 * t + r], xf); Vec16<u16>::unpack(yv[2 * t + r], yf);
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const f32x4 sc = *(const f32x4*)(s_par + cl + 4 * h), sh = *(const f32x4*)(s_par + GCP + cl + 4 * h);
-                        const f32x4 a1 = *(const f32x4*)(s_par + 2 * GCP + cl + 4 * h), a0 = *(const f32x4*)(s_par + 3 * GCP + cl + 4 * h);
-                        float e1[4], e2[4];
+                        const f32x4 sc = *(const f32x4*)(s_par + cp + 4 * h), sh = *(const f32x4*)(s_par + GCP + cp + 4 * h);
+                        const f32x4 a1 = *(const f32x4*)(s_par + 2 * GCP + cp + 4 * h), a0 = *(const f32x4*)(s_par + 3 * GCP + cp + 4 * h);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int e = 4 * h + q;
                             const bool keep = ok && (!a.relu || fmaf(xf[e], sc[q], sh[q]) > 0.f);
                             const float Gv = keep ? G[e] : 0.f;
-                            e1[q] = half_wave_sum(Gv); e2[q] = half_wave_sum(Gv * fmaf(xf[e], a1[q], a0[q]));
+                            e1[e] = Gv; e2[e] = Gv * fmaf(xf[e], a1[q], a0[q]);
                             o[e] = a.accumulate ? fmaf(sc[q], Gv, yf[e]) : Gv;
                         }
-                        if (lr == 31) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) { atomicAdd(&s_sum[cl + 4 * h + q], e1[q]); atomicAdd(&s_sum[GCP + cl + 4 * h + q], e2[q]); }
-                        }
                     }
+                    red[step][2 * t + r] += row_transpose_sum(e1, e2, sd0, sd1, sd2, sd3);
                     outv[2 * t + r] = Vec16<u16>::pack(o);
                 }
+            };
+            constexpr std::integral_constant<int, 0> T0{};
+            constexpr std::integral_constant<int, 1> T1{};
+            const bool two = step * 64 + 32 < GCP;       // block-uniform: the step's second 32-channel tile exists
+#pragma unroll
+            for (int i = 2; i < 4; ++i) outv[i] = u32x4{0u, 0u, 0u, 0u};
+            if constexpr (LAST) {
+                const f32x16 acc0 = mma(T0);
+                f32x16 acc1 = acc0;
+                if (two) acc1 = mma(T1);
+                request_g(ppn);                  // gf is free: the next tile's fragments travel behind this step's two epilogues
+                epilogue(T0, acc0);
+                if (two) epilogue(T1, acc1);
+                if constexpr ((NS & 1) == 1) cur = nxt;     // odd number of steps: the next tile's step 0 reads the set this step read
+            } else {
+                const f32x16 acc0 = mma(T0);
+                epilogue(T0, acc0);
+                if (two) { const f32x16 acc1 = mma(T1); epilogue(T1, acc1); }
             }
             TSTAMP(44);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (live && step * 64 + 16 * i + 8 * lh < GC) *(u32x4*)(yrow + step * 64 + 16 * i) = outv[i];
-            cur = nxt;
             TSTAMP(45);
-        }
+        };
+        do_step(std::integral_constant<int, 0>{}, xa, xb);
+        if constexpr (NS > 1) do_step(std::integral_constant<int, 1>{}, xb, xa);
+        if constexpr (NS > 2) do_step(std::integral_constant<int, 2>{}, xa, xb);
+        if constexpr (NS > 3) do_step(std::integral_constant<int, 3>{}, xb, xa);
     }
+    TSTAMP(46);
+    // block-level fold of the register accumulators: every wave parks its partial sums in the (now idle) weight area, then one thread per
+    // channel adds the 4 waves x 2 DPP rows that hold it and sends the pair of sums to the replicated float64 accumulators
     __syncthreads();
+    float* s_red = (float*)d_smem;                       // [wave][step * 4 + k][64 lanes]
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_red[(wave * (NS * 4) + i * 4 + k) * 64 + lane] = red[i][k];
+    __syncthreads();
+    TSTAMP(47);
     const size_t ro = (size_t)(blockIdx.x % a.reps) * a.rstride;
-    for (int i = threadIdx.x; i < GC; i += NT) {
-        atomicAdd(&a.sums[ro + g0 + i], (double)s_sum[i]);
-        atomicAdd(&a.sums[ro + a.Cin + g0 + i], (double)s_sum[GCP + i]);
+    for (int c = threadIdx.x; c < GC; c += NT) {
+        // channel c of the group = step (c >> 6), register (c >> 4) & 3, lane bits: lh = bit 3 of c, then 4*b1 + 2*b0 + b2 = c & 7
+        const int reg = (c >> 6) * 4 + ((c >> 4) & 3);
+        const int l0 = 32 * ((c >> 3) & 1) + 4 * (c & 1) + 2 * ((c >> 2) & 1) + ((c >> 1) & 1);
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < DG_WAVES; ++w)
+#pragma unroll
+            for (int row = 0; row < 2; ++row) {
+                const float* q = s_red + (w * (NS * 4) + reg) * 64 + l0 + 16 * row;
+                t1 += q[0]; t2 += q[8];
+            }
+        atomicAdd(&a.sums[ro + g0 + c], (double)t1);
+        atomicAdd(&a.sums[ro + a.Cin + g0 + c], (double)t2);
     }
+    TSTAMP(48);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -221,6 +315,8 @@ constexpr int D3_WPITCH = 296;
 __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgrad3Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char d_smem[];
+    TSTAMP_INIT();
+    TSTAMP(50);
     u16* s_w = (u16*)d_smem;                                        // [128][D3_WPITCH]
     float* s_par = (float*)(d_smem + (size_t)128 * D3_WPITCH * 2);  // [4][128]
     float* s_sum = s_par + 4 * 128;                                 // [2][128]
@@ -252,6 +348,7 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgr
         const unsigned pc = live ? p : a.P - 1;
         const unsigned n = a.dHW.div(pc), rem = pc - n * (unsigned)(a.H * a.W);
         const int py = (int)a.dW.div(rem), px = (int)(rem - (unsigned)py * a.W);
+        TSTAMP(51);
         // B fragments: [tap][k half]  (k = 16*h + 8*lh .. +8 of the 32 gradient channels)
         u32x4 gf[18];
 #pragma unroll
@@ -263,6 +360,7 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgr
             gf[2 * tap] = ok ? v0 : u32x4{0u, 0u, 0u, 0u};
             gf[2 * tap + 1] = ok ? v1 : u32x4{0u, 0u, 0u, 0u};
         }
+        TSTAMP(52);
         const u16* zrow = a.z + (size_t)pc * a.ldz + 8 * lh;
         u16* yrow = a.y + (size_t)pc * a.ldy + 8 * lh;
 #pragma unroll 1
@@ -270,6 +368,7 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgr
             u32x4 zv[4], outv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) zv[i] = *(const u32x4*)(zrow + step * 64 + 16 * i);
+            TSTAMP(53);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int ct = step * 64 + 32 * t;
@@ -282,6 +381,7 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgr
                     const u32x4 wf = *(const u32x4*)(wrow + ks * 16);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, gf[ks]), acc, 0, 0, 0);
                 }
+                TSTAMP(54);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     float G[8];
@@ -313,13 +413,16 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgr
                     }
                     outv[2 * t + r] = Vec16<u16>::pack(o);
                 }
+                TSTAMP(55);
             }
             if (live) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) *(u32x4*)(yrow + step * 64 + 16 * i) = outv[i];
             }
+            TSTAMP(56);
         }
     }
+    TSTAMP(57);
     __syncthreads();
     const size_t ro = (size_t)(blockIdx.x % a.reps) * a.rstride;
     for (int i = threadIdx.x; i < 128; i += NT) {
@@ -374,20 +477,41 @@ int dense_dgrad_forward(const saunet_conv_desc* d, const void* x, const void* w,
     // channels per block: 256 (weights copied to LDS once per block) when every wave gets many pixel tiles, fewer on the
     // low-resolution blocks where the copy would dominate and more blocks are needed to fill the chip
     const long ntp = ((long)a.P + 31) / 32;
-    a.group = ntp >= 4096 ? DG_GROUP : (ntp >= 1024 ? 128 : 64);
+    static const int big_group = getenv("SAUNET_DG_GROUP") ? atoi(getenv("SAUNET_DG_GROUP")) : DG_GROUP;      // A/B switch: 64 / 128 / 192 / 256
+    a.group = ntp >= 4096 ? big_group : (ntp >= 1024 ? 128 : 64);
+    {   // equal groups: every group runs the same number of 64-channel steps (the step sequence is compiled per step count), so
+        // Cin = 320 with at most 256 channels per group is 2 x 160, not 256 + 64
+        const int ng = (a.Cin + a.group - 1) / a.group;
+        a.group = ((a.Cin + ng - 1) / ng + 31) & ~31;
+    }
     if (const char* e = getenv("SAUNET_DG_GROUP_SMALL")) {      // A/B switch for the small-map heuristic: "<group at ntp>=1024>,<group below>"
         int g3 = 128, g4 = 64;
         if (sscanf(e, "%d,%d", &g3, &g4) == 2 && ntp < 4096) a.group = ntp >= 1024 ? g3 : g4;
     }
     const int groups = (a.Cin + a.group - 1) / a.group;
     const int gcp = ((a.Cin < a.group ? a.Cin : a.group) + 31) & ~31;
-    const size_t lds = (size_t)gcp * DG_WPITCH * 2 + sizeof(float) * 6 * gcp;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
-    // two resident blocks per CU in total; at least one pixel tile per wave
-    long bx = (512 + groups - 1) / groups; const long maxbx = ((long)a.P + 32 * DG_WAVES - 1) / (32 * DG_WAVES);
+    const int ns = (gcp + 63) / 64;                      // 64-channel steps of a full group (a shorter last group masks its surplus steps)
+    size_t lds = (size_t)gcp * DG_WPITCH * 2 + sizeof(float) * 4 * gcp;
+    const size_t red_bytes = (size_t)DG_WAVES * ns * 4 * 64 * sizeof(float);       // the end-of-kernel fold re-uses the weight area
+    if (lds < red_bytes) lds = red_bytes;
+    // two resident blocks per CU (registers): the grid must not EXCEED that capacity -- a handful of surplus blocks start only when the first
+    // ones retire and double the kernel time (515 blocks for Cin = 640 at 32 x 32 ran 60 us, 512 blocks for Cin = 992 61 us); at least one
+    // pixel tile per wave
+    long bx = 512 / groups; const long maxbx = ((long)a.P + 32 * DG_WAVES - 1) / (32 * DG_WAVES);
     if (bx > maxbx) bx = maxbx; if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(dense_dgrad_kernel, dim3((unsigned)bx, groups), dim3(DG_WAVES * 64), lds, st, a);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)bx, groups), block(DG_WAVES * 64);
+    if (ns == 1) hipLaunchKernelGGL(dense_dgrad_kernel<1>, grid, block, lds, st, a);
+    else if (ns == 2) hipLaunchKernelGGL(dense_dgrad_kernel<2>, grid, block, lds, st, a);
+    else if (ns == 3) hipLaunchKernelGGL(dense_dgrad_kernel<3>, grid, block, lds, st, a);
+    else hipLaunchKernelGGL(dense_dgrad_kernel<4>, grid, block, lds, st, a);
     SAUNET_CHECK_LAUNCH("dense_dgrad");
     return SAUNET_OK;
 }
