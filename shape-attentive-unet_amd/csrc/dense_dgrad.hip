@@ -319,14 +319,13 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgr
     TSTAMP(50);
     u16* s_w = (u16*)d_smem;                                        // [128][D3_WPITCH]
     float* s_par = (float*)(d_smem + (size_t)128 * D3_WPITCH * 2);  // [4][128]
-    float* s_sum = s_par + 4 * 128;                                 // [2][128]
     constexpr int NT = DG_WAVES * 64;
     for (int i0 = threadIdx.x; i0 < 128 * 36; i0 += NT * 9) {     // 9 loads in flight per thread
         u32x4 v[9];
 #pragma unroll
         for (int u = 0; u < 9; ++u) {
-            const int i = i0 + u * NT;
-            if (i < 128 * 36) v[u] = *(const u32x4*)(a.w + (size_t)i * 8);      // rows are contiguous in the packed weights
+            const int i = min(i0 + u * NT, 128 * 36 - 1);
+            v[u] = *(const u32x4*)(a.w + (size_t)i * 8);      // rows are contiguous in the packed weights
         }
 #pragma unroll
         for (int u = 0; u < 9; ++u) {
@@ -337,11 +336,17 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgr
     for (int i = threadIdx.x; i < 128; i += NT) {
         const float is = a.invstd[i];
         s_par[i] = a.scale[i]; s_par[128 + i] = a.shift[i]; s_par[256 + i] = is; s_par[384 + i] = -a.mean[i] * is;
-        s_sum[i] = 0.f; s_sum[128 + i] = 0.f;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
     const unsigned ntp = (a.P + 31) / 32;
+    // the two BN-backward sums in registers for the wave's lifetime (see dense_dgrad_kernel): red[step][2t + r]
+    float red[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[i][k] = 0.f;
+    const bool sd0 = lane & 8, sd1 = lane & 4, sd2 = lane & 1, sd3 = lane & 2;
     for (unsigned tp = blockIdx.x * DG_WAVES + wave; tp < ntp; tp += gridDim.x * DG_WAVES) {
         const unsigned p = tp * 32u + lr;
         const bool live = p < a.P;
@@ -363,8 +368,12 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgr
         TSTAMP(52);
         const u16* zrow = a.z + (size_t)pc * a.ldz + 8 * lh;
         u16* yrow = a.y + (size_t)pc * a.ldy + 8 * lh;
-#pragma unroll 1
-        for (int step = 0; step < 2; ++step) {
+        // opaque per-tile bases: with the two steps written out the weight / parameter addresses are tile-invariant and the compiler would
+        // hoist all 72 weight fragments + 32 parameter vectors out of the tile loop (spills)
+        int wlane = (lr * D3_WPITCH + lh * 8) * 2, plane = 8 * lh;
+        asm volatile("" : "+v"(wlane), "+v"(plane));
+        auto do_step = [&](auto step_c) {
+            constexpr int step = decltype(step_c)::value;
             u32x4 zv[4], outv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) zv[i] = *(const u32x4*)(zrow + step * 64 + 16 * i);
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgr
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                const u16* wrow = s_w + (ct + lr) * D3_WPITCH + lh * 8;
+                const u16* wrow = (const u16*)((const unsigned char*)s_w + wlane) + ct * D3_WPITCH;
 #pragma unroll
                 for (int ks = 0; ks < 18; ++ks) {
                     const u32x4 wf = *(const u32x4*)(wrow + ks * 16);
@@ -390,27 +399,23 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgr
                         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * r + q]), __float_as_uint(acc[8 * r + 4 + q]), false, false);
                         G[q] = __uint_as_float(sw[0]); G[4 + q] = __uint_as_float(sw[1]);
                     }
-                    const int cl = ct + 16 * r + 8 * lh;
-                    float zf[8], o[8];
+                    const int cp = ct + 16 * r + plane;
+                    float zf[8], o[8], e1[8], e2[8];
                     Vec16<u16>::unpack(zv[2 * t + r], zf);
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const f32x4 sc = *(const f32x4*)(s_par + cl + 4 * h), sh = *(const f32x4*)(s_par + 128 + cl + 4 * h);
-                        const f32x4 a1 = *(const f32x4*)(s_par + 256 + cl + 4 * h), a0 = *(const f32x4*)(s_par + 384 + cl + 4 * h);
-                        float e1[4], e2[4];
+                        const f32x4 sc = *(const f32x4*)(s_par + cp + 4 * h), sh = *(const f32x4*)(s_par + 128 + cp + 4 * h);
+                        const f32x4 a1 = *(const f32x4*)(s_par + 256 + cp + 4 * h), a0 = *(const f32x4*)(s_par + 384 + cp + 4 * h);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int e = 4 * h + q;
                             const bool keep = live && (!a.relu || fmaf(zf[e], sc[q], sh[q]) > 0.f);
                             const float Gv = keep ? G[e] : 0.f;
-                            e1[q] = half_wave_sum(Gv); e2[q] = half_wave_sum(Gv * fmaf(zf[e], a1[q], a0[q]));
+                            e1[e] = Gv; e2[e] = Gv * fmaf(zf[e], a1[q], a0[q]);
                             o[e] = Gv;
                         }
-                        if (lr == 31) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) { atomicAdd(&s_sum[cl + 4 * h + q], e1[q]); atomicAdd(&s_sum[128 + cl + 4 * h + q], e2[q]); }
-                        }
                     }
+                    red[step][2 * t + r] += row_transpose_sum(e1, e2, sd0, sd1, sd2, sd3);
                     outv[2 * t + r] = Vec16<u16>::pack(o);
                 }
                 TSTAMP(55);
@@ -420,14 +425,33 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgr
                 for (int i = 0; i < 4; ++i) *(u32x4*)(yrow + step * 64 + 16 * i) = outv[i];
             }
             TSTAMP(56);
-        }
+        };
+        do_step(std::integral_constant<int, 0>{});
+        do_step(std::integral_constant<int, 1>{});
     }
     TSTAMP(57);
+    // block-level fold of the register accumulators through the (now idle) weight area: see dense_dgrad_kernel
+    __syncthreads();
+    float* s_red = (float*)d_smem;                       // [wave][step * 4 + k][64 lanes]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_red[(wave * 8 + i * 4 + k) * 64 + lane] = red[i][k];
     __syncthreads();
     const size_t ro = (size_t)(blockIdx.x % a.reps) * a.rstride;
-    for (int i = threadIdx.x; i < 128; i += NT) {
-        atomicAdd(&a.sums[ro + i], (double)s_sum[i]);
-        atomicAdd(&a.sums[ro + 128 + i], (double)s_sum[128 + i]);
+    for (int c = threadIdx.x; c < 128; c += NT) {
+        const int reg = (c >> 6) * 4 + ((c >> 4) & 3);
+        const int l0 = 32 * ((c >> 3) & 1) + 4 * (c & 1) + 2 * ((c >> 2) & 1) + ((c >> 1) & 1);
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < DG_WAVES; ++w)
+#pragma unroll
+            for (int row = 0; row < 2; ++row) {
+                const float* q = s_red + (w * 8 + reg) * 64 + l0 + 16 * row;
+                t1 += q[0]; t2 += q[8];
+            }
+        atomicAdd(&a.sums[ro + c], (double)t1);
+        atomicAdd(&a.sums[ro + 128 + c], (double)t2);
     }
 }
 
@@ -448,7 +472,7 @@ int dense_dgrad3_forward(const saunet_conv_desc* d, const void* x, const void* w
     a.sums = epi->sums; a.reps = epi->sums_replicas > 1 ? epi->sums_replicas : 1; a.rstride = epi->sums_rstride;
     a.N = d->N; a.H = d->H; a.W = d->W; a.P = (unsigned)((long)d->N * d->H * d->W); a.relu = epi->relu;
     a.dW = FastDiv::make((unsigned)d->W); a.dHW = FastDiv::make((unsigned)(d->H * d->W));
-    const size_t lds = (size_t)128 * D3_WPITCH * 2 + sizeof(float) * 6 * 128;
+    const size_t lds = (size_t)128 * D3_WPITCH * 2 + sizeof(float) * 4 * 128;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
     long bx = 512; const long maxbx = ((long)a.P + 32 * DG_WAVES - 1) / (32 * DG_WAVES);
