@@ -391,6 +391,12 @@ template <typename T> static int dispatch_fwd(const IgemmArgs& a, int phases, hi
     } else {
         // small problems (low-resolution maps): 64x64 tiles so that the grid still covers the 256 CUs
         const long blocks128 = (long)cdiv(a.M, 128) * cdiv(a.Cout, 128) * phases;
+        // opt-in (SAUNET_IGEMM_T32=<workgroup threshold>): 32-row tiles of two waves for tiny problems (16 x 16 maps: 256 workgroups of 64 x 64
+        // tiles, one per CU) so that two K loops overlap on every CU.  Measured (same-box A/B, threshold 384): +0.1 ms per step
+        static const long t32 = getenv("SAUNET_IGEMM_T32") ? atol(getenv("SAUNET_IGEMM_T32")) : 0;
+        const long blocks64 = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64) * phases;
+        if (blocks64 < t32 && !a.epi.bn_x)
+            return narrow ? launch_fwd<T, 32, 64, 32, 32, 4>(a, phases, st) : launch_fwd<T, 32, 64, 32, 32, 8>(a, phases, st);
         if (blocks128 < 384)
             return narrow ? launch_fwd<T, 64, 64, 32, 32, 4>(a, phases, st) : launch_fwd<T, 64, 64, 32, 32, 8>(a, phases, st);
         return narrow ? launch_fwd<T, 128, 128, 64, 64, 4>(a, phases, st) : launch_fwd<T, 128, 128, 64, 64, 8>(a, phases, st);

@@ -1306,6 +1306,13 @@ int tile_wgrad_grouped(const saunet_wgrad_group* s, void* ws, size_t ws_bytes, s
     for (int i = s->count; i < SAUNET_WGRAD_GROUP_MAX; ++i) g.item[i] = GWItem{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
     if (s->dtype == SAUNET_BF16) {
         if (s->KH == 3) {
+            // opt-in (SAUNET_WGRAD3_WIDE=1), DenseNet conv2 (128 -> 32): one workgroup takes ALL 128 input channels of a pixel tile (its four
+            // waves 32 each), so the dy tile is staged once instead of once per 32-channel input tile.  Measured (same-box A/B): +0.15 ms per
+            // step -- two 66 KB workgroups per CU overlap less than four 37 KB ones
+            static const bool wide = getenv("SAUNET_WGRAD3_WIDE") && getenv("SAUNET_WGRAD3_WIDE")[0] == '1';
+            bool all_128_32 = true;
+            for (int i = 0; i < s->count; ++i) if (s->item[i].Cout > 32 || s->item[i].Cin % 128) all_128_32 = false;
+            if (wide && all_128_32) return launch_tile_wgrad_grouped<u16, 3, 8, 32, 128, 32, 32, 1>(g, s, ws, ws_bytes, need, st);
             if (small) return launch_tile_wgrad_grouped<u16, 3, 16, 32, 32, 32, 32, 4>(g, s, ws, ws_bytes, need, st);
             return launch_tile_wgrad_grouped<u16, 3, 8, 64, 64, 32, 32, 1>(g, s, ws, ws_bytes, need, st);
         }

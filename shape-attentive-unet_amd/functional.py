@@ -773,7 +773,7 @@ class _ConvBNAct(torch.autograd.Function):
         if has_bias:
             # a bias in front of a training-mode BatchNorm has an exactly zero gradient (sum of dz over the batch is 0)
             cout = dz.shape[1]
-            db = torch.zeros(cout, dtype=torch.float32, device=dz.device) if training else channel_sum(dz)
+            db = (GRADS.take(cout, dz.device) if dz.is_cuda else torch.zeros(cout, dtype=torch.float32, device=dz.device)) if training else channel_sum(dz)
         return dx, dw, db, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
@@ -1268,7 +1268,7 @@ class _DualAttTail(torch.autograd.Function):
         dt = L.dtype_code(F)
         L.call("saunet_att_combine_backward", dt, F.data_ptr(), ld_of(F), S.data_ptr(), se.data_ptr(), dout.data_ptr(), ld_of(dout),
                dF.data_ptr(), ld_of(dF), dS.data_ptr(), dse.data_ptr(), n, h * w, c, L.stream())
-        g = torch.zeros(2 * c * cr + c + cr, dtype=torch.float32, device=dev)
+        g = GRADS.take(2 * c * cr + c + cr, dev) if F.is_cuda else torch.zeros(2 * c * cr + c + cr, dtype=torch.float32, device=dev)
         dw1, db1 = g[:cr * c], g[cr * c:cr * c + cr]
         dw2, db2 = g[cr * c + cr:2 * cr * c + cr], g[2 * cr * c + cr:]
         dpooled = torch.empty(n, c, dtype=torch.float32, device=dev)
@@ -1351,7 +1351,7 @@ class _DualLoss(torch.autograd.Function):
         edge_t = edge_t.to(device=dev, dtype=torch.float32).contiguous()
         if seg_t.numel() != P or edge_t.numel() != P:
             raise RuntimeError("DualLoss: target sizes %s / %s do not match logits %s" % (tuple(seg_t.shape), tuple(edge_t.shape), tuple(logits.shape)))
-        sums = torch.zeros(32, dtype=torch.float64, device=dev)
+        sums = STATS.take(32, dev) if logits.is_cuda else torch.zeros(32, dtype=torch.float64, device=dev)
         L.call("saunet_dual_loss_forward", L.F32, logits.data_ptr(), ld_of(logits), edge.data_ptr(), seg_t.data_ptr(), edge_t.data_ptr(), P,
                sums.data_ptr(), L.stream())
         out = torch.empty(5, dtype=torch.float32, device=dev)
