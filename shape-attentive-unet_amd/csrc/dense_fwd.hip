@@ -490,6 +490,10 @@ __global__ __launch_bounds__(DF_THREADS, 1) void dense_block_fwd_kernel(DenseFwd
         load_stats(cin, cin + 32);
         __syncthreads();
     }
+    // a barrier that expired (workgroups not co-resident: CU masking, a second process on the device) left wrong numbers behind; nobody may
+    // train on them silently -- the run must fail loudly: poison the block's statistics, every later BatchNorm and the loss turn NaN
+    if (bid == 0 && tid == 0 && __hip_atomic_load(&a.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+        d.stats[0] = __builtin_nan("");
 }
 
 }  // namespace saunet

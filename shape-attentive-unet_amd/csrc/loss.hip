@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void softmax_argmax_kernel(const T* __restrict
         for (int c = 0; c < C; ++c) z[c] = Elem<T>::load(logits + p * ldl + c);
         float m = z[0]; int am = 0;
 #pragma unroll
-        for (int c = 1; c < C; ++c) if (z[c] > m) { m = z[c]; am = c; }
+        for (int c = 1; c < C; ++c) if (z[c] > m || (z[c] != z[c] && m == m)) { m = z[c]; am = c; }     // first maximum; a NaN wins (torch.argmax)
         if (prob) {
             float e[C], sum = 0.f;
 #pragma unroll
@@ -150,6 +150,25 @@ __global__ __launch_bounds__(256) void softmax_argmax_kernel(const T* __restrict
             const float inv = 1.f / sum;
 #pragma unroll
             for (int c = 0; c < C; ++c) prob[p * ldp + c] = e[c] * inv;
+        }
+        if (label) label[p] = am;
+    }
+}
+
+// any class count (runtime loop, two passes over the pixel's logits): the num_class != 2 / 4 / 8 case of a drop-in user
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_argmax_generic_kernel(const T* __restrict__ logits, int ldl, long P, int C, float* __restrict__ prob,
+                                                                     int ldp, int64_t* __restrict__ label)
+{
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        const T* row = logits + p * ldl;
+        float m = Elem<T>::load(row); int am = 0;
+        for (int c = 1; c < C; ++c) { const float z = Elem<T>::load(row + c); if (z > m || (z != z && m == m)) { m = z; am = c; } }
+        if (prob) {
+            float sum = 0.f;
+            for (int c = 0; c < C; ++c) sum += expf(Elem<T>::load(row + c) - m);
+            const float inv = 1.f / sum;
+            for (int c = 0; c < C; ++c) prob[p * ldp + c] = expf(Elem<T>::load(row + c) - m) * inv;
         }
         if (label) label[p] = am;
     }
@@ -194,10 +213,17 @@ int saunet_dual_loss_backward(int dtype, const void* logits, int ldl, const void
 
 int saunet_softmax_argmax(int dtype, const void* logits, int ldl, int64_t pixels, int C, float* prob, int ldp, int64_t* label, void* stream)
 {
-    if (C != 2 && C != 4 && C != 8) return set_error(SAUNET_UNSUPPORTED, "softmax_argmax: %d classes (2, 4 or 8)", C);
+    if (C < 1) return set_error(SAUNET_BAD_SHAPE, "softmax_argmax: %d classes", C);
     if (!prob && !label) return set_error(SAUNET_BAD_SHAPE, "softmax_argmax: no output requested");
     long b = (pixels + 255) / 256; if (b > 4096) b = 4096; if (b < 1) b = 1;
     hipStream_t st = (hipStream_t)stream;
+    if (C != 2 && C != 4 && C != 8) {
+        if (dtype == SAUNET_F32) hipLaunchKernelGGL(softmax_argmax_generic_kernel<float>, dim3((unsigned)b), dim3(256), 0, st, (const float*)logits, ldl, (long)pixels, C, prob, ldp, label);
+        else if (dtype == SAUNET_BF16) hipLaunchKernelGGL(softmax_argmax_generic_kernel<u16>, dim3((unsigned)b), dim3(256), 0, st, (const u16*)logits, ldl, (long)pixels, C, prob, ldp, label);
+        else return set_error(SAUNET_BAD_DTYPE, "softmax_argmax: dtype %d", dtype);
+        SAUNET_CHECK_LAUNCH("softmax_argmax");
+        return SAUNET_OK;
+    }
 #define SM(TT, CC) hipLaunchKernelGGL((softmax_argmax_kernel<TT, CC>), dim3((unsigned)b), dim3(256), 0, st, (const TT*)logits, ldl, (long)pixels, prob, ldp, label)
 #define SMT(TT) do { if (C == 2) SM(TT, 2); else if (C == 4) SM(TT, 4); else SM(TT, 8); } while (0)
     if (dtype == SAUNET_F32) SMT(float);

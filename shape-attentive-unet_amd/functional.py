@@ -229,6 +229,11 @@ class InferenceCache:
         if ent is not None and ent[0] == vers and all(r() is t for r, t in zip(ent[1], tensors)):
             return ent[2]
         val = build()
+        if capturing():
+            # built inside a capture: its buffers belong to the graph's memory pool and hold nothing until the first replay -- serve it to
+            # this capture only, never from the cache to a later eager call
+            self.retired.append(val)
+            return val
         if ent is not None and self.seen_capture:
             self.retired.append(ent[2])
         if len(self.entries) > 4096:
@@ -1046,11 +1051,11 @@ class _Cast(torch.autograd.Function):
     """storage-dtype conversion (bf16 <-> float32) of an activation; the gradient is cast back."""
 
     @staticmethod
-    def forward(ctx, x, dtype):
+    def forward(ctx, x, dtype, out=None):
         x = nhwc(x)
         n, c, h, w = x.shape
         ctx.src_dtype = x.dtype
-        y = new_act(n, c, h, w, dtype, x.device)
+        y = out if out is not None else new_act(n, c, h, w, dtype, x.device)
         copy_channels(x, y)
         return y
 
@@ -1060,11 +1065,14 @@ class _Cast(torch.autograd.Function):
         n, c, h, w = dy.shape
         dx = new_act(n, c, h, w, ctx.src_dtype, dy.device)
         copy_channels(dy, dx)
-        return dx, None
+        return dx, None, None
 
 
-def cast(x, dtype):
-    return x if x.dtype == dtype else _Cast.apply(x, dtype)
+def cast(x, dtype, out=None):
+    """out: optional destination of dtype `dtype` (a channel slice of a concat buffer); written even when no conversion is needed."""
+    if x.dtype == dtype and out is None:
+        return x
+    return _Cast.apply(x, dtype, out)
 
 
 class _GateMul(torch.autograd.Function):

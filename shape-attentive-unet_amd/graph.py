@@ -24,12 +24,12 @@ class GraphedStep:
             raise RuntimeError("GraphedStep needs the GPU (no CPU fallback)")
         self.changes_params = changes_params
         self.optimizers = list(optimizers)
-        for o in self.optimizers:
-            o.upload_hyper()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(max(warmup, 1)):
+                for o in self.optimizers:          # every warm-up iteration is a real step: it needs its own bias-correction / step-size terms
+                    o.upload_hyper()
                 fn()
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()

@@ -85,7 +85,11 @@ class ConvBNReLU(nn.Sequential):
         direct = out is not None and (out_dtype is None or out_dtype == x.dtype)
         y = HF.conv_bn_act(x, conv.weight, conv.bias, bn, relu=True, stride=conv.stride[0], padding=conv.padding[0], out=out if direct else None,
                            pool=pool)
-        return y if out_dtype is None or out_dtype == y.dtype else HF.cast(y, out_dtype)
+        if out_dtype is None or out_dtype == y.dtype:
+            return y
+        # a cast is needed (e.g. the float32 edge head feeding a bf16 decoder outside the fused `expand` kernel: eval mode with gradients, or
+        # num_filters other than 32 / 64): the cast itself then writes the caller's destination slice, so cat_alias still finds the piece in place
+        return HF.cast(y, out_dtype, out=out)
 
 
 def conv3x3_bn_relu(in_planes, out_planes, stride=1):

@@ -252,3 +252,49 @@ def test_inference_path_folded_and_cached(dtype, tol):
         assert float((lg3.float().cpu() - lg3_o).abs().max()) < tol * float(lg3_o.abs().max())
     finally:
         S.set_compute_dtype(torch.float32)
+
+
+def test_eval_mode_with_gradients_in_bf16_storage():
+    """eval mode WITH gradients (--fix_bn, the saliency scripts) in bf16 storage takes the unfused `expand` path, whose float32
+    result is cast into the decoder's concat slice -- the forward must not trip cat_alias, and loss + gradients must follow the fp32 oracle
+    as closely as bf16 storage allows (the same bounds as test_bf16_storage_tracks_fp32_oracle)."""
+    seed = 23
+    S, spec, sd, net, sm = make_net(seed, torch.bfloat16)
+    try:
+        img, seg, edge = Wt.synthetic_batch(2, 64, 96, seed=141)
+        sdo = {k: v.clone() for k, v in sd.items()}
+        keys = Wt.trainable_keys(spec)
+        for k in keys:
+            sdo[k].requires_grad_(True)
+        loss_o, *_ = R.segmentation_step(sdo, img, seg, edge, False)
+        loss_o.backward()
+        sm.eval()
+        loss, _ = sm({"image": img.cuda(), "mask": (seg.cuda(), edge.cuda())}, 1)
+        loss.backward()
+        assert abs(float(loss) - float(loss_o)) < 3e-2 * max(1.0, float(loss_o)), (float(loss), float(loss_o))
+        pd = dict(net.named_parameters())
+        num = sum(float((pd[k].grad.cpu().double() - sdo[k].grad.double()).pow(2).sum()) for k in keys)
+        den = sum(float(sdo[k].grad.double().pow(2).sum()) for k in keys)
+        assert (num / den) ** 0.5 < 0.25, (num / den) ** 0.5
+        assert all(torch.isfinite(pd[k].grad).all() for k in keys)
+    finally:
+        S.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("C", [3, 5, 19])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_softmax_argmax_any_class_count(C, dtype):
+    """the device softmax / argmax head for class counts other than 2 / 4 / 8 (a 3-class dataset validates through it), incl. the
+    first-maximum tie rule and NaN-wins of torch.argmax."""
+    import saunet_amd as S
+    HF = S.functional
+    torch.manual_seed(C)
+    lg = torch.randn(2, C, 24, 40, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    lg[0, :, 3, 5] = 1.25                      # an all-equal pixel: argmax = 0
+    if dtype == torch.float32:
+        lg[1, C - 1, 7, 9] = float("nan")
+    prob, label = HF.softmax_argmax(lg)
+    ref = torch.softmax(lg.float(), 1)
+    ok = torch.isfinite(ref).all(1, keepdim=True).expand_as(ref)
+    assert float((prob - ref)[ok].abs().max()) < 1e-5
+    assert torch.equal(label, lg.float().argmax(1))
