@@ -15,6 +15,6 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $O/rf_writ
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/rf_sq -o p -- python $R/bench.py --roofline-only --no-launch-mix > $O/rf_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/cal_fetch -o p -- $R/scripts/probes/rowpiece_probe > $O/cal_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/cal_write -o p -- $R/scripts/probes/rowpiece_probe > $O/cal_write.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/step -o p -- python $R/bench.py --no-graph --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/step.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/step -o p -- python $R/bench.py --no-graph --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extras > $O/step.log 2>&1
 grep -h '"roofline"\|"metric"' $O/*.log | cut -c1-400
 ls $O

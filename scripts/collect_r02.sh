@@ -5,9 +5,9 @@ O=$R/gpurun_out/r02; mkdir -p $O
 cd $R
 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 python bench.py --infer --steps 30 > $O/bench_infer.json 2>> $O/bench.err
-python bench.py --steps 10 --warmup 3 --batch 64 --no-cpu-baseline --no-roofline > $O/bench_cfg3_b64.json 2>> $O/bench.err
-python bench.py --steps 10 --warmup 3 --size 512 --batch 8 --dtype f32 --no-cpu-baseline --no-roofline > $O/bench_cfg4_512_f32.json 2>> $O/bench.err
-python bench.py --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-roofline > $O/bench_eager.json 2>> $O/bench.err
+python bench.py --steps 10 --warmup 3 --batch 64 --no-cpu-baseline --no-roofline --no-extras > $O/bench_cfg3_b64.json 2>> $O/bench.err
+python bench.py --steps 10 --warmup 3 --size 512 --batch 8 --dtype f32 --no-cpu-baseline --no-roofline --no-extras > $O/bench_cfg4_512_f32.json 2>> $O/bench.err
+python bench.py --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-roofline --no-extras > $O/bench_eager.json 2>> $O/bench.err
 python scripts/fwd_micro.py > $O/micro_fwd.txt 2>&1
 python scripts/wgrad_micro.py > $O/micro_wgrad.txt 2>&1
 ( export SAUNET_HIP_LIB=scripts/_ab/libsaunet_timing.so; for c in conv2fwd conv2wgrad conv1wgrad dec3wgrad conv1dgrad dec3fwd conv1fwd dense3fwd; do python scripts/phase_timing.py $c 2>&1 | grep -v amdgpu.ids; done ) > $O/phase_timing.txt

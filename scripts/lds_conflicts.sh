@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/ldsc; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES -d $O -o p -- python $R/bench.py --no-graph --steps 4 --warmup 2 --no-cpu-baseline --no-roofline > $O.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES -d $O -o p -- python $R/bench.py --no-graph --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-extras > $O.log 2>&1
 python - <<PY > $R/gpurun_out/lds_conflicts.txt
 import sqlite3, collections, glob
 db = glob.glob("$O/**/p_results.db", recursive=True) + glob.glob("$O/p_results.db")

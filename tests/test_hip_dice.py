@@ -1,0 +1,62 @@
+"""The metric's second half -- validation Dice after TRAINING (BASELINE.json "val Dice vs ref"; /root/reference/train.py:25-64 eval, train.sh recipe):
+ (1) from one seeded initialisation the HIP path is trained 300 steps in float32 and in bf16 storage on synthetic phantoms and evaluated on
+     held-out phantoms: both must learn the task, the bf16 - float32 Dice difference must stay within the drift two float32 runs show on their
+     own (a third run from 1e-6-perturbed weights) and the loss curves must coincide;
+ (2) the float32 run is anchored to the CPU oracle: the first steps of the same training loop (same weights, same mini-batches, Adam) give
+     the oracle's loss curve within the float32 parity bound.
+The measured table is written to gpurun_out/r03_dice.json (copied to profiles/)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import saunet_ref as R, weights as Wt
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bf16_training_reaches_the_float32_dice():
+    from saunet_amd import dice
+    res = dice.run(size=128, batch=8, steps=300, pool=64, eval_n=32, seed=304, optimizer="radam", lr=2e-3, noise_floor=True)
+    slim = {k: ({kk: vv for kk, vv in v.items() if kk != "loss_curve"} if isinstance(v, dict) else v) for k, v in res.items()}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r03_dice.json"), "w") as f:
+        json.dump(slim, f, indent=1)
+    print(json.dumps(slim["delta"]))
+    f32, bf16, d = res["f32"], res["bf16"], res["delta"]
+    assert f32["mean_dice"] > 0.9 and bf16["mean_dice"] > 0.9, (f32["dice"], bf16["dice"])          # both learned the phantoms
+    assert f32["loss_last"] < 0.25 * f32["loss_first"] and bf16["loss_last"] < 0.25 * bf16["loss_first"]
+    # bf16 storage costs no Dice beyond the run-to-run drift of float32 training itself (floor: 3 Dice points for a 32-slice validation set)
+    assert d["max_abs_dice_delta"] <= max(3.0 * d["f32_noise_floor_max_abs_dice_delta"], 0.03), d
+    assert abs(d["mean_dice_delta"]) <= 0.02, d
+    assert d["loss_curve_rel_distance"] <= 0.05, d
+
+
+def test_float32_training_is_anchored_to_the_oracle():
+    """six Adam steps at 64 x 64, B = 2: the HIP float32 run of dice.run against the CPU oracle trained by torch.optim.Adam on the same weights
+    and mini-batches (train.py:197-201: Adam without weight decay)."""
+    from saunet_amd import dice, data as sdata
+    spec = R.state_dict_spec()
+    sd = Wt.make_state_dict(spec, seed=77)
+    steps, B, pool, size, lr = 6, 2, 4, 64, 1e-3
+    res = dice.run(size=size, batch=B, steps=steps, pool=pool, eval_n=4, seed=500, optimizer="adam", lr=lr, dtypes=("f32",),
+                   state_dict={k: v.clone() for k, v in sd.items()})
+    keys = Wt.trainable_keys(spec)
+    sdo = {k: v.clone() for k, v in sd.items()}
+    for k in keys:
+        sdo[k].requires_grad_(True)
+    opt = torch.optim.Adam([sdo[k] for k in keys], lr=lr, betas=(0.9, 0.999))
+    img, seg, edge = sdata.synthetic_batch(pool, size, size, seed=500)
+    ref = []
+    for it in range(steps):
+        idx = [(it * B + j) % pool for j in range(B)]
+        opt.zero_grad()
+        loss, *_ = R.segmentation_step(sdo, img[idx], seg[idx], edge[idx], True)
+        loss.backward(); opt.step(); ref.append(float(loss))
+    got = np.array(res["f32"]["loss_curve"][:steps]); ref = np.array(ref)
+    assert np.abs(got[:2] - ref[:2]).max() < 2e-4 * max(1.0, abs(ref[0])), (got, ref)
+    assert np.abs(got - ref).max() < 2e-2 * max(1.0, abs(ref[0])), (got, ref)       # Adam's 1/sqrt(v) amplifies last-bit gradient differences
+    assert ref[-1] < ref[0]
