@@ -38,8 +38,8 @@ def parse():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
-    ap.add_argument("--graph-dp", action="store_true", help="N>1: capture fwd+bwd (incl. the SyncBN all-reduces) in a hipGraph too; "
-                    "default for N>1 is eager launches with the bucket all-reduces overlapped with backward")
+    ap.add_argument("--dry-run", action="store_true", help="host-side rehearsal of the N>1 path WITHOUT a GPU (gloo): real SAUNet parameter set, "
+                    "synthetic gradients, bucketed all-reduce overlapped with the backward hooks, timing protocol and JSON line; no kernel runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "radam"])
@@ -373,6 +373,72 @@ def infer_bench(args, S, dev, dtype):
             "achieved_tflops_algorithmic": round(args.batch * args.steps / dt * 72.15 * scale / 1e3, 2)}
 
 
+def dry_run(args, S, dp):
+    """`--dry-run`: everything of the N-rank path that does not need a GPU, end to end over gloo -- environment bootstrap, parameter broadcast,
+    gradient buckets in reverse registration order with their post-accumulate hooks, overlapped all-reduce + averaged write-back, the timing
+    protocol (barrier, K steps, max over ranks) and rank 0's JSON line with the `comm` record.  The step itself is a stand-in (a gradient of
+    the right shape for every SAUNet parameter); the CPU suite runs this with two ranks (tests/test_bench_dry.py)."""
+    rank, local, world = dp.init_from_env(backend="gloo")
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.manual_seed(304 + rank)                     # different replicas before the broadcast
+    net = S.SAUNet(num_classes=4)
+    dp.broadcast_parameters(net)
+    params = [p for p in net.parameters() if p.requires_grad]
+    buckets = dp.GradientBuckets(params, bucket_mb=args.bucket_mb, overlap=True) if world > 1 else None
+    if buckets is not None:
+        buckets.time_finish = True
+    lr = 5e-4
+
+    def step(it):
+        for p in params:
+            p.grad = None
+        loss = sum((p * float(rank + 1 + it)).sum() for p in params)
+        loss.backward()                               # hooks launch each bucket's all-reduce as soon as it is complete
+        if buckets is not None:
+            buckets.finish()
+        with torch.no_grad():
+            for p in params:
+                p.add_(p.grad, alpha=-lr)
+        return loss.detach()
+    for it in range(max(args.warmup, 1)):
+        step(it)
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        loss = step(it)
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt)
+    # every rank must hold the same averaged gradient and the same parameters afterwards
+    want = sum(float(r + 1 + args.steps - 1) for r in range(world)) / world
+    gerr = max(float((p.grad - want).abs().max()) for p in params[:8] + params[-8:])
+    chk = torch.tensor([float(params[0].detach().double().sum()), float(params[-1].detach().double().sum())], dtype=torch.float64)
+    lo, hi = chk.clone(), chk.clone()
+    if world > 1:
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN); torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+    if rank == 0:
+        payload = sum(p.numel() for p in params) * 4
+        print(json.dumps({
+            "metric": "DRY RUN of the N-rank host path (no GPU work): 2D slices/sec (train fwd+bwd+allreduce+SGD) at %dx%d" % (args.size, args.size),
+            "value": None, "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "none (stand-in gradients)", "dry_run": True,
+            "config": {"workload": "dry run: SAUNet parameter set, stand-in step", "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "mode": "eager, bucketed all-reduce overlapped with backward hooks"},
+            "comm": {"backend": torch.distributed.get_backend() if world > 1 else None, "rccl_ranks": 0,
+                     "buckets": len(buckets.buckets) if buckets is not None else 0, "bucket_mb": args.bucket_mb, "allreduce_payload_bytes": payload,
+                     "bucket_table_last_step": buckets.bucket_table() if buckets is not None else [],
+                     "averaged_gradient_max_err": gerr, "replicas_identical": bool(torch.equal(lo, hi))}}), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
     import saunet_amd as S
@@ -389,9 +455,13 @@ def main():
         S.set_compute_dtype(dtype)
         print(json.dumps(infer_bench(args, S, torch.device("cuda", 0), dtype)), flush=True)
         return
+    if args.dry_run:
+        return dry_run(args, S, dp)
     rank, local, world = dp.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1 and torch.distributed.get_backend() == "nccl" and torch.distributed.get_world_size() != world:
+        raise SystemExit("RCCL group has %d ranks, expected %d" % (torch.distributed.get_world_size(), world))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -401,7 +471,7 @@ def main():
     sm = S.SegmentationModule(S.DualLoss(mode="train"), net, 4).train()
     dp.broadcast_parameters(net)
     opt = optim.create_optimizers(net, args.optimizer, lr=5e-4, momentum=0.9, weight_decay=1e-4)[0]
-    use_graph = (not args.no_graph) and (world == 1 or args.graph_dp)
+    use_graph = (not args.no_graph) and world == 1      # N > 1: eager launches, bucket all-reduces overlapped with the backward kernels
     buckets = dp.GradientBuckets(list(net.parameters()), bucket_mb=args.bucket_mb, overlap=not use_graph) if world > 1 else None
     if buckets is not None:
         buckets.time_finish = True
@@ -446,8 +516,8 @@ def main():
 
             # weight re-packing is recorded INSIDE the graph (functional.PackedWeights.prepack under capture), so every replay trains
             # on the weights its predecessor's optimiser step produced
-            graph = GraphedStep(captured, warmup=1, optimizers=[opt] if world == 1 else [])
-            mode = "hipgraph(fwd+bwd+opt)" if world == 1 else "hipgraph(fwd+bwd)+eager(allreduce+opt)"
+            graph = GraphedStep(captured, warmup=1, optimizers=[opt])
+            mode = "hipgraph(fwd+bwd+opt)"
             graph.replay(); torch.cuda.synchronize()
         except Exception as e:  # capture unsupported -> measured eagerly, and said so in the JSON
             graph = None
@@ -486,9 +556,10 @@ def main():
         if buckets is not None and buckets.exposed_events is not None:
             exposed = buckets.exposed_events[0].elapsed_time(buckets.exposed_events[1])
         payload = sum(p.numel() for p in buckets.params) * 4 if buckets is not None else 0
-        comm = {"backend": torch.distributed.get_backend(), "rccl_ranks": world if torch.distributed.get_backend() == "nccl" else 0,
-                "buckets": len(buckets.buckets) if buckets is not None else 0, "allreduce_payload_bytes": payload,
+        comm = {"backend": torch.distributed.get_backend(), "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.get_backend() == "nccl" else 0,
+                "buckets": len(buckets.buckets) if buckets is not None else 0, "bucket_mb": args.bucket_mb, "allreduce_payload_bytes": payload,
                 "exposed_allreduce_ms_last_step": None if exposed is None else round(exposed, 3),
+                "bucket_table_last_step": buckets.bucket_table() if buckets is not None else [],
                 "syncbn_allreduces_per_step": 12}
     final_loss = float(loss.detach().float())
 

@@ -102,6 +102,8 @@ class GradientBuckets:
         self.first_step_done = False
         self.exposed_events = None        # (start, end) HIP events around the wait+unpack of finish(), if timing is enabled
         self.time_finish = False
+        self.trace = None                 # time_finish: per-bucket record of the last step, see bucket_table()
+        self._t0 = None
         self._build(self.params)
 
     def _build(self, params):
@@ -153,6 +155,15 @@ class GradientBuckets:
             self.flat[b].zero_()      # first step only: slots of gradient-less parameters travel as zeros (every rank agrees)
         if grads:
             _copy((grads, views), True, 1.0)
+        if self.time_finish:
+            import time
+            if self.trace is None or len(self.trace) != len(self.buckets) or all(t.get("waited") for t in self.trace):
+                self.trace = [{} for _ in self.buckets]
+                self._t0 = time.perf_counter()
+            rec = self.trace[b]
+            rec.update(bucket=b, numel=int(self.flat[b].numel()), host_launch_ms=(time.perf_counter() - self._t0) * 1e3)
+            if self.flat[b].is_cuda:
+                rec["ev_launch"] = torch.cuda.Event(enable_timing=True); rec["ev_launch"].record()
         self.handles[b] = dist.all_reduce(self.flat[b], group=self.group, async_op=True)
 
     def _on_grad(self, p):
@@ -173,10 +184,20 @@ class GradientBuckets:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         for b in range(len(self.buckets)):
+            if self.time_finish and self.trace is not None:
+                import time
+                self.trace[b]["host_wait_start_ms"] = (time.perf_counter() - self._t0) * 1e3
             self.handles[b].wait()
             grads, views = self._present(b)
             if grads:
                 _copy((grads, views), False, 1.0 / self.world)
+            if self.time_finish and self.trace is not None:
+                import time
+                rec = self.trace[b]
+                rec["host_wait_end_ms"] = (time.perf_counter() - self._t0) * 1e3
+                rec["waited"] = True
+                if self.flat[b].is_cuda:
+                    rec["ev_done"] = torch.cuda.Event(enable_timing=True); rec["ev_done"].record()
         if ev is not None:
             ev[1].record()
             self.exposed_events = ev
@@ -187,6 +208,32 @@ class GradientBuckets:
                 self._build(used)
                 return
         self.reset()
+
+    def bucket_table(self):
+        """Per-bucket view of the LAST step's gradient exchange (time_finish=True): when each bucket's all-reduce was launched (relative to the first
+        launch of the step) and when the compute stream had it back, so exposed vs hidden exchange time is a table, not one number.  On the GPU
+        the times are HIP-event times on the compute stream; `exposed_ms` of bucket b = what the stream waited for it beyond its predecessor.
+        Synchronises the device."""
+        if not self.trace:
+            return []
+        rows, prev_done = [], None
+        cuda = all("ev_launch" in t and "ev_done" in t for t in self.trace)
+        if cuda:
+            torch.cuda.synchronize()
+        first = self.trace[min(range(len(self.trace)), key=lambda i: self.trace[i].get("host_launch_ms", 0.0))]
+        for t in self.trace:
+            row = {"bucket": t.get("bucket"), "MB": round(t.get("numel", 0) * 4 / 1e6, 2), "host_launch_ms": round(t.get("host_launch_ms", 0.0), 3),
+                   "host_wait_ms": round(t.get("host_wait_end_ms", 0.0) - t.get("host_wait_start_ms", 0.0), 3)}
+            if cuda:
+                row["launch_ms"] = round(first["ev_launch"].elapsed_time(t["ev_launch"]), 3)
+                row["done_ms"] = round(first["ev_launch"].elapsed_time(t["ev_done"]), 3)
+                if self.exposed_events is not None:
+                    start = first["ev_launch"].elapsed_time(self.exposed_events[0])
+                    base = max(start, prev_done if prev_done is not None else start)
+                    row["exposed_ms"] = round(max(0.0, row["done_ms"] - base), 3)
+                prev_done = row["done_ms"]
+            rows.append(row)
+        return rows
 
     def remove_hooks(self):
         for h in self.hooks:
