@@ -179,6 +179,8 @@ def test_fp32_512_against_oracle():
     for k in keys:
         err = float((pd[k].grad.cpu() - ga[k]).abs().max())
         assert err < 1e-3 * gmax, (k, err, gmax)
+    from tests.golden_util import assert_grads_per_tensor
+    assert_grads_per_tensor({k: pd[k].grad for k in keys}, ga, keys)           # configs[4] geometry: every tensor on its own scale
 
 
 @pytest.mark.parametrize("dtype,B", [(torch.bfloat16, 32), (torch.float32, 4)])

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import saunet_ref as R, weights as Wt
-from tests.golden_util import load, close
+from tests.golden_util import load, close, assert_grads_per_tensor
 
 pytestmark = pytest.mark.gpu
 
@@ -105,6 +105,7 @@ def test_other_shapes_against_oracle(B, H, W, seed):
     for k in keys:
         err = float((pd[k].grad.cpu() - sdo[k].grad).abs().max())
         assert err < 1e-3 * gmax, (k, err, gmax)
+    assert_grads_per_tensor({k: pd[k].grad for k in keys}, {k: sdo[k].grad for k in keys}, keys)      # every tensor on its OWN scale
 
 
 def test_fix_bn_training_step_against_oracle():
@@ -128,6 +129,7 @@ def test_fix_bn_training_step_against_oracle():
     for k in keys:
         err = float((pd[k].grad.cpu() - sdo[k].grad).abs().max())
         assert err < 1e-3 * gmax, (k, err, gmax)
+    assert_grads_per_tensor({k: pd[k].grad for k in keys}, {k: sdo[k].grad for k in keys}, keys)
     # running statistics untouched
     for k, v in net.state_dict().items():
         if k.endswith("running_mean") and "_tmp" not in k and k in sd:
