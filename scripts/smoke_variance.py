@@ -6,7 +6,7 @@ import saunet_amd
 from oracle import saunet_ref as R, weights as Wt
 spec = R.state_dict_spec()
 sd = Wt.make_state_dict(spec, seed=5)
-img, seg, edge = Wt.synthetic_batch(2, 128, 128, seed=41)
+img, seg, edge = Wt.synthetic_batch(2, 64, 64, seed=41)
 sdo = {k: v.clone() for k, v in sd.items()}
 keys = Wt.trainable_keys(spec)
 for k in keys:

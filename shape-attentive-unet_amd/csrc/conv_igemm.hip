@@ -236,12 +236,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void conv_igemm_fwd_
     }
 
     // ---- epilogue: statistics, bias, transpose through LDS, coalesced stores
-    float* s_sum = (float*)(smem + BM * BN * sizeof(T));
-    float* s_sq = s_sum + BN;
+    // per-channel partial sums of the waves that share a column range: one SLOT per row-wave, added in a fixed order below (float atomics on
+    // LDS made the sum depend on the waves' arrival order -- and cost 12 cycles per active lane)
+    constexpr int RW = BM / WM;
+    float* s_sum = (float*)(smem + BM * BN * sizeof(T));          // [RW][2][BN]
     const bool do_stats = a.stat_sum != nullptr;
-    if (do_stats) {
-        for (int i = tid; i < 2 * BN; i += NT) s_sum[i] = 0.f;
-    }
     __syncthreads();
     T* so = (T*)smem;
     const int lr = lane & 31, lh = lane >> 5;
@@ -261,16 +260,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void conv_igemm_fwd_
             }
         if (do_stats) {
             s += __shfl_xor(s, 32, 64); ss += __shfl_xor(ss, 32, 64);
-            if (lh == 0) { atomicAdd(&s_sum[col], s); atomicAdd(&s_sq[col], ss); }
+            if (lh == 0) { float* slot = s_sum + (wave / (BN / WN)) * 2 * BN; slot[col] = s; slot[BN + col] = ss; }
         }
     }
     TSTAMP(71);
     __syncthreads();
     TSTAMP(72);
     if (do_stats && tid < BN && n0 + tid < a.Cout) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < RW; ++w) { t1 += s_sum[w * 2 * BN + tid]; t2 += s_sum[w * 2 * BN + BN + tid]; }
         const size_t ro = (size_t)(blockIdx.x % a.stat_replicas) * a.stat_rstride;
-        atomicAdd(&a.stat_sum[ro + n0 + tid], (double)s_sum[tid]);
-        atomicAdd(&a.stat_sumsq[ro + n0 + tid], (double)s_sq[tid]);
+        atomicAdd(&a.stat_sum[ro + n0 + tid], (double)t1);
+        atomicAdd(&a.stat_sumsq[ro + n0 + tid], (double)t2);
     }
     TSTAMP(73);
     constexpr int CH = BN / EPC;  // 16-byte chunks per output row
@@ -336,18 +338,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void conv_igemm_fwd_
         if (okv[i]) *(u32x4*)(yg + opixv[i] * a.ldy + colv) = v;
     }
     TSTAMP(70);
-    if (bnb) {   // NT % CH == 0: a thread always owns the same EPC channels -> one LDS atomic per channel per thread
+    if (bnb) {   // NT % CH == 0: a thread always owns the same EPC channels -> its partial sums go to slot tid / CH of the (now idle) tile area
         __syncthreads();
-        for (int i = tid; i < 2 * BN; i += NT) s_sum[i] = 0.f;
-        __syncthreads();
-        const int ch = tid % CH;
+        constexpr int SL = NT / CH;
+        float* s_e = (float*)smem;                                // [SL][2][BN]
+        const int ch = tid % CH, sl = tid / CH;
 #pragma unroll
-        for (int j = 0; j < EPC; ++j) { atomicAdd(&s_sum[ch * EPC + j], e1[j]); atomicAdd(&s_sq[ch * EPC + j], e2[j]); }
+        for (int j = 0; j < EPC; ++j) { s_e[(sl * 2) * BN + ch * EPC + j] = e1[j]; s_e[(sl * 2 + 1) * BN + ch * EPC + j] = e2[j]; }
         __syncthreads();
         if (tid < BN && n0 + tid < a.Cout) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int w = 0; w < SL; ++w) { t1 += s_e[(w * 2) * BN + tid]; t2 += s_e[(w * 2 + 1) * BN + tid]; }
             const size_t ro = (size_t)(blockIdx.x % a.epi.sums_replicas) * a.epi.sums_rstride;
-            atomicAdd(&a.epi.sums[ro + n0 + tid], (double)s_sum[tid]);
-            atomicAdd(&a.epi.sums[ro + a.Cout + n0 + tid], (double)s_sq[tid]);
+            atomicAdd(&a.epi.sums[ro + n0 + tid], (double)t1);
+            atomicAdd(&a.epi.sums[ro + a.Cout + n0 + tid], (double)t2);
         }
     }
 }
@@ -357,8 +361,10 @@ static int launch_fwd_i(const IgemmArgs& a, int phases, hipStream_t st)
 {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     constexpr int STAGE = (BM + BN) * CPR * 16;
-    constexpr int EPI = BM * BN * (int)sizeof(T) + 2 * BN * 4;
     constexpr int EPC_ = 16 / (int)sizeof(T);
+    constexpr int EPI_TILE = BM * BN * (int)sizeof(T) + (BM / WM) * 2 * BN * 4;                 // output tile + one statistics slot per row-wave
+    constexpr int EPI_BN = (NT / (BN / EPC_)) * 2 * BN * 4;                                        // BN-backward sums: one slot per thread group
+    constexpr int EPI = EPI_TILE > EPI_BN ? EPI_TILE : EPI_BN;
     const int pro_bytes = (a.pro_scale || a.bnp.gamma) ? 2 * a.kpt * CPR * EPC_ * 4 : 0;      // prologue scale/shift vectors behind the two stages
     const int LDS = (2 * STAGE + pro_bytes > EPI) ? 2 * STAGE + pro_bytes : EPI;
     auto kern = conv_igemm_fwd_kernel<T, BM, BN, WM, WN, CPR, BNEPI>;

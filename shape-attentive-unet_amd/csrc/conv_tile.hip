@@ -216,10 +216,10 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64, BNEPI ? 1 : 2) void co
     TSTAMP(16);
 
     // ---- epilogue (same scheme as the generic kernel)
-    float* s_sum = (float*)(smem + 256 * BN * sizeof(T));
-    float* s_sq = s_sum + BN;
+    // one statistics slot per row-wave, added in a fixed order (no float atomics on LDS: deterministic, and cheaper)
+    constexpr int RW = 256 / WM;
+    float* s_sum = (float*)(smem + 256 * BN * sizeof(T));          // [RW][2][BN]
     const bool do_stats = a.stat_sum != nullptr;
-    if (do_stats) for (int i = tid; i < 2 * BN; i += NT) s_sum[i] = 0.f;
     __syncthreads();
     T* so = (T*)smem;
 #pragma unroll
@@ -238,14 +238,17 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64, BNEPI ? 1 : 2) void co
             }
         if (do_stats) {
             s += __shfl_xor(s, 32, 64); ss += __shfl_xor(ss, 32, 64);
-            if (lh == 0) { atomicAdd(&s_sum[col], s); atomicAdd(&s_sq[col], ss); }
+            if (lh == 0) { float* slot = s_sum + (wave / (BN / WN)) * 2 * BN; slot[col] = s; slot[BN + col] = ss; }
         }
     }
     __syncthreads();
     if (do_stats && tid < BN && n0 + tid < a.Cout) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < RW; ++w) { t1 += s_sum[w * 2 * BN + tid]; t2 += s_sum[w * 2 * BN + BN + tid]; }
         const size_t ro = (size_t)(blockIdx.x % a.stat_replicas) * a.stat_rstride;
-        atomicAdd(&a.stat_sum[ro + n0 + tid], (double)s_sum[tid]);
-        atomicAdd(&a.stat_sumsq[ro + n0 + tid], (double)s_sq[tid]);
+        atomicAdd(&a.stat_sum[ro + n0 + tid], (double)t1);
+        atomicAdd(&a.stat_sumsq[ro + n0 + tid], (double)t2);
     }
     constexpr int CH = BN / EPC;
     T* __restrict__ yg = (T*)a.y + (size_t)n * a.H * a.W * a.ldy;
@@ -299,18 +302,20 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64, BNEPI ? 1 : 2) void co
         }
         if (cok) *(u32x4*)(yg + opix * a.ldy + colv) = v;
     }
-    if (bnb) {
+    if (bnb) {      // slot tid / CH of the (now idle) tile area per thread group, folded in a fixed order
         __syncthreads();
-        for (int i = tid; i < 2 * BN; i += NT) s_sum[i] = 0.f;
-        __syncthreads();
-        const int ch = tid % CH;
+        constexpr int SL = NT / CH;
+        float* s_e = (float*)smem;                                // [SL][2][BN]
+        const int ch = tid % CH, sl = tid / CH;
 #pragma unroll
-        for (int j = 0; j < EPC; ++j) { atomicAdd(&s_sum[ch * EPC + j], e1[j]); atomicAdd(&s_sq[ch * EPC + j], e2[j]); }
+        for (int j = 0; j < EPC; ++j) { s_e[(sl * 2) * BN + ch * EPC + j] = e1[j]; s_e[(sl * 2 + 1) * BN + ch * EPC + j] = e2[j]; }
         __syncthreads();
         if (tid < BN && n0 + tid < a.Cout) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int w = 0; w < SL; ++w) { t1 += s_e[(w * 2) * BN + tid]; t2 += s_e[(w * 2 + 1) * BN + tid]; }
             const size_t ro = (size_t)(blockIdx.x % a.epi.sums_replicas) * a.epi.sums_rstride;
-            atomicAdd(&a.epi.sums[ro + n0 + tid], (double)s_sum[tid]);
-            atomicAdd(&a.epi.sums[ro + a.Cout + n0 + tid], (double)s_sq[tid]);
+            atomicAdd(&a.epi.sums[ro + n0 + tid], (double)t1);
+            atomicAdd(&a.epi.sums[ro + a.Cout + n0 + tid], (double)t2);
         }
     }
 }
@@ -319,7 +324,10 @@ template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI> static int la
 {
     constexpr int NT = (256 / WM) * (BN / WN) * 64;
     constexpr int MAIN = NPIX * CPR * 16 + 2 * BN * CPR * 16;
-    constexpr int EPI = 256 * BN * (int)sizeof(T) + 2 * BN * 4;
+    constexpr int EPC_ = 16 / (int)sizeof(T);
+    constexpr int EPI_TILE = 256 * BN * (int)sizeof(T) + (256 / WM) * 2 * BN * 4;
+    constexpr int EPI_BN = (NT / (BN / EPC_)) * 2 * BN * 4;
+    constexpr int EPI = EPI_TILE > EPI_BN ? EPI_TILE : EPI_BN;
     constexpr int LDS = MAIN > EPI ? MAIN : EPI;
     auto kern = conv3x3_tile_fwd_kernel<T, BN, WM, WN, CPR, BNEPI>;
     static bool attr_set = false;
@@ -405,30 +413,35 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
     if (it0 >= it1) return;
 
     // block-lifetime accumulators (statistics / BN-backward sums): flushed to global memory once per n-tile, not per tile
-    float* s_acc = (float*)(smem + a.lds_acc_off);      // [2][BN]
-    for (int i = tid; i < 2 * BN; i += NT) s_acc[i] = 0.f;
+    // one slot per wave, written by a unique owner lane (plain read-modify-write) and folded in wave order at the flush: no float atomics on LDS
+    constexpr int NW = NT / 64;
+    float* s_acc = (float*)(smem + a.lds_acc_off);      // [NW][2][BN]
+    for (int i = tid; i < NW * 2 * BN; i += NT) s_acc[i] = 0.f;
     // BatchNorm prologue vectors live in LDS for the block's lifetime.  They must NOT be fetched from global memory inside the unit
     // loop: vmcnt retires in order, so waiting for a scale/shift load issued after the halo prefetch drains the whole prefetch queue
     // (s_waitcnt vmcnt(0) right before the commit -- the prefetch then overlaps nothing).  LDS reads count on lgkmcnt instead.
-    float* s_pro = s_acc + 2 * BN;                       // [2][ncb * KC]
+    float* s_pro = s_acc + NW * 2 * BN;                  // [2][ncb * KC]
     // (filled further down, behind the weight copy and the first halo prefetches: the fill's own loads -- with a consumer-side BatchNorm finalize
     // two dependent round trips to the statistic replicas -- then overlap those instead of delaying them)
     auto flush_acc = [&](int nt) {
         __syncthreads();
         const int n0f = nt * BN;
         if (tid < BN && n0f + tid < a.Cout) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { t1 += s_acc[(w * 2) * BN + tid]; t2 += s_acc[(w * 2 + 1) * BN + tid]; }
             if constexpr (BNEPI) {
                 const size_t ro = (size_t)(blockIdx.x % a.epi.sums_replicas) * a.epi.sums_rstride;
-                atomicAdd(&a.epi.sums[ro + n0f + tid], (double)s_acc[tid]);
-                atomicAdd(&a.epi.sums[ro + a.Cout + n0f + tid], (double)s_acc[BN + tid]);
+                atomicAdd(&a.epi.sums[ro + n0f + tid], (double)t1);
+                atomicAdd(&a.epi.sums[ro + a.Cout + n0f + tid], (double)t2);
             } else if (a.stat_sum != nullptr) {
                 const size_t ro = (size_t)(blockIdx.x % a.stat_replicas) * a.stat_rstride;
-                atomicAdd(&a.stat_sum[ro + n0f + tid], (double)s_acc[tid]);
-                atomicAdd(&a.stat_sumsq[ro + n0f + tid], (double)s_acc[BN + tid]);
+                atomicAdd(&a.stat_sum[ro + n0f + tid], (double)t1);
+                atomicAdd(&a.stat_sumsq[ro + n0f + tid], (double)t2);
             }
         }
         __syncthreads();
-        for (int i = tid; i < 2 * BN; i += NT) s_acc[i] = 0.f;
+        for (int i = tid; i < NW * 2 * BN; i += NT) s_acc[i] = 0.f;
     };
 
     int cur_nt = -1;
@@ -628,8 +641,8 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
         // ---- epilogue for this tile (output staged in the halo area)
         __syncthreads();
         const int n = c_n, ty0 = c_tyi * TILE, tx0 = c_txi * TILE;
-        float* s_sum = s_acc;
-        float* s_sq = s_acc + BN;
+        float* s_sum = s_acc + (wave * 2) * BN;           // this wave's slot
+        float* s_sq = s_sum + BN;
         const bool do_stats = !BNEPI && a.stat_sum != nullptr;
         T* so = (T*)s_halo;
 #pragma unroll
@@ -648,7 +661,7 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
                 }
             if (do_stats) {
                 s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-                if (lh == 0) { atomicAdd(&s_sum[col], s1); atomicAdd(&s_sq[col], s2); }
+                if (lh == 0) { s_sum[col] += s1; s_sq[col] += s2; }
             }
         }
         __syncthreads();
@@ -693,9 +706,18 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
                 }
                 if (cok) *(u32x4*)(yg + opix * a.ldy + colv) = Vec16<T>::pack(g);
             }
-            const int ch = tid % CH;
+            // the 64 / CH lanes of the wave that own the same channel chunk: fixed xor tree, then one owner lane per chunk adds into the wave's slot
+            static_assert(64 % CH == 0, "channel chunks per row divide the wave");
+            const int ch = lane % CH;
 #pragma unroll
-            for (int j = 0; j < EPC; ++j) { atomicAdd(&s_sum[ch * EPC + j], e1[j]); atomicAdd(&s_sq[ch * EPC + j], e2[j]); }
+            for (int off = CH; off < 64; off <<= 1) {
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) { e1[j] += __shfl_xor(e1[j], off, 64); e2[j] += __shfl_xor(e2[j], off, 64); }
+            }
+            if (lane < CH) {
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) { s_sum[ch * EPC + j] += e1[j]; s_sq[ch * EPC + j] += e2[j]; }
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < S_ITERS; ++i) {
@@ -731,7 +753,7 @@ template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI> static int la
     const int ncb = (a.Cin + CPR * EPC - 1) / (CPR * EPC);
     constexpr int HALO_B = HPITCH * res_halo_rowb(CPR), EPI_B = 256 * BN * (int)sizeof(T);
     int lds = (HALO_B > EPI_B ? HALO_B : EPI_B) + ncb * 9 * BN * (CPR * 16 + 16);
-    a.lds_acc_off = lds; lds += 2 * BN * 4 + 2 * ncb * CPR * EPC * 4;      // accumulators + the prologue scale/shift vectors
+    a.lds_acc_off = lds; lds += (NT / 64) * 2 * BN * 4 + 2 * ncb * CPR * EPC * 4;      // accumulators (one slot per wave) + the prologue scale/shift vectors
     auto kern = conv3x3_res_fwd_kernel<T, BN, WM, WN, CPR, BNEPI>;
     static int attr_lds = 0;
     if (lds > attr_lds) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_lds = lds; }
@@ -753,7 +775,7 @@ template <typename T> static int dispatch_res_fwd(const TileArgs& a, hipStream_t
     const int pitch = cpr * 16 + 16;
     const int bn = a.Cout <= 32 ? 32 : (a.Cout <= 64 ? 64 : 128);
     const long halo_b = (long)HPITCH * res_halo_rowb(cpr), epi_b = 256L * bn * sizeof(T);
-    long lds = (halo_b > epi_b ? halo_b : epi_b) + (long)ncb * 9 * bn * pitch + 2 * bn * 4 + 2L * ncb * cpr * EPC * 4;
+    long lds = (halo_b > epi_b ? halo_b : epi_b) + (long)ncb * 9 * bn * pitch + 8 * 2 * bn * 4 + 2L * ncb * cpr * EPC * 4;   // (at most 8 wave slots)
     *handled = lds <= 154 * 1024 && (a.tiles_x * a.tiles_y * a.N) >= 32;   // even at one tile per block a single bulk weight load beats nine dependent per-tap loads
     if (!*handled) return SAUNET_OK;
 #define RES(BN_, WM_, WN_, CPR_) (a.epi.bn_x ? launch_res_fwd_i<T, BN_, WM_, WN_, CPR_, true>(a, st) : launch_res_fwd_i<T, BN_, WM_, WN_, CPR_, false>(a, st))

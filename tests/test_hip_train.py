@@ -80,7 +80,11 @@ def test_graph_replays_follow_the_eager_trajectory(dtype):
     # the loss of this B=2 toy is sensitive to summation-order noise (float atomics) and the sensitivity grows with the learning rate
     # (scripts/graph_debug3.py: two EAGER fp32 runs differ by 1.6e-2 at lr 5e-3 and by 3e-4 at lr 2e-4; bf16 runs by ~5e-2 at any lr), so the
     # test trains gently: a graph that replayed frozen packed weights would hold the loss constant while the eager curve falls 0.1-0.3 per step
-    lr, tol0, tol, wtol = (2e-4, 1e-4, 5e-3, 1e-5) if dtype == torch.float32 else (1e-3, 0.1, 0.15, 3e-4)
+    # Round 3: the convolution epilogues fold their partial sums in a fixed order now (no float atomics on LDS); single-step gradients repeat to
+    # 4e-7 of their scale (scripts/smoke_variance.py) and five float32 steps at this learning rate to 2e-4 in the loss
+    # (scripts/replay_vs_eager_probe.py) -- not bit-equal: float64 atomics between workgroups and the float atomics of the SE pool / the
+    # few-channel weight gradients still depend on arrival order.
+    lr, tol0, tol, wtol = (2e-4, 1e-4, 1e-3, 1e-5) if dtype == torch.float32 else (1e-3, 0.1, 0.15, 3e-4)
     try:
         S_, net, sm, opt, feed = _make_training(dtype, lr=lr)
         w_init = net.final.weight.detach().clone()
