@@ -856,9 +856,10 @@ class _BasicBlock(torch.autograd.Function):
         return dx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None, None
 
 
-# Opt-in (SAUNET_FUSED_BASIC_BLOCK=1).  Measured twice (rounds 1 and 2, same-box A/B): the three full-resolution passes it saves (0.3 ms) are lost
-# to the slower prologue / epilogue variants of the 64-, 32- and 16-channel kernels it needs instead -- 33.45 -> 33.86 ms per step.
-FUSED_BASIC_BLOCK = os.environ.get("SAUNET_FUSED_BASIC_BLOCK", "0") == "1"
+# Default since round 3 (SAUNET_FUSED_BASIC_BLOCK=0 restores the two conv_bn_act calls).  Rounds 1 and 2 measured it SLOWER (33.45 -> 33.86 ms per
+# step): the three full-resolution passes it saves (0.3 ms) were lost to the BN-backward epilogue of the narrow 3x3 kernels, whose partial sums
+# went through float atomics on LDS (12 cycles per active lane).  With the per-wave slot fold those epilogues are cheap: 30.23 -> 30.05 ms.
+FUSED_BASIC_BLOCK = os.environ.get("SAUNET_FUSED_BASIC_BLOCK", "1") == "1"
 
 
 def basic_block(x, conv1, bn1, conv2, bn2):
