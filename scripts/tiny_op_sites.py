@@ -24,9 +24,11 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
     step()
 torch.cuda.synchronize()
+allops = collections.Counter(ev.name for ev in prof.events() if ev.name.startswith("aten::"))
+print("all aten ops of one step:", dict(allops.most_common(40)))
 tot = collections.Counter(); sites = collections.Counter()
 for ev in prof.events():
-    if ev.name in ("aten::copy_", "aten::fill_", "aten::add_", "aten::add", "aten::clone", "aten::mul", "aten::sum"):
+    if ev.name in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::zeros", "aten::add_", "aten::add", "aten::clone", "aten::mul", "aten::sum"):
         tot[ev.name] += 1
         st = [f for f in (ev.stack or []) if ("repo" in f or "saunet" in f) and "tiny_op_sites" not in f]
         shp = str([tuple(x) for x in (ev.input_shapes or []) if x])[:70]

@@ -1598,6 +1598,7 @@ class _DenseBlock(torch.autograd.Function):
         ctx.save_for_backward(buf, xh, *params, *saved)
         ctx.meta = (nl, c0, growth, count, training)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)           # no zero-filled "gradient" of the statistics tensor in backward
         return buf, stats
 
     @staticmethod
