@@ -818,6 +818,12 @@ int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const 
     return set_error(SAUNET_BAD_DTYPE, "conv: dtype %d", d->dtype);
 }
 
+// Register prefetch of the next pixel tile (compile-time switch, OFF): measured round 3 -- 1x1 kernels neutral (they sit at the HBM floor), 3x3
+// kernels SLOWER (block-1 conv2 92 -> 123 us, res1 263 -> 409 us): their 144 accumulator registers leave no room, the prefetch registers
+// spill (76-80 B / lane), and the 3x3 inner loop is bound by LDS operand bandwidth (one fresh 1 KB B fragment per MFMA), not by load latency.
+#ifndef SAUNET_WGRAD_PREFETCH
+#define SAUNET_WGRAD_PREFETCH 0
+#endif
 // =====================================================================================================
 // wgrad on pixel tiles: dW[co][ci][tap] += sum_{pixels of the tile} dy[p][co] * a[p (+) tap][ci]
 struct TileWgradArgs {
@@ -880,9 +886,15 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
     unsigned char* s_x = smem + NPY * PY;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    static_assert((CO_T / WM) * (CI_T / WN) * KSPLIT == 4, "4 waves per block");
+    // KSPLIT > 0: the waves beyond the channel sub-tiles split K (tile rows), each holds all taps and they are summed through LDS at the end.
+    // KSPLIT < 0: "tap split" -- -KSPLIT waves share the taps (wave w takes taps w, w + 4, w + 8), each runs all tile rows: a third of the
+    //             accumulator registers (48 instead of 144 for 3x3), which is what makes room for the register prefetch of the next tile.
+    constexpr bool TS = KSPLIT < 0;
+    constexpr int KSP = TS ? 1 : KSPLIT, NTW = TS ? -KSPLIT : 1;
+    constexpr int TPW = (KS * KS + NTW - 1) / NTW;                 // taps held per wave
+    static_assert((CO_T / WM) * (CI_T / WN) * KSP * NTW == 4, "4 waves per block");
     constexpr int CWAVES = (CO_T / WM) * (CI_T / WN);
-    const int cwave = wave % CWAVES, kwave = wave / CWAVES;       // channel sub-tile / K (tile row) slice of this wave
+    const int cwave = wave % CWAVES, kwave = TS ? 0 : wave / CWAVES, twave = TS ? wave / CWAVES : 0;   // channel sub-tile / K slice / tap slice
     const int wm0 = (cwave / (CI_T / WN)) * WM, wn0 = (cwave % (CI_T / WN)) * WN;
     const int cot = by / a.ncit, cit = by - cot * a.ncit;
     const int co0 = cot * CO_T, ci0 = cit * CI_T;
@@ -891,13 +903,13 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
     const bool has_pro = a.pro_scale != nullptr;
     const float relu_lo = a.pro_relu ? 0.f : -__builtin_inff();
 
-    f32x16 acc[MI][NI][TAPS];
+    f32x16 acc[MI][NI][TPW];
 #pragma unroll
     for (int m = 0; m < MI; ++m)
 #pragma unroll
         for (int n = 0; n < NI; ++n)
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t)
+            for (int t = 0; t < TPW; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][t][r] = 0.f;
 
@@ -918,76 +930,119 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
 
     TSTAMP_INIT();
     TSTAMP(20);
-    for (int tile = gx; tile < a.ntiles; tile += ngroups) {
+    // ---- staging of one pixel tile: dy tile + activation halo, global -> registers -> (prologue) -> LDS
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    auto tile_coords = [&](int tile, int& n, int& ty0, int& tx0) {
         int bt = tile;
         const int txi = bt % a.tiles_x; bt /= a.tiles_x;
-        const int tyi = bt % a.tiles_y; const int n = bt / a.tiles_y;
-        const int ty0 = tyi * TR, tx0 = txi * TILE;
+        const int tyi = bt % a.tiles_y; n = bt / a.tiles_y;
+        ty0 = tyi * TR; tx0 = txi * TILE;
+    };
+    auto load_y = [&](int n, int ty0, int tx0, u32x4* yreg) {
+#pragma unroll
+        for (int i = 0; i < YI; ++i) {
+            int q = tid + i * 256, pix = q / CHY, ch = q - pix * CHY;
+            int c = co0 + ch * EPC;
+            bool ok = (YI * 256 == NPY * CHY || q < NPY * CHY) && c < a.Cout;
+            size_t off = ok ? (((size_t)n * a.H + ty0 + pix / TILE) * a.W + tx0 + (pix % TILE)) * a.lddy : (size_t)0;
+            yreg[i] = load_chunk<T, ALIGNED>(dyg + off, ok ? c : 0, a.Cout);
+        }
+    };
+    auto store_y = [&](const u32x4* yreg) {
+#pragma unroll
+        for (int i = 0; i < YI; ++i) {
+            int q = tid + i * 256, pix = q / CHY, ch = q - pix * CHY;
+            bool ok = (YI * 256 == NPY * CHY || q < NPY * CHY) && co0 + ch * EPC < a.Cout;
+            if (YI * 256 == NPY * CHY || q < NPY * CHY) *(u32x4*)(s_y + pix * PY + ch * 16) = ok ? yreg[i] : zero4;
+        }
+    };
+    // chunks b0 .. b0 + cnt - 1 of the halo
+    auto x_ok = [&](int ty0, int tx0, int i, int& c) {
+        int q = tid + i * 256, pix = q / CHX, ch = q - pix * CHX;
+        int hy = pix / HC, hx = pix - hy * HC;
+        int iy = ty0 + hy - PAD, ix = tx0 + hx - PAD;
+        c = ci0 + ch * EPC;
+        return (i < XI) && q < NPX * CHX && c < a.Cin && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    };
+    auto load_x = [&](int n, int ty0, int tx0, u32x4* xreg, int b0, int cnt) {
+#pragma unroll
+        for (int i = 0; i < cnt; ++i) {
+            int q = tid + (b0 + i) * 256, pix = q / CHX;
+            int hy = pix / HC, hx = pix - hy * HC;
+            int iy = ty0 + hy - PAD, ix = tx0 + hx - PAD;
+            int c; const bool ok = x_ok(ty0, tx0, b0 + i, c);
+            xreg[i] = load_chunk<T, ALIGNED>(xg + (ok ? (((size_t)n * a.H + iy) * a.W + ix) * a.ldx : (size_t)0), ok ? c : 0, a.Cin);
+        }
+    };
+    auto store_x = [&](int ty0, int tx0, u32x4* xreg, int b0, int cnt) {
+        if (has_pro) {
+#pragma unroll
+            for (int i = 0; i < cnt; ++i) {
+                int c; const bool ok = x_ok(ty0, tx0, b0 + i, c);
+                const int cx = ok ? c : 0;
+                float f[EPC];
+                Vec16<T>::unpack(xreg[i], f);
+                if constexpr (ALIGNED) {
+#pragma unroll
+                    for (int j = 0; j < EPC; ++j) f[j] = fmaxf(fmaf(f[j], pro_s[j], pro_t[j]), relu_lo);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < EPC; ++j) {
+                        const int cc = cx + j < a.Cin ? cx + j : 0;
+                        f[j] = (cx + j < a.Cin) ? fmaxf(fmaf(f[j], a.pro_scale[cc], a.pro_shift[cc]), relu_lo) : 0.f;
+                    }
+                }
+                xreg[i] = Vec16<T>::pack(f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < cnt; ++i) {
+            int q = tid + (b0 + i) * 256, pix = q / CHX, ch = q - pix * CHX;
+            int c; const bool ok = x_ok(ty0, tx0, b0 + i, c);
+            if ((b0 + i < XI) && q < NPX * CHX) *(u32x4*)(s_x + pix * PX + ch * 16) = ok ? xreg[i] : zero4;
+        }
+    };
+    // register prefetch: the NEXT tile's global loads are issued right after this tile is in LDS and fly during its matrix-core loop
+    // (without it every tile pays load latency -> LDS -> barrier -> MFMA in sequence; two resident blocks per CU hide only part of it)
+    constexpr bool PF = (SAUNET_WGRAD_PREFETCH || TS) && ALIGNED && sizeof(T) == 2 && (YI + XI) <= 16;
+    u32x4 pyreg[PF ? YI : 1], pxreg[PF ? XI : 1];
+    if constexpr (PF) {
+        if (gx < a.ntiles) { int n, ty0, tx0; tile_coords(gx, n, ty0, tx0); load_y(n, ty0, tx0, pyreg); load_x(n, ty0, tx0, pxreg, 0, XI); }
+    }
+    for (int tile = gx; tile < a.ntiles; tile += ngroups) {
+        int n, ty0, tx0; tile_coords(tile, n, ty0, tx0);
         TSTAMP(21);
         __syncthreads();   // previous tile fully consumed
         TSTAMP(22);
-        {
-            u32x4 yreg[YI];
-            const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int i = 0; i < YI; ++i) {
-                int q = tid + i * 256, pix = q / CHY, ch = q - pix * CHY;
-                int c = co0 + ch * EPC;
-                bool ok = (YI * 256 == NPY * CHY || q < NPY * CHY) && c < a.Cout;
-                size_t off = ok ? (((size_t)n * a.H + ty0 + pix / TILE) * a.W + tx0 + (pix % TILE)) * a.lddy : (size_t)0;
-                u32x4 v = load_chunk<T, ALIGNED>(dyg + off, ok ? c : 0, a.Cout);
-                yreg[i] = ok ? v : z;
+        if constexpr (PF) {
+            store_y(pyreg);
+            TSTAMP(23);
+            store_x(ty0, tx0, pxreg, 0, XI);
+            TSTAMP(24);
+            __syncthreads();
+            if (tile + ngroups < a.ntiles) {
+                int n2, ty2, tx2; tile_coords(tile + ngroups, n2, ty2, tx2);
+                load_y(n2, ty2, tx2, pyreg); load_x(n2, ty2, tx2, pxreg, 0, XI);
             }
-#pragma unroll
-            for (int i = 0; i < YI; ++i) {
-                int q = tid + i * 256, pix = q / CHY, ch = q - pix * CHY;
-                if (YI * 256 == NPY * CHY || q < NPY * CHY) *(u32x4*)(s_y + pix * PY + ch * 16) = yreg[i];
+        } else {
+            {
+                u32x4 yreg[YI];
+                load_y(n, ty0, tx0, yreg);
+                store_y(yreg);
             }
+            TSTAMP(23);
+#pragma unroll
+            for (int b0 = 0; b0 < XI; b0 += XB) {
+                u32x4 xreg[XB];
+                load_x(n, ty0, tx0, xreg, b0, XB);
+                store_x(ty0, tx0, xreg, b0, XB);
+            }
+            TSTAMP(24);
+            __syncthreads();
         }
-        TSTAMP(23);
-#pragma unroll
-        for (int b0 = 0; b0 < XI; b0 += XB) {
-            u32x4 xreg[XB]; bool okx[XB]; int cx[XB];
-            const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int i = 0; i < XB; ++i) {
-                int q = tid + (b0 + i) * 256, pix = q / CHX, ch = q - pix * CHX;
-                int hy = pix / HC, hx = pix - hy * HC;
-                int iy = ty0 + hy - PAD, ix = tx0 + hx - PAD;
-                int c = ci0 + ch * EPC;
-                bool ok = (b0 + i < XI) && q < NPX * CHX && c < a.Cin && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                okx[i] = ok; cx[i] = ok ? c : 0;
-                xreg[i] = load_chunk<T, ALIGNED>(xg + (ok ? (((size_t)n * a.H + iy) * a.W + ix) * a.ldx : (size_t)0), cx[i], a.Cin);
-            }
-            if (has_pro) {
-#pragma unroll
-                for (int i = 0; i < XB; ++i) {
-                    float f[EPC];
-                    Vec16<T>::unpack(xreg[i], f);
-                    if constexpr (ALIGNED) {
-#pragma unroll
-                        for (int j = 0; j < EPC; ++j) f[j] = fmaxf(fmaf(f[j], pro_s[j], pro_t[j]), relu_lo);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < EPC; ++j) {
-                            const int cc = cx[i] + j < a.Cin ? cx[i] + j : 0;
-                            f[j] = (cx[i] + j < a.Cin) ? fmaxf(fmaf(f[j], a.pro_scale[cc], a.pro_shift[cc]), relu_lo) : 0.f;
-                        }
-                    }
-                    xreg[i] = Vec16<T>::pack(f);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < XB; ++i) {
-                int q = tid + (b0 + i) * 256, pix = q / CHX, ch = q - pix * CHX;
-                if ((b0 + i < XI) && q < NPX * CHX) *(u32x4*)(s_x + pix * PX + ch * 16) = okx[i] ? xreg[i] : z;
-            }
-        }
-        TSTAMP(24);
-        __syncthreads();
         TSTAMP(25);
         // ---- one MFMA K-step = one tile row (16 pixels)
-        for (int ty = kwave; ty < TR; ty += KSPLIT) {
+        for (int ty = kwave; ty < TR; ty += KSP) {
             if constexpr (sizeof(T) == 2) {
                 u32x4 af[MI];
 #pragma unroll
@@ -996,7 +1051,9 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
                     tr_read2(base, 4 * PY, af[m]);
                 }
 #pragma unroll
-                for (int t = 0; t < TAPS; ++t) {
+                for (int j = 0; j < TPW; ++j) {
+                    const int t = TS ? twave + NTW * j : j;
+                    if (TS && t >= TAPS) continue;             // wave-uniform
                     const int kh = t / KS, kw = t - kh * KS;
 #pragma unroll
                     for (int nn = 0; nn < NI; ++nn) {
@@ -1005,7 +1062,7 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
                         tr_read2(base, 4 * PX, bf);
 #pragma unroll
                         for (int m = 0; m < MI; ++m)
-                            acc[m][nn][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[m]), __builtin_bit_cast(bf16x8_t, bf), acc[m][nn][t], 0, 0, 0);
+                            acc[m][nn][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[m]), __builtin_bit_cast(bf16x8_t, bf), acc[m][nn][j], 0, 0, 0);
                     }
                 }
             } else {
@@ -1015,6 +1072,7 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
                     float af[MI];
 #pragma unroll
                     for (int m = 0; m < MI; ++m) af[m] = *(const float*)(s_y + (ty * TILE + k + lh) * PY + (wm0 + m * 32 + lr) * 4);
+                    static_assert(!TS || sizeof(T) == 2, "tap split: bf16 only");
 #pragma unroll
                     for (int t = 0; t < TAPS; ++t) {
                         const int kh = t / KS, kw = t - kh * KS;
@@ -1031,33 +1089,34 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
     }
     TSTAMP(26);
     const int lr = lane & 31, lh = lane >> 5;
-    float* s_red = (float*)smem;   // [KSPLIT-1][64 lanes][16] floats per (m, n, tap) round
+    float* s_red = (float*)smem;   // [KSP-1][64 lanes][16] floats per (m, n, tap) round
 #pragma unroll
     for (int m = 0; m < MI; ++m)
 #pragma unroll
         for (int nn = 0; nn < NI; ++nn) {
             const int ci = ci0 + wn0 + nn * 32 + lr;
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                if constexpr (KSPLIT > 1) {
+            for (int j = 0; j < TPW; ++j) {
+                const int t = TS ? twave + NTW * j : j;
+                if constexpr (KSP > 1) {
                     __syncthreads();
                     if (kwave > 0) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) s_red[((kwave - 1) * 16 + r) * 64 + lane] = acc[m][nn][t][r];
+                        for (int r = 0; r < 16; ++r) s_red[((kwave - 1) * 16 + r) * 64 + lane] = acc[m][nn][j][r];
                     }
                     __syncthreads();
                     if (kwave == 0) {
 #pragma unroll
-                        for (int k = 0; k < KSPLIT - 1; ++k)
+                        for (int k = 0; k < KSP - 1; ++k)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[m][nn][t][r] += s_red[(k * 16 + r) * 64 + lane];
+                            for (int r = 0; r < 16; ++r) acc[m][nn][j][r] += s_red[(k * 16 + r) * 64 + lane];
                     }
                 }
-                if (kwave == 0) {
+                if (kwave == 0 && t < TAPS) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         int co = co0 + wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (co < a.Cout && ci < a.Cin) a.ws[(size_t)gx * a.wsize + (size_t)co * a.sM + (size_t)ci * a.sN + t] = acc[m][nn][t][r];
+                        if (co < a.Cout && ci < a.Cin) a.ws[(size_t)gx * a.wsize + (size_t)co * a.sM + (size_t)ci * a.sN + t] = acc[m][nn][j][r];
                     }
                 }
             }
@@ -1129,7 +1188,7 @@ template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KS
     constexpr int PY = sizeof(T) == 2 ? ((PY_RAW % 128 == 64) ? PY_RAW : PY_RAW + 64) : PY_RAW;
     constexpr int PX = sizeof(T) == 2 ? ((PX_RAW % 128 == 64) ? PX_RAW : PX_RAW + 64) : PX_RAW;
     constexpr int LDS_MAIN = NPY * PY + NPX * PX;
-    constexpr int LDS_RED = KSPLIT > 1 ? (KSPLIT - 1) * 16 * 64 * 4 : 0;
+    constexpr int LDS_RED = KSPLIT > 1 ? (KSPLIT - 1) * 16 * 64 * 4 : 0;   // (tap split: no cross-wave reduction)
     constexpr int LDS = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
     static_assert(LDS <= 160 * 1024, "tile does not fit LDS");
     auto kern = conv_tile_wgrad_kernel<T, KS, TR, CO_T, CI_T, WM, WN, KSPLIT, ALIGNED>;
@@ -1169,6 +1228,8 @@ template <typename T> static int dispatch_tile_wgrad(TileWgradArgs& a, int ks, b
     const bool small = (long)a.Cout * a.Cin <= 64 * 128;
     if constexpr (sizeof(T) == 2) {
         if (ks == 3) {
+            static const bool tapsplit = getenv("SAUNET_WGRAD3_TS") && getenv("SAUNET_WGRAD3_TS")[0] == '1';
+            if (small && tapsplit) return launch_tile_wgrad<T, 3, 16, 32, 32, 32, 32, -4>(a, wsb, need, st);
             if (small) return launch_tile_wgrad<T, 3, 16, 32, 32, 32, 32, 4>(a, wsb, need, st);
             return launch_tile_wgrad<T, 3, 8, 64, 64, 32, 32, 1>(a, wsb, need, st);
         }
@@ -1237,7 +1298,7 @@ static int launch_tile_wgrad_grouped(GroupedWgradArgs& g, const saunet_wgrad_gro
     constexpr int PY = sizeof(T) == 2 ? ((PY_RAW % 128 == 64) ? PY_RAW : PY_RAW + 64) : PY_RAW;
     constexpr int PX = sizeof(T) == 2 ? ((PX_RAW % 128 == 64) ? PX_RAW : PX_RAW + 64) : PX_RAW;
     constexpr int LDS_MAIN = NPY * PY + NPX * PX;
-    constexpr int LDS_RED = KSPLIT > 1 ? (KSPLIT - 1) * 16 * 64 * 4 : 0;
+    constexpr int LDS_RED = KSPLIT > 1 ? (KSPLIT - 1) * 16 * 64 * 4 : 0;   // (tap split: no cross-wave reduction)
     constexpr int LDS = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
     auto kern = conv_tile_wgrad_grouped_kernel<T, KS, TR, CO_T, CI_T, WM, WN, KSPLIT>;
     static bool attr_set = false;
@@ -1335,6 +1396,10 @@ int tile_wgrad_grouped(const saunet_wgrad_group* s, void* ws, size_t ws_bytes, s
             bool all_128_32 = true;
             for (int i = 0; i < s->count; ++i) if (s->item[i].Cout > 32 || s->item[i].Cin % 128) all_128_32 = false;
             if (wide && all_128_32) return launch_tile_wgrad_grouped<u16, 3, 8, 32, 128, 32, 32, 1>(g, s, ws, ws_bytes, need, st);
+            // opt-in (SAUNET_WGRAD3_TS=1): tap split + register prefetch.  Measured: block 1 slower (90.6 -> 114.5 us per layer: every wave re-reads
+            // all 16 dy fragments and wave 0 carries 3 of the 9 taps), blocks 2-4 5-15 % faster; step +0.25 ms.  Off.
+            static const bool tapsplit = getenv("SAUNET_WGRAD3_TS") && getenv("SAUNET_WGRAD3_TS")[0] == '1';
+            if (small && tapsplit) return launch_tile_wgrad_grouped<u16, 3, 16, 32, 32, 32, 32, -4>(g, s, ws, ws_bytes, need, st);
             if (small) return launch_tile_wgrad_grouped<u16, 3, 16, 32, 32, 32, 32, 4>(g, s, ws, ws_bytes, need, st);
             return launch_tile_wgrad_grouped<u16, 3, 8, 64, 64, 32, 32, 1>(g, s, ws, ws_bytes, need, st);
         }
