@@ -247,11 +247,12 @@ def test_pools_sigmoid_relu_cat_gate(dtype):
     close(yd2, y2, tol, "gate"); close(xd.grad, gx2, tol, "gate dx"); close(gd.grad, gg2, tol * 2, "gate dalpha")
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 8, 8), (1, 512, 4, 4), (2, 128, 6, 10), (3, 256, 5, 7)])   # bf16: 8 / 64 / 16 / 32 chunks per pixel, ragged pixel ranges
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_dual_att_tail(dtype):
+def test_dual_att_tail(dtype, shape):
     import torch.nn as nn
     hf = HF()
-    n, c, h, w, r = 2, 64, 8, 8, 16
+    (n, c, h, w), r = shape, 16
     Fm, S = rnd(n, c, h, w), torch.sigmoid(rnd(n, 1, h, w, seed=2))
     fc1_r, fc2_r = nn.Conv2d(c, c // r, 1), nn.Conv2d(c // r, c, 1)
     fc1_d, fc2_d = nn.Conv2d(c, c // r, 1).cuda(), nn.Conv2d(c // r, c, 1).cuda()
