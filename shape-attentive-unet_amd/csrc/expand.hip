@@ -77,18 +77,35 @@ void expand_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const float* _
         float A[8], B[8], s1[8], s2[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { A[j] = coef[c + j]; B[j] = coef[C + c + j]; s1[j] = 0.f; s2[j] = 0.f; }
-        for (unsigned p = blockIdx.x * rl + r0; p < P; p += gridDim.x * rl) {
-            const float av = a[p];
-            float g[8];
-            load8v(dy + (size_t)p * lddy + c, g);
+        // four pixels per step: four independent 16-byte loads in flight per lane (one per step left the 16-step walk a chain of exposed latencies:
+        // 1.4 TB/s); indices past the end re-read the last pixel and contribute zero
+        const unsigned stride = gridDim.x * rl;
+        for (unsigned p0 = blockIdx.x * rl + r0; p0 < P; p0 += 4 * stride) {
+            float av[4], g[4][8]; bool live[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float gj = (!relu || fmaf(A[j], av, B[j]) > 0.f) ? g[j] : 0.f;
-                s1[j] += gj; s2[j] = fmaf(gj, av, s2[j]);
+            for (int u = 0; u < 4; ++u) {
+                const unsigned p = p0 + u * stride; live[u] = p < P;
+                const unsigned pp = live[u] ? p : P - 1;
+                av[u] = a[pp];
+                load8v(dy + (size_t)pp * lddy + c, g[u]);
             }
-        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { atomicAdd(&e_red[c + j], s1[j]); atomicAdd(&e_red[C + c + j], s2[j]); }
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gj = (live[u] && (!relu || fmaf(A[j], av[u], B[j]) > 0.f)) ? g[u][j] : 0.f;
+                    s1[j] += gj; s2[j] = fmaf(gj, av[u], s2[j]);
+                }
+        }
+        // lanes of a wave that own the same channel group (lane % CG; CG = 4 or 8 divides 64): xor tree, then ONE LDS atomic per group and wave
+        for (int off = CG; off < 64; off <<= 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[j] += __shfl_xor(s1[j], off, 64); s2[j] += __shfl_xor(s2[j], off, 64); }
+        }
+        if ((threadIdx.x & 63) < CG) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { atomicAdd(&e_red[c + j], s1[j]); atomicAdd(&e_red[C + c + j], s2[j]); }
+        }
     }
     __syncthreads();
     const size_t ro = (size_t)(blockIdx.x % reps) * rstride;
