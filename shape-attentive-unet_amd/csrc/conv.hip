@@ -30,6 +30,9 @@ constexpr bool kUnalignedTileWgrad = false;
 int tile_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw,
                void* ws, size_t ws_bytes, size_t* need, bool aligned, hipStream_t st, saunet_wgrad_pending* pend = nullptr);
 int wgrad_reduce_multi(const saunet_wgrad_reduce_list* l, hipStream_t st);
+bool tile_wgrad_convt_supported(const saunet_conv_desc* d);
+int tile_wgrad_convt(const saunet_conv_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, size_t* need, hipStream_t st,
+                     saunet_wgrad_pending* pend);
 bool tile_wgrad_grouped_supported(const saunet_wgrad_group* s);
 int tile_wgrad_grouped(const saunet_wgrad_group* s, void* ws, size_t ws_bytes, size_t* need, hipStream_t st);
 int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, const float* ps, const float* psh,
@@ -631,8 +634,20 @@ int saunet_conv2d_forward_bnpro(const saunet_conv_desc* d, const void* x, const 
     return saunet_conv2d_forward_ex(d, x, w, bias, p.params, p.params + d->Cin, y, ssum, ssq, nullptr, stream);
 }
 
+// A/B switch: SAUNET_CONVT_WGRAD_DIRECT=0 sends ConvTranspose2d weight gradients back to the generic path
+static bool convt_direct(const saunet_conv_desc* d)
+{
+    static const bool on = !(getenv("SAUNET_CONVT_WGRAD_DIRECT") && getenv("SAUNET_CONVT_WGRAD_DIRECT")[0] == '0');
+    return on && tile_wgrad_convt_supported(d);
+}
+
 int64_t saunet_conv2d_wgrad_workspace(const saunet_conv_desc* d)
 {
+    if (convt_direct(d)) {
+        size_t need = 0;
+        int rc = tile_wgrad_convt(d, nullptr, nullptr, nullptr, nullptr, 0, &need, nullptr, nullptr);
+        return rc == SAUNET_OK ? (int64_t)need : (int64_t)rc;
+    }
     saunet_conv_desc flat;
     if (is_pointwise(d) && dense_pointwise_rows(d, &flat)) d = &flat;
     if (igemm_supported(d) && tile_wgrad_supported(d)) {
@@ -680,6 +695,7 @@ int saunet_conv2d_wgrad_deferred(const saunet_conv_desc* d, const void* x, const
 {
     hipStream_t st = (hipStream_t)stream;
     if (pending) { pending->ws = nullptr; pending->dw = nullptr; pending->wsize = 0; pending->groups = 0; pending->reserved = 0; }
+    if (ps == nullptr && convt_direct(d)) return tile_wgrad_convt(d, x, dy, dw, workspace, (size_t)workspace_bytes, nullptr, st, pending);
     saunet_conv_desc flat;
     if (is_pointwise(d) && dense_pointwise_rows(d, &flat)) d = &flat;     // pixels are just rows for a 1x1 conv: any map shape tiles
     if (igemm_supported(d)) {

@@ -831,6 +831,10 @@ struct TileWgradArgs {
     const float* pro_scale; const float* pro_shift;
     int N, H, W, Cin, ldx, Cout, lddy, pro_relu;
     int tiles_x, tiles_y, ntiles, ncit;   // tiles per row / column, total, number of ci tiles
+    // haloed operand: element strides of (image, row, pixel); 0 = dense NHWC (H*W*ldx, W*ldx, ldx).
+    // KS == 2 (ConvTranspose2d k4 s2 p1, see tile_wgrad_convt): the haloed operand is one PARITY sub-image of dy, blockIdx.y also carries the parity
+    long xs_n, xs_r, xs_p;
+    int ncot, Wo;
     long sM, sN;
     float* ws; long wsize;                 // per-group partial gradients [groups][wsize] (plain stores, reduced afterwards)
     saunet_wgrad_pending* pend;            // non-null: do not launch the reduction, describe it here (saunet_wgrad_reduce_multi runs it later)
@@ -896,9 +900,17 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
     constexpr int CWAVES = (CO_T / WM) * (CI_T / WN);
     const int cwave = wave % CWAVES, kwave = TS ? 0 : wave / CWAVES, twave = TS ? wave / CWAVES : 0;   // channel sub-tile / K slice / tap slice
     const int wm0 = (cwave / (CI_T / WN)) * WM, wn0 = (cwave % (CI_T / WN)) * WN;
-    const int cot = by / a.ncit, cit = by - cot * a.ncit;
+    // KS == 2: weight gradient of ConvTranspose2d(k=4, s=2, p=1) as four 2x2-tap problems, one per output parity (py, px):
+    //   dW[ci][co][kh0 + 2 th][kw0 + 2 tw] = sum x[n, iy, ix, ci] * D[n, iy + th + kh0 - 1, ix + tw + kw0 - 1, co],   D[i][j] = dy[2 i + 1 - kh0][2 j + 1 - kw0]
+    // (kh0 = 1 - py, kw0 = 1 - px).  The kernel's haloed operand "x" is D (a strided view of dy, its channels are the layer's OUTPUT channels), its
+    // "dy" operand is the layer input; the staged halo is the 3x3 one and the taps read rows / columns (kh + kh0, kw + kw0) of it.
+    int kh0 = 0, kw0 = 0, byc = by;
+    if constexpr (KS == 2) { const int per = a.ncot * a.ncit, par = by / per; byc = by - par * per; kh0 = 1 - (par >> 1); kw0 = 1 - (par & 1); }
+    const int cot = byc / a.ncit, cit = byc - cot * a.ncit;
     const int co0 = cot * CO_T, ci0 = cit * CI_T;
-    const T* __restrict__ xg = (const T*)a.x;
+    const size_t xs_p = a.xs_p ? (size_t)a.xs_p : (size_t)a.ldx, xs_r = a.xs_r ? (size_t)a.xs_r : (size_t)a.W * a.ldx,
+                 xs_n = a.xs_n ? (size_t)a.xs_n : (size_t)a.H * a.W * a.ldx;
+    const T* __restrict__ xg = (const T*)a.x + (KS == 2 ? ((size_t)(1 - kh0) * a.Wo + (1 - kw0)) * a.ldx : (size_t)0);
     const T* __restrict__ dyg = (const T*)a.dy;
     const bool has_pro = a.pro_scale != nullptr;
     const float relu_lo = a.pro_relu ? 0.f : -__builtin_inff();
@@ -971,7 +983,7 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
             int hy = pix / HC, hx = pix - hy * HC;
             int iy = ty0 + hy - PAD, ix = tx0 + hx - PAD;
             int c; const bool ok = x_ok(ty0, tx0, b0 + i, c);
-            xreg[i] = load_chunk<T, ALIGNED>(xg + (ok ? (((size_t)n * a.H + iy) * a.W + ix) * a.ldx : (size_t)0), ok ? c : 0, a.Cin);
+            xreg[i] = load_chunk<T, ALIGNED>(xg + (ok ? (size_t)n * xs_n + (size_t)iy * xs_r + (size_t)ix * xs_p : (size_t)0), ok ? c : 0, a.Cin);
         }
     };
     auto store_x = [&](int ty0, int tx0, u32x4* xreg, int b0, int cnt) {
@@ -1058,7 +1070,7 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
 #pragma unroll
                     for (int nn = 0; nn < NI; ++nn) {
                         u32x4 bf;
-                        const unsigned char* base = s_x + ((ty + kh) * HC + kw + 8 * khalf + (li >> 2)) * PX + (wn0 + nn * 32 + 16 * nhalf + 4 * (li & 3)) * 2;
+                        const unsigned char* base = s_x + ((ty + kh + kh0) * HC + kw + kw0 + 8 * khalf + (li >> 2)) * PX + (wn0 + nn * 32 + 16 * nhalf + 4 * (li & 3)) * 2;
                         tr_read2(base, 4 * PX, bf);
 #pragma unroll
                         for (int m = 0; m < MI; ++m)
@@ -1078,7 +1090,7 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
                         const int kh = t / KS, kw = t - kh * KS;
 #pragma unroll
                         for (int nn = 0; nn < NI; ++nn) {
-                            float bv = *(const float*)(s_x + ((ty + kh) * HC + kw + k + lh) * PX + (wn0 + nn * 32 + lr) * 4);
+                            float bv = *(const float*)(s_x + ((ty + kh + kh0) * HC + kw + kw0 + k + lh) * PX + (wn0 + nn * 32 + lr) * 4);
 #pragma unroll
                             for (int m = 0; m < MI; ++m) acc[m][nn][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bv, acc[m][nn][t], 0, 0, 0);
                         }
@@ -1116,7 +1128,8 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         int co = co0 + wm0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (co < a.Cout && ci < a.Cin) a.ws[(size_t)gx * a.wsize + (size_t)co * a.sM + (size_t)ci * a.sN + t] = acc[m][nn][j][r];
+                        const int toff = KS == 2 ? (kh0 + 2 * (t >> 1)) * 4 + kw0 + 2 * (t & 1) : t;
+                        if (co < a.Cout && ci < a.Cin) a.ws[(size_t)gx * a.wsize + (size_t)co * a.sM + (size_t)ci * a.sN + toff] = acc[m][nn][j][r];
                     }
                 }
             }
@@ -1153,6 +1166,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_wgrad_grouped_kernel(Grouped
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.ntiles = g.ntiles; a.ncit = it.ncit;
     a.sM = (long)it.Cin * g.taps; a.sN = g.taps;
     a.ws = it.ws; a.wsize = (long)it.Cout * it.Cin * g.taps; a.pend = nullptr;
+    a.xs_n = a.xs_r = a.xs_p = 0; a.ncot = 0; a.Wo = 0;
     const int local = (int)blockIdx.x - it.blk0;
     const int by = local / g.groups, gx = local - by * g.groups;
     tile_wgrad_body<T, KS, TR, CO_T, CI_T, WM, WN, KSPLIT, true>(a, gx, g.groups, by, smem);
@@ -1195,13 +1209,14 @@ template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KS
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
     a.tiles_y = a.H / TR; a.tiles_x = a.W / TILE; a.ntiles = a.N * a.tiles_y * a.tiles_x;
-    const int ncot = cdiv(a.Cout, CO_T); a.ncit = cdiv(a.Cin, CI_T);
-    const int groups = tile_wgrad_groups(a.ntiles, ncot * a.ncit);
-    a.wsize = (long)a.Cout * a.Cin * KS * KS;
+    constexpr int PARS = KS == 2 ? 4 : 1;                      // conv-transpose: the four output parities ride on blockIdx.y
+    const int ncot = cdiv(a.Cout, CO_T); a.ncit = cdiv(a.Cin, CI_T); a.ncot = ncot;
+    const int groups = tile_wgrad_groups(a.ntiles, ncot * a.ncit * PARS);
+    a.wsize = (long)a.Cout * a.Cin * (KS == 2 ? 16 : KS * KS);
     const size_t bytes = (size_t)groups * a.wsize * sizeof(float);
     if (need) { *need = bytes; return SAUNET_OK; }
     if (a.ws == nullptr || ws_bytes < bytes) return set_error(SAUNET_BAD_SHAPE, "wgrad: workspace %zu < %zu bytes", ws_bytes, bytes);
-    dim3 grid(groups, ncot * a.ncit);
+    dim3 grid(groups, ncot * a.ncit * PARS);
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, a);
     if (a.pend) {
         a.pend->ws = a.ws; a.pend->dw = a.dw; a.pend->wsize = a.wsize; a.pend->groups = groups; a.pend->reserved = 0;
@@ -1422,10 +1437,33 @@ int tile_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const f
     a.x = x; a.dy = dy; a.dw = dw; a.pro_scale = ps; a.pro_shift = psh; a.pro_relu = d->pro_relu;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Cout = d->Cout; a.lddy = d->ldy;
     a.sM = (long)d->Cin * d->KH * d->KW; a.sN = (long)d->KH * d->KW;
+    a.xs_n = a.xs_r = a.xs_p = 0; a.ncot = 0; a.Wo = 0;
     if (aligned && !need && (((uintptr_t)x | (uintptr_t)dy) & 15)) return set_error(SAUNET_BAD_ALIGN, "wgrad: pointers must be 16-byte aligned");
     if (d->dtype == SAUNET_BF16) return dispatch_tile_wgrad<u16>(a, d->KH, aligned, ws_bytes, need, st);
     if (d->dtype == SAUNET_F32) return dispatch_tile_wgrad<float>(a, d->KH, aligned, ws_bytes, need, st);
     return set_error(SAUNET_BAD_DTYPE, "wgrad: dtype %d", d->dtype);
+}
+
+// Weight gradient of ConvTranspose2d(k = 4, s = 2, p = 1) straight from the NHWC tensors (no im2col of dy: that pass wrote and the GEMM re-read four
+// copies of dy): d describes the transposed convolution (x [N,H,W,Cin], dy [N,2H,2W,Cout], dw [Cin][Cout][4][4]).  See the KS == 2 notes in tile_wgrad_body.
+bool tile_wgrad_convt_supported(const saunet_conv_desc* d)
+{
+    return d->transposed && d->dtype == SAUNET_BF16 && d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && d->Ho == 2 * d->H && d->Wo == 2 * d->W &&
+           d->H % TILE == 0 && d->W % TILE == 0 && d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0;
+}
+int tile_wgrad_convt(const saunet_conv_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, size_t* need, hipStream_t st,
+                     saunet_wgrad_pending* pend)
+{
+    TileWgradArgs a;
+    a.pend = pend; a.ws = (float*)ws;
+    a.x = dy; a.dy = x; a.dw = dw; a.pro_scale = nullptr; a.pro_shift = nullptr; a.pro_relu = 0;      // roles swapped: the haloed operand is dy's parity image
+    a.N = d->N; a.H = d->H; a.W = d->W;
+    a.Cin = d->Cout; a.ldx = d->ldy;          // "input channels" of the kernel = channels of the haloed operand = the layer's output channels
+    a.Cout = d->Cin; a.lddy = d->ldx;         // "output channels" = channels of the un-haloed operand = the layer's input channels
+    a.xs_p = 2L * d->ldy; a.xs_r = 2L * d->Wo * d->ldy; a.xs_n = (long)d->Ho * d->Wo * d->ldy; a.Wo = d->Wo; a.ncot = 0;
+    a.sM = (long)d->Cout * 16; a.sN = 16;     // dw[ci][co][kh][kw]
+    if (!need && (((uintptr_t)x | (uintptr_t)dy) & 15)) return set_error(SAUNET_BAD_ALIGN, "conv-transpose wgrad: pointers must be 16-byte aligned");
+    return launch_tile_wgrad<u16, 2, 8, 64, 64, 32, 32, 1>(a, ws_bytes, need, st);
 }
 
 }  // namespace saunet

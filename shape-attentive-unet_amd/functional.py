@@ -512,8 +512,16 @@ def conv_wgrad_grouped(problems, ksize, pad, pro_relu):
     return out
 
 
+# ConvTranspose2d(k4 s2 p1) weight gradients straight from the NHWC tensors on the tiled kernel (four parity sub-problems with 2x2 taps, csrc/conv_tile.hip
+# KS == 2); "0" = the round-2 path (im2col of dy + pointwise weight gradient), kept for maps that are not multiples of 16 and as the A/B reference
+CONVT_WGRAD_DIRECT = os.environ.get("SAUNET_CONVT_WGRAD_DIRECT", "1") != "0"
+
+
 def _conv_wgrad_impl(x, dy, weight, stride, pad, transposed=False, pro=None, pending=None):
-    if transposed and pro is None and weight.shape[2:] == (4, 4) and weight.shape[1] % 8 == 0 and weight.shape[0] % 8 == 0:
+    direct_t = (CONVT_WGRAD_DIRECT and transposed and pro is None and x.dtype == torch.bfloat16 and tuple(weight.shape[2:]) == (4, 4)
+                and x.shape[2] % 16 == 0 and x.shape[3] % 16 == 0 and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0 and ld_of(x) % 8 == 0
+                and ld_of(dy) % 8 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0)
+    if transposed and not direct_t and pro is None and weight.shape[2:] == (4, 4) and weight.shape[1] % 8 == 0 and weight.shape[0] % 8 == 0:
         # ConvTranspose2d(k=4, s=2, p=1):  dW[ci][co][kh][kw] = sum x[n,ih,iw,ci] * dy[n, 2ih-1+kh, 2iw-1+kw, co]  is the weight
         # gradient of a POINTWISE conv from im2col(dy; k=4, s=2, p=1) (K order kh,kw,co) to x: one gather pass over dy,
         # then the transposing-read matrix-core kernel instead of the generic atomic split-K one (3-5x faster).

@@ -96,7 +96,8 @@ def test_conv2d_fwd_bwd(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("case", [(2, 64, 8, 8, 64), (1, 48, 16, 16, 32), (2, 128, 4, 4, 128)])
+@pytest.mark.parametrize("case", [(2, 64, 8, 8, 64), (1, 48, 16, 16, 32), (2, 128, 4, 4, 128),
+                                  (2, 128, 32, 16, 72), (1, 256, 16, 32, 256)])      # maps that are multiples of 16 (bf16): the direct parity weight gradient
 def test_conv_transpose_fwd_bwd(case, dtype):
     n, ci, h, w, co = case
     hf = HF()
