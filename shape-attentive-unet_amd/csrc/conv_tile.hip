@@ -1054,7 +1054,7 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
         }
         TSTAMP(25);
         // ---- one MFMA K-step = one tile row (16 pixels)
-        for (int ty = kwave; ty < TR; ty += KSP) {
+        auto k_step = [&](int ty) {
             if constexpr (sizeof(T) == 2) {
                 u32x4 af[MI];
 #pragma unroll
@@ -1097,6 +1097,12 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
                     }
                 }
             }
+        };
+        if constexpr (KS == 2) {       // two tile rows per iteration: the second row's fragment reads are in flight behind the first row's MFMAs
+            static_assert(KS != 2 || (KSP == 1 && TR % 2 == 0), "conv-transpose variant: unsplit K, even tile rows");
+            for (int ty = 0; ty < TR; ty += 2) { k_step(ty); k_step(ty + 1); }
+        } else {
+            for (int ty = kwave; ty < TR; ty += KSP) k_step(ty);
         }
     }
     TSTAMP(26);
