@@ -281,8 +281,10 @@ int saunet_global_pool_backward(int dtype, int mode, const float* dy, const int*
 
 /* ---- fused GatedSpatialConv2d (models/GSConv.py:16-57; call sites models/models.py:341-352) ----------------------
  * Replaces  cat -> BN(C+1) -> conv1x1(C+1,C+1) -> relu -> conv1x1(C+1,1) -> BN(1) -> sigmoid -> x*(alpha+1) -> conv1x1(C,C)
- * for C = 8/16/32 feature channels + 1 gating channel, bf16 storage, training-mode batch norm.  One thread owns one
- * pixel; intermediate maps never reach memory; backward recomputes them.  Parameter vectors are float32:
+ * for C = 8/16/32 feature channels + 1 gating channel, bf16 storage, training-mode batch norm.  The chain is recomputed per
+ * pixel (a wave owns 32 pixels per tile; the (C+1)x(C+1) products run on the matrix cores with the pixel's NHWC row as the
+ * B operand and the float32 weights as bf16 hi + lo A fragments); intermediate maps never reach memory; backward recomputes
+ * them.  Parameter vectors are float32:
  *   bn0 [4][C+1] = scale, shift, mean, invstd of BN(C+1) (saunet_bn_finalize layout);  bn1 [4][1] likewise for BN(1);
  *   w1 [C+1][C+1], b1 [C+1], w2 [C+1], b2 [1] the two gate convolutions;  wm [C][C] the module weight (no bias).
  * forward_z:   z[p] = w2 . relu(w1 . bn0(cat_p) + b1) + b2 (float32) and its sum / sum of squares (replicated float64

@@ -1,7 +1,9 @@
 """GPU parity of the fused GatedSpatialConv2d kernels (csrc/gate.hip) against a float64 restatement of the module
 (/root/reference/models/GSConv.py:16-57) evaluated on the SAME bf16-rounded inputs and float32 parameters.  The fused
-path keeps every intermediate in float32 registers, so outputs differ from the float64 result only by their final bf16
-rounding (2^-9 relative); cross-pixel sums use bf16 matrix-core operands (weight gradients: ~1e-2 of the tensor's scale)."""
+path keeps every intermediate in float32 accumulators (the per-pixel products run on the matrix cores with the float32 weights as
+bf16 hi + lo operand pairs and the bf16 activations exactly as stored: ~2^-17 relative), so outputs differ from the float64 result
+only by their final bf16 rounding (2^-9 relative); the second backward product (W1^T dh) and the cross-pixel sums use single bf16
+matrix-core operands (input / weight gradients: ~1e-2 of the tensor's scale)."""
 import pytest
 import torch
 import torch.nn.functional as F
