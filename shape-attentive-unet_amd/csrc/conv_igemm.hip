@@ -403,7 +403,13 @@ template <typename T> static int dispatch_fwd(const IgemmArgs& a, int phases, hi
         const long blocks64 = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64) * phases;
         if (blocks64 < t32 && !a.epi.bn_x)
             return narrow ? launch_fwd<T, 32, 64, 32, 32, 4>(a, phases, st) : launch_fwd<T, 32, 64, 32, 32, 8>(a, phases, st);
-        if (blocks128 < 384)
+        // A/B probe (SAUNET_IGEMM_T64X128=1): 64 pixels x 128 output channels per workgroup on the small maps -- the pixel rows are read once instead
+        // of once per 64-channel column tile
+        static const bool t64x128 = getenv("SAUNET_IGEMM_T64X128") && getenv("SAUNET_IGEMM_T64X128")[0] == '1';
+        if (blocks128 < 384 && t64x128 && a.Cout % 128 == 0 && !a.epi.bn_x)
+            return narrow ? launch_fwd<T, 64, 128, 32, 64, 4>(a, phases, st) : launch_fwd<T, 64, 128, 32, 64, 8>(a, phases, st);
+        static const long bigmin = getenv("SAUNET_IGEMM_BIGMIN") ? atol(getenv("SAUNET_IGEMM_BIGMIN")) : 384;      // A/B probe
+        if (blocks128 < bigmin)
             return narrow ? launch_fwd<T, 64, 64, 32, 32, 4>(a, phases, st) : launch_fwd<T, 64, 64, 32, 32, 8>(a, phases, st);
         return narrow ? launch_fwd<T, 128, 128, 64, 64, 4>(a, phases, st) : launch_fwd<T, 128, 128, 64, 64, 8>(a, phases, st);
     }

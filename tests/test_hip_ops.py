@@ -391,3 +391,33 @@ def test_deferred_wgrad_reduction_matches_the_immediate_one(dtype):
     assert not pend
     for a, b in zip(deferred, immediate):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(32, 128, 3, 3), (40, 72, 3, 3), (128, 200, 1, 1), (64, 8, 7, 7), (9, 33, 1, 1)])
+def test_weight_packings_are_the_documented_permutations(dtype, shape):
+    """include/saunet_hip.h saunet_pack_mode: FWD [Co][kh][kw][Ci], DGRAD [Ci][kh'][kw'][Co] with flipped taps (tiled through LDS since round 3;
+    ragged channel counts and the element-wise path of the 7x7 stem included)"""
+    import ctypes as C
+    from saunet_amd import lib as L
+    co, ci, kh, kw = shape
+    w = rnd(co, ci, kh, kw).cuda()
+    for mode, ref in ((L.PACK_FWD, w.permute(0, 2, 3, 1)), (L.PACK_DGRAD, w.flip(2, 3).permute(1, 2, 3, 0))):
+        out = torch.full((w.numel(),), float("nan"), dtype=dtype, device="cuda")
+        L.call("saunet_pack_weight", mode, L.BF16 if dtype == torch.bfloat16 else L.F32, w.data_ptr(), co, ci, kh, kw, out.data_ptr(), L.stream())
+        assert torch.equal(out, ref.contiguous().reshape(-1).to(dtype)), (mode, shape)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(64, 32), (48, 40), (130, 8)])
+def test_conv_transpose_weight_packings(dtype, shape):
+    """CONVT_FWD [ph][pw][Co][th][tw][Ci] with kh = (1 - ph) + 2 th, kw = (1 - pw) + 2 tw;  CONVT_DGRAD [Ci][kh][kw][Co]"""
+    from saunet_amd import lib as L
+    ci, co = shape
+    w = rnd(ci, co, 4, 4).cuda()
+    v = w.view(ci, co, 2, 2, 2, 2)                       # kh = 2 th + (1 - ph): dims (th, q = 1 - ph, tw, r = 1 - pw)
+    fwd = v.flip(3, 5).permute(3, 5, 1, 2, 4, 0)         # [ph][pw][co][th][tw][ci]
+    for mode, ref in ((L.PACK_CONVT_FWD, fwd), (L.PACK_CONVT_DGRAD, w.permute(0, 2, 3, 1))):
+        out = torch.full((w.numel(),), float("nan"), dtype=dtype, device="cuda")
+        L.call("saunet_pack_weight", mode, L.BF16 if dtype == torch.bfloat16 else L.F32, w.data_ptr(), co, ci, 4, 4, out.data_ptr(), L.stream())
+        assert torch.equal(out, ref.contiguous().reshape(-1).to(dtype)), (mode, shape)
