@@ -116,6 +116,7 @@ def run(size=128, batch=8, steps=300, pool=64, eval_n=32, seed=304, optimizer="r
             if "f32p" in out:
                 dp_ = np.array(out["f32p"]["dice"]) - np.array(out["f32"]["dice"])
                 out["delta"]["f32_noise_floor_max_abs_dice_delta"] = round(float(np.abs(dp_).max()), 5)
+                out["delta"]["f32_noise_floor_mean_dice_delta"] = round(float(dp_.mean()), 5)
     finally:
         M.set_compute_dtype(prev)
     return out

@@ -31,7 +31,8 @@ def test_bf16_training_reaches_the_float32_dice():
     assert f32["loss_last"] < 0.25 * f32["loss_first"] and bf16["loss_last"] < 0.25 * bf16["loss_first"]
     # bf16 storage costs no Dice beyond the run-to-run drift of float32 training itself (floor: 3 Dice points for a 32-slice validation set)
     assert d["max_abs_dice_delta"] <= max(3.0 * d["f32_noise_floor_max_abs_dice_delta"], 0.03), d
-    assert abs(d["mean_dice_delta"]) <= 0.02, d
+    # (the mean over the three classes drifts too: two float32 runs from weights 1e-6 apart have been seen 0.028 apart in mean Dice on this 32-slice set)
+    assert abs(d["mean_dice_delta"]) <= max(2.0 * abs(d["f32_noise_floor_mean_dice_delta"]), 0.02), d
     assert d["loss_curve_rel_distance"] <= 0.05, d
 
 
