@@ -102,28 +102,6 @@ template <int NS> __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgra
     const int GCP = (GC + 31) & ~31;
     u16* s_w = (u16*)d_smem;                             // [GCP][DG_WPITCH]
     float* s_par = (float*)(d_smem + (size_t)GCP * DG_WPITCH * 2);   // [4][GCP] scale, shift, invstd, -mean*invstd
-    constexpr int NT = DG_WAVES * 64;
-    for (int i0 = threadIdx.x; i0 < GCP * 16; i0 += NT * 8) {     // 8 loads in flight per thread: the copy costs ~2 memory latencies
-        u32x4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = min(i0 + u * NT, GCP * 16 - 1), r = i >> 4, ch = i & 15;
-            v[u] = *(const u32x4*)(a.w + (size_t)min(g0 + r, a.Cin - 1) * 128 + ch * 8);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * NT, r = i >> 4, ch = i & 15;
-            if (i < GCP * 16) *(u32x4*)(s_w + r * DG_WPITCH + ch * 8) = v[u];
-        }
-    }
-    for (int i = threadIdx.x; i < GCP; i += NT) {
-        const bool ok = i < GC;
-        const float is = ok ? a.invstd[g0 + i] : 0.f;
-        s_par[i] = ok ? a.scale[g0 + i] : 0.f; s_par[GCP + i] = ok ? a.shift[g0 + i] : 0.f;
-        s_par[2 * GCP + i] = is; s_par[3 * GCP + i] = ok ? -a.mean[g0 + i] * is : 0.f;
-    }
-    __syncthreads();
-    TSTAMP(41);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
     const unsigned ntp = (a.P + 31) / 32;
     const unsigned stride = gridDim.x * DG_WAVES;
@@ -151,12 +129,34 @@ template <int NS> __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgra
 #pragma unroll
         for (int k = 0; k < 4; ++k) red[i][k] = 0.f;
     const bool sd0 = lane & 8, sd1 = lane & 4, sd2 = lane & 1, sd3 = lane & 2;
-    {
+    {       // the first tile's operands are requested BEFORE the weight copy: both are one memory latency, now overlapped (they were sequential)
         const unsigned tp0 = min(blockIdx.x * DG_WAVES + wave, ntp - 1);
         const size_t pp0 = min(tp0 * 32u + lr, a.P - 1);
         request_g(pp0);
         request_x(pp0, 0, xa, 8 * lh);
     }
+    constexpr int NT = DG_WAVES * 64;
+    for (int i0 = threadIdx.x; i0 < GCP * 16; i0 += NT * 8) {     // 8 loads in flight per thread: the copy costs ~2 memory latencies
+        u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + u * NT, GCP * 16 - 1), r = i >> 4, ch = i & 15;
+            v[u] = *(const u32x4*)(a.w + (size_t)min(g0 + r, a.Cin - 1) * 128 + ch * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * NT, r = i >> 4, ch = i & 15;
+            if (i < GCP * 16) *(u32x4*)(s_w + r * DG_WPITCH + ch * 8) = v[u];
+        }
+    }
+    for (int i = threadIdx.x; i < GCP; i += NT) {
+        const bool ok = i < GC;
+        const float is = ok ? a.invstd[g0 + i] : 0.f;
+        s_par[i] = ok ? a.scale[g0 + i] : 0.f; s_par[GCP + i] = ok ? a.shift[g0 + i] : 0.f;
+        s_par[2 * GCP + i] = is; s_par[3 * GCP + i] = ok ? -a.mean[g0 + i] * is : 0.f;
+    }
+    __syncthreads();
+    TSTAMP(41);
     for (unsigned tp = blockIdx.x * DG_WAVES + wave; tp < ntp; tp += stride) {
         const unsigned p = tp * 32u + lr;
         const bool live = p < a.P;
