@@ -20,6 +20,10 @@ elif case in ("conv2wgrad", "conv1wgrad", "dec3wgrad"):
     x = act(cin, h); dy = act(cout, h); w = torch.nn.Parameter(torch.randn(cout, cin, k, k, device="cuda") * 0.03)
     sc = torch.rand(cin, device="cuda") + 0.5; sh = torch.randn(cin, device="cuda") * 0.1
     run = lambda: (HF.GRADS.reset(), HF.conv_wgrad_raw(x, dy, w, 1, k // 2, pro=(sc, sh, True) if case != "dec3wgrad" else None))
+elif case in ("dec4convtwgrad", "dec2convtwgrad"):
+    ci, h = {"dec4convtwgrad": (512, 16), "dec2convtwgrad": (128, 64)}[case]
+    x = act(ci, h); dy = act(ci, 2 * h); w = torch.nn.Parameter(torch.randn(ci, ci, 4, 4, device="cuda") * 0.03)
+    run = lambda: (HF.GRADS.reset(), HF.conv_wgrad_raw(x, dy, w, 2, 1, transposed=True))
 elif case in ("dec3fwd", "dec5fwd"):
     cin, h, cout = {"dec3fwd": (512, 64, 128), "dec5fwd": (1536, 16, 512)}[case]
     x = act(cin, h); w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device="cuda") * 0.02)
