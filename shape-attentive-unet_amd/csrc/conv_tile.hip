@@ -956,8 +956,16 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
             int q = tid + i * 256, pix = q / CHY, ch = q - pix * CHY;
             int c = co0 + ch * EPC;
             bool ok = (YI * 256 == NPY * CHY || q < NPY * CHY) && c < a.Cout;
-            size_t off = ok ? (((size_t)n * a.H + ty0 + pix / TILE) * a.W + tx0 + (pix % TILE)) * a.lddy : (size_t)0;
-            yreg[i] = load_chunk<T, ALIGNED>(dyg + off, ok ? c : 0, a.Cout);
+            if constexpr (ALIGNED) {
+                // tile origin = block-uniform 64-bit scalar arithmetic; per lane only a 32-bit offset inside the tile (the 64-bit multiply chains of
+                // the absolute form were ~20 VALU instructions per 16-byte load)
+                const T* ytile = dyg + (((size_t)n * a.H + ty0) * a.W + tx0) * a.lddy;
+                const int rel = (((pix / TILE) * a.W + (pix % TILE)) * a.lddy + c) & -(int)ok;      // masked, not selected: a select becomes an exec-mask branch around the load
+                yreg[i] = *(const u32x4*)(ytile + rel);
+            } else {
+                size_t off = ok ? (((size_t)n * a.H + ty0 + pix / TILE) * a.W + tx0 + (pix % TILE)) * a.lddy : (size_t)0;
+                yreg[i] = load_chunk<T, ALIGNED>(dyg + off, ok ? c : 0, a.Cout);
+            }
         }
     };
     auto store_y = [&](const u32x4* yreg) {
@@ -983,7 +991,13 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
             int hy = pix / HC, hx = pix - hy * HC;
             int iy = ty0 + hy - PAD, ix = tx0 + hx - PAD;
             int c; const bool ok = x_ok(ty0, tx0, b0 + i, c);
-            xreg[i] = load_chunk<T, ALIGNED>(xg + (ok ? (size_t)n * xs_n + (size_t)iy * xs_r + (size_t)ix * xs_p : (size_t)0), ok ? c : 0, a.Cin);
+            if constexpr (ALIGNED) {
+                const T* xtile = xg + (size_t)n * xs_n + (size_t)ty0 * xs_r + (size_t)tx0 * xs_p;      // block-uniform
+                const int rel = ((hy - PAD) * (int)xs_r + (hx - PAD) * (int)xs_p + c) & -(int)ok;      // |rel| < 2^31: a few rows of the map
+                xreg[i] = *(const u32x4*)(xtile + rel);
+            } else {
+                xreg[i] = load_chunk<T, ALIGNED>(xg + (ok ? (size_t)n * xs_n + (size_t)iy * xs_r + (size_t)ix * xs_p : (size_t)0), ok ? c : 0, a.Cin);
+            }
         }
     };
     auto store_x = [&](int ty0, int tx0, u32x4* xreg, int b0, int cnt) {
@@ -1016,7 +1030,7 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
     };
     // register prefetch: the NEXT tile's global loads are issued right after this tile is in LDS and fly during its matrix-core loop
     // (without it every tile pays load latency -> LDS -> barrier -> MFMA in sequence; two resident blocks per CU hide only part of it)
-    constexpr bool PF = (SAUNET_WGRAD_PREFETCH || TS) && ALIGNED && sizeof(T) == 2 && (YI + XI) <= 16;
+    constexpr bool PF = (SAUNET_WGRAD_PREFETCH || TS || KS == 2) && ALIGNED && sizeof(T) == 2 && (YI + XI) <= 16;
     u32x4 pyreg[PF ? YI : 1], pxreg[PF ? XI : 1];
     if constexpr (PF) {
         if (gx < a.ntiles) { int n, ty0, tx0; tile_coords(gx, n, ty0, tx0); load_y(n, ty0, tx0, pyreg); load_x(n, ty0, tx0, pxreg, 0, XI); }
@@ -1471,6 +1485,8 @@ int tile_wgrad_convt(const saunet_conv_desc* d, const void* x, const void* dy, f
     if (!need && (((uintptr_t)x | (uintptr_t)dy) & 15)) return set_error(SAUNET_BAD_ALIGN, "conv-transpose wgrad: pointers must be 16-byte aligned");
     // (measured at dec4, 189 us: a 128 x 64 channel tile with 64 x 32 per wave -- each haloed-operand fragment feeding two MFMAs -- 264 us; the register
     // prefetch of the next tile, which fits here without spills, 194 us: the tile loop is bound by the transposing LDS fragment reads, not by load latency)
+    static const bool wide = getenv("SAUNET_CONVT_WGRAD_WIDE") && getenv("SAUNET_CONVT_WGRAD_WIDE")[0] == '1';      // A/B probe (see above)
+    if (wide && a.Cout >= 128) return launch_tile_wgrad<u16, 2, 8, 128, 64, 64, 32, 1>(a, ws_bytes, need, st);
     return launch_tile_wgrad<u16, 2, 8, 64, 64, 32, 32, 1>(a, ws_bytes, need, st);
 }
 
