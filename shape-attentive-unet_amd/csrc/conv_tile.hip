@@ -1121,7 +1121,7 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
     }
     TSTAMP(26);
     const int lr = lane & 31, lh = lane >> 5;
-    float* s_red = (float*)smem;   // [KSP-1][64 lanes][16] floats per (m, n, tap) round
+    float* s_red = (float*)smem;   // [channel wave][KSP-1][16][64 lanes] floats per (m, n, tap) round
 #pragma unroll
     for (int m = 0; m < MI; ++m)
 #pragma unroll
@@ -1134,14 +1134,14 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
                     __syncthreads();
                     if (kwave > 0) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) s_red[((kwave - 1) * 16 + r) * 64 + lane] = acc[m][nn][j][r];
+                        for (int r = 0; r < 16; ++r) s_red[((cwave * (KSP - 1) + kwave - 1) * 16 + r) * 64 + lane] = acc[m][nn][j][r];
                     }
                     __syncthreads();
                     if (kwave == 0) {
 #pragma unroll
                         for (int k = 0; k < KSP - 1; ++k)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[m][nn][j][r] += s_red[(k * 16 + r) * 64 + lane];
+                            for (int r = 0; r < 16; ++r) acc[m][nn][j][r] += s_red[((cwave * (KSP - 1) + k) * 16 + r) * 64 + lane];
                     }
                 }
                 if (kwave == 0 && t < TAPS) {
@@ -1222,7 +1222,7 @@ template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KS
     constexpr int PY = sizeof(T) == 2 ? ((PY_RAW % 128 == 64) ? PY_RAW : PY_RAW + 64) : PY_RAW;
     constexpr int PX = sizeof(T) == 2 ? ((PX_RAW % 128 == 64) ? PX_RAW : PX_RAW + 64) : PX_RAW;
     constexpr int LDS_MAIN = NPY * PY + NPX * PX;
-    constexpr int LDS_RED = KSPLIT > 1 ? (KSPLIT - 1) * 16 * 64 * 4 : 0;   // (tap split: no cross-wave reduction)
+    constexpr int LDS_RED = KSPLIT > 1 ? (4 / KSPLIT) * (KSPLIT - 1) * 16 * 64 * 4 : 0;   // per channel wave; (tap split: no cross-wave reduction)
     constexpr int LDS = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
     static_assert(LDS <= 160 * 1024, "tile does not fit LDS");
     auto kern = conv_tile_wgrad_kernel<T, KS, TR, CO_T, CI_T, WM, WN, KSPLIT, ALIGNED>;
@@ -1333,7 +1333,7 @@ static int launch_tile_wgrad_grouped(GroupedWgradArgs& g, const saunet_wgrad_gro
     constexpr int PY = sizeof(T) == 2 ? ((PY_RAW % 128 == 64) ? PY_RAW : PY_RAW + 64) : PY_RAW;
     constexpr int PX = sizeof(T) == 2 ? ((PX_RAW % 128 == 64) ? PX_RAW : PX_RAW + 64) : PX_RAW;
     constexpr int LDS_MAIN = NPY * PY + NPX * PX;
-    constexpr int LDS_RED = KSPLIT > 1 ? (KSPLIT - 1) * 16 * 64 * 4 : 0;   // (tap split: no cross-wave reduction)
+    constexpr int LDS_RED = KSPLIT > 1 ? (4 / KSPLIT) * (KSPLIT - 1) * 16 * 64 * 4 : 0;   // per channel wave; (tap split: no cross-wave reduction)
     constexpr int LDS = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
     auto kern = conv_tile_wgrad_grouped_kernel<T, KS, TR, CO_T, CI_T, WM, WN, KSPLIT>;
     static bool attr_set = false;
@@ -1435,6 +1435,11 @@ int tile_wgrad_grouped(const saunet_wgrad_group* s, void* ws, size_t ws_bytes, s
             // all 16 dy fragments and wave 0 carries 3 of the 9 taps), blocks 2-4 5-15 % faster; step +0.25 ms.  Off.
             static const bool tapsplit = getenv("SAUNET_WGRAD3_TS") && getenv("SAUNET_WGRAD3_TS")[0] == '1';
             if (small && tapsplit) return launch_tile_wgrad_grouped<u16, 3, 16, 32, 32, 32, 32, -4>(g, s, ws, ws_bytes, need, st);
+            // DenseNet conv2 (128 -> 32): 64 input channels per workgroup (two channel waves x two K waves) -- the dy tile is re-read per 64 instead of per
+            // 32 input channels (the block-1 launch is HBM-bound at 1.47x its algorithmic bytes): 27.71 -> 27.50 ms per step.  SAUNET_WGRAD3_CI64=0 = the
+            // 32-channel tile with four K waves
+            static const bool ci64 = !(getenv("SAUNET_WGRAD3_CI64") && getenv("SAUNET_WGRAD3_CI64")[0] == '0');
+            if (small && ci64 && all_128_32) return launch_tile_wgrad_grouped<u16, 3, 16, 32, 64, 32, 32, 2>(g, s, ws, ws_bytes, need, st);
             if (small) return launch_tile_wgrad_grouped<u16, 3, 16, 32, 32, 32, 32, 4>(g, s, ws, ws_bytes, need, st);
             return launch_tile_wgrad_grouped<u16, 3, 8, 64, 64, 32, 32, 1>(g, s, ws, ws_bytes, need, st);
         }
