@@ -1490,8 +1490,6 @@ int tile_wgrad_convt(const saunet_conv_desc* d, const void* x, const void* dy, f
     if (!need && (((uintptr_t)x | (uintptr_t)dy) & 15)) return set_error(SAUNET_BAD_ALIGN, "conv-transpose wgrad: pointers must be 16-byte aligned");
     // (measured at dec4, 189 us: a 128 x 64 channel tile with 64 x 32 per wave -- each haloed-operand fragment feeding two MFMAs -- 264 us; the register
     // prefetch of the next tile, which fits here without spills, 194 us: the tile loop is bound by the transposing LDS fragment reads, not by load latency)
-    static const bool wide = getenv("SAUNET_CONVT_WGRAD_WIDE") && getenv("SAUNET_CONVT_WGRAD_WIDE")[0] == '1';      // A/B probe (see above)
-    if (wide && a.Cout >= 128) return launch_tile_wgrad<u16, 2, 8, 128, 64, 64, 32, 1>(a, ws_bytes, need, st);
     return launch_tile_wgrad<u16, 2, 8, 64, 64, 32, 32, 1>(a, ws_bytes, need, st);
 }
 
