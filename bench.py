@@ -379,8 +379,8 @@ def dry_run(args, S, dp):
     protocol (barrier, K steps, max over ranks) and rank 0's JSON line with the `comm` record.  The step itself is a stand-in (a gradient of
     the right shape for every SAUNet parameter); the CPU suite runs this with two ranks (tests/test_bench_dry.py)."""
     rank, local, world = dp.init_from_env(backend="gloo")
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but %d rank(s) were launched" % (args.gpus, world))
     torch.manual_seed(304 + rank)                     # different replicas before the broadcast
     net = S.SAUNet(num_classes=4)
     dp.broadcast_parameters(net)
@@ -439,8 +439,30 @@ def dry_run(args, S, dp):
         torch.distributed.destroy_process_group()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` WITHOUT a launcher (N > 1, no WORLD_SIZE in the environment): re-execute this command line as N ranks through
+    torch.distributed.run on 127.0.0.1 -- one process per GPU, as /root/reference/train.py:272-277,404 intends one replica per device -- and
+    exit with its status.  Without this the run would silently measure ONE GPU and print n_gpus = 1."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if env_world == 0 and args.gpus > 1 and not (args.roofline_only or args.infer):
+        self_launch(args)
+    if env_world not in (0, args.gpus) and not (args.roofline_only or args.infer):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch exactly one rank per requested GPU" % (args.gpus, env_world))
     import saunet_amd as S
     from saunet_amd import dp, data, optim
     if args.roofline_only:
@@ -458,10 +480,10 @@ def main():
     if args.dry_run:
         return dry_run(args, S, dp)
     rank, local, world = dp.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if world > 1 and torch.distributed.get_backend() == "nccl" and torch.distributed.get_world_size() != world:
-        raise SystemExit("RCCL group has %d ranks, expected %d" % (torch.distributed.get_world_size(), world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but %d rank(s) were launched" % (args.gpus, world))
+    if world > 1 and ((torch.distributed.get_backend() != "nccl" and not os.environ.get("SAUNET_DIST_BACKEND")) or torch.distributed.get_world_size() != args.gpus):
+        raise SystemExit("expected an RCCL ('nccl') group of %d ranks, got backend %s with %d" % (args.gpus, torch.distributed.get_backend(), torch.distributed.get_world_size()))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32

@@ -39,3 +39,24 @@ def test_two_rank_dry_run_of_the_bench_contract():
     assert launches == sorted(launches)                            # buckets leave in reverse registration order, while backward is still running
     assert abs(sum(row["MB"] for row in comm["bucket_table_last_step"]) - comm["allreduce_payload_bytes"] / 1e6) < 0.1
     assert comm["averaged_gradient_max_err"] < 1e-5 and comm["replicas_identical"] is True
+
+
+def test_bench_launches_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with NO torch.distributed.run in front (and no WORLD_SIZE) must still run two ranks, never
+    print n_gpus != --gpus with rc 0 (the reference runs one replica per listed GPU: train.py:272-277, 404)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "4"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["comm"]["backend"] == "gloo"
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
