@@ -16,6 +16,7 @@ from . import dp  # noqa: F401
 from . import graph  # noqa: F401
 from . import postprocess  # noqa: F401
 from . import augment  # noqa: F401
+from . import nifti  # noqa: F401
 from . import acdc  # noqa: F401
 from . import dice  # noqa: F401
 

@@ -12,8 +12,11 @@ The re-scaling is the one step the reference delegates to a third-party library 
 import numpy as np
 import torch
 
+import os
+
 from . import augment as A
 from . import data as sdata
+from . import nifti
 
 
 # ------------------------------------------------------------------------------------------------ fold split
@@ -44,18 +47,48 @@ def volume_name(patient, frame):
     return "patient%03d/patient%03d_frame%02d" % (patient, patient, frame)
 
 
+# ------------------------------------------------------------------------------------------------ NIfTI files
+def load_training_volume(img_root, seg_root, patient, frame):
+    """ac17_dataloader.py:107-114: `<root>/patientNNN/patientNNN_frameFF.nii.gz` and its `_gt` label volume -> (img [H, W, Z], seg [H, W, Z],
+    pixdim[1]).  (The reference joins the patient directory with a BACKSLASH, a Windows path; both spellings resolve to the same file there.)"""
+    name = volume_name(patient, frame)
+    img, pix = nifti.load_volume(os.path.join(img_root, name + ".nii.gz"))
+    seg, _ = nifti.load_volume(os.path.join(seg_root, name + "_gt.nii.gz"))
+    if seg.shape != img.shape:
+        raise ValueError("%s: label volume %s does not match the image %s" % (name, seg.shape, img.shape))
+    return np.array(img), np.array(seg), pix
+
+
+def load_test_volume(img_root, patient, frame):
+    """data/test_loader.py:46-51 -> (img [H, W, Z], pixdim[1])"""
+    img, pix = nifti.load_volume(os.path.join(img_root, volume_name(patient, frame) + ".nii.gz"))
+    return np.array(img), pix
+
+
+def load_fold(img_root, seg_root, series, split="train", k=5, k_split=1):
+    """The `volumes` mapping build_cache expects, read from disk for one fold: (patient, frame) -> (img, seg, pix_dim)."""
+    return {key: load_training_volume(img_root, seg_root, *key) for key in fold_split(series, split, k, k_split)}
+
+
 # ------------------------------------------------------------------------------------------------ in-plane re-scaling
-def _resize_axis_linear(a, n_out, axis):
+def _resize_axis_linear(a, n_out, axis, edge_mode="blend"):
     """order-1 resize along one axis, skimage / scipy convention: output pixel centre o maps to source coordinate (o + 0.5) * n_in / n_out - 0.5;
-    mode='constant': samples outside the array are 0"""
+    mode='constant': samples outside the array are 0.  edge_mode 'blend' interpolates between the edge sample and that zero for coordinates
+    in (-1, 0) and (n-1, n) (scipy's 'grid-constant', skimage's own 2-D warp); 'cval' returns 0 for every coordinate outside [0, n-1]
+    (`ndi.map_coordinates(mode='constant')`, the n-D path of skimage 0.15-0.18)."""
     n_in = a.shape[axis]
     src = (np.arange(n_out) + 0.5) * (n_in / float(n_out)) - 0.5
     i0 = np.floor(src).astype(np.int64); f = src - i0
+    outside = (src < 0) | (src > n_in - 1)
     a = np.moveaxis(a, axis, 0)
     pad = np.concatenate([np.zeros((1,) + a.shape[1:], a.dtype), a, np.zeros((1,) + a.shape[1:], a.dtype)], 0)     # index -1 and n_in read 0
     lo = pad[np.clip(i0 + 1, 0, n_in + 1)]; hi = pad[np.clip(i0 + 2, 0, n_in + 1)]
     shape = (-1,) + (1,) * (a.ndim - 1)
     out = lo * (1.0 - f).reshape(shape) + hi * f.reshape(shape)
+    if edge_mode == "cval":
+        out = np.where(outside.reshape(shape), 0.0, out)
+    elif edge_mode != "blend":
+        raise ValueError("edge_mode is 'blend' or 'cval'")
     return np.moveaxis(out, 0, axis)
 
 
@@ -70,18 +103,27 @@ def _gauss1d_zero(a, sigma, axis):
     return np.moveaxis(out, 0, axis)
 
 
-def rescale_volume(vol, pix_dim, target_mm=1.25, order=1, anti_aliasing=None):
+def rescale_volume(vol, pix_dim, target_mm=1.25, order=1, anti_aliasing=None, anti_aliasing_labels=False, edge_mode="blend"):
     """`transform.rescale(vol, [r, r, 1], order, preserve_range=True, multichannel=False, mode='constant')` with r = pix_dim / target_mm
     (ac17_dataloader.py:112-131, test_loader.py:55-64): output in-plane shape round(n * r); order 1 = separable linear interpolation at the
     pixel-centre-aligned coordinates, zeros outside the volume; order 0 = nearest (the source index under the output pixel's centre); the slice
     axis is untouched.  anti_aliasing=None follows skimage 0.15-0.18 (the versions that still accept `multichannel=`): a Gaussian pre-filter
     with sigma = (1/r - 1) / 2 when an order-1 image is SHRUNK (r < 1), none otherwise and never for labels.  UNPINNED: skimage is not
-    installed here and the reference pins no version; tests/test_acdc.py holds known-answer vectors of this restatement."""
+    installed here and the reference pins no version; tests/test_acdc.py holds known-answer vectors of this restatement.
+    Two DELIBERATE deviations from what skimage 0.15-0.18 literally executes, each with a switch that reproduces the library:
+    (1) those versions Gaussian-filter EVERY input that is shrunk, the order-0 label volume included (labels 0..3 blurred, then sampled at the
+    nearest voxel and truncated to uint8 -- class boundaries erode towards the smaller label); here labels are sampled unfiltered unless
+    `anti_aliasing_labels=True`; (2) their n-D path samples with `ndi.map_coordinates(mode='constant')`, which returns 0 for coordinates
+    outside [0, n-1] instead of blending the edge sample towards 0: `edge_mode='cval'` reproduces that, the default 'blend' keeps the
+    one-pixel border of an up-sampled volume (spacing > target) from going dark."""
     vol = np.asarray(vol)
     r = float(pix_dim) / float(target_mm)
     h, w = vol.shape[0], vol.shape[1]
     ho, wo = int(np.round(h * r)), int(np.round(w * r))
     if order == 0:
+        if anti_aliasing_labels and (ho < h or wo < w):
+            f = _gauss1d_zero(vol.astype(np.float64), max(0.0, (h / float(ho) - 1.0) / 2.0), 0)
+            vol = _gauss1d_zero(f, max(0.0, (w / float(wo) - 1.0) / 2.0), 1)
         iy = np.minimum(np.floor((np.arange(ho) + 0.5) * h / ho).astype(np.int64), h - 1)
         ix = np.minimum(np.floor((np.arange(wo) + 0.5) * w / wo).astype(np.int64), w - 1)
         return vol[iy][:, ix].astype(np.float64)
@@ -91,8 +133,8 @@ def rescale_volume(vol, pix_dim, target_mm=1.25, order=1, anti_aliasing=None):
     if anti_aliasing:
         out = _gauss1d_zero(out, max(0.0, (h / float(ho) - 1.0) / 2.0), 0)
         out = _gauss1d_zero(out, max(0.0, (w / float(wo) - 1.0) / 2.0), 1)
-    out = _resize_axis_linear(out, ho, 0)
-    return _resize_axis_linear(out, wo, 1)
+    out = _resize_axis_linear(out, ho, 0, edge_mode)
+    return _resize_axis_linear(out, wo, 1, edge_mode)
 
 
 # ------------------------------------------------------------------------------------------------ per-volume preparation (load time)
@@ -160,12 +202,34 @@ class SliceCache(torch.utils.data.Dataset):
 
     def __init__(self, volumes, split="train", deform=True, seed=None):
         self.split, self.deform = split, deform
-        self.rng = np.random.default_rng(seed)
+        self.seed = seed
+        self._rng, self._rng_key = None, ()
         self.data = []
         for name, img, seg in volumes:
             for x in range(img.shape[-1]):
                 self.data.append({"image": torch.from_numpy(np.ascontiguousarray(img[:, :, x])).float(),
                                   "mask": torch.from_numpy(np.ascontiguousarray(seg[:, :, x])).long(), "name": "%s_z%d" % (name, x)})
+
+    @property
+    def rng(self):
+        """The generator of the CURRENT process.  The reference draws from the `random` / `np.random` globals, which torch re-seeds per DataLoader
+        worker and per epoch; a generator stored in the Dataset would be copied into every worker with the same state (and re-copied, never
+        advanced, each epoch), so all workers would replay one sequence of deform decisions and displacement fields.  Inside a
+        worker the generator is therefore derived from `get_worker_info().seed` (= base seed of this epoch's iterator + worker id), in the
+        parent process from `seed`; it is rebuilt whenever the worker identity changes."""
+        info = torch.utils.data.get_worker_info()
+        key = None if info is None else (info.id, info.seed)
+        if self._rng is None or key != self._rng_key:
+            if info is None:
+                self._rng = np.random.default_rng(self.seed)
+            else:
+                self._rng = np.random.default_rng([0 if self.seed is None else int(self.seed), int(info.seed) & 0xffffffffffffffff])
+            self._rng_key = key
+        return self._rng
+
+    def __getstate__(self):
+        d = dict(self.__dict__); d["_rng"], d["_rng_key"] = None, ()      # never ship generator state to a worker
+        return d
 
     def __len__(self):
         return len(self.data)

@@ -150,3 +150,57 @@ def test_rotation_matches_hand_computed_affine_vectors():
     hand = (big[y0, x0] * (1 - dx) + big[y0, x0 + 1] * dx) * (1 - dy) + (big[y0 + 1, x0] * (1 - dx) + big[y0 + 1, x0 + 1] * dx) * dy
     o, s = augment.rotate(big, (big > 50).astype(np.int64), 30.0)
     assert abs(o[2, 5] - hand) < 1e-9 and s[2, 5] == int(big[int(np.floor(yin)), int(np.floor(xin))] > 50)
+
+
+def _first_fields(cache, workers, n=8):
+    """images of the first n accesses of each epoch, keyed by (epoch, index)"""
+    out = []
+    dl = torch.utils.data.DataLoader(cache, batch_size=1, shuffle=False, num_workers=workers)
+    for epoch in range(2):
+        imgs = []
+        for i, b in enumerate(dl):
+            imgs.append(b["image"][0, 0].clone())
+            if i + 1 == n:
+                break
+        out.append(imgs)
+    return out
+
+
+def test_slice_cache_draws_differ_per_worker_and_per_epoch():
+    """a generator stored in the Dataset is copied into every DataLoader worker with one state and re-copied unchanged each
+    epoch, so every worker of every epoch would replay the same deform decisions and displacement fields.  The reference draws from the
+    random / np.random globals, re-seeded by torch per worker and per epoch (ac17_dataloader.py:196-216).  Here: with two workers, (a) the
+    deformed slices the two workers produce for the SAME cached slice differ, (b) the second epoch differs from the first."""
+    torch.manual_seed(7)
+    img = np.random.default_rng(0).standard_normal((64, 64, 1))
+    seg = (np.random.default_rng(1).random((64, 64, 1)) * 4).astype(np.int64).astype(np.float64)
+    same_slice = [("v", np.repeat(img, 16, 2), np.repeat(seg, 16, 2))]                 # 16 copies of one slice: worker 0 serves even, worker 1 odd indices
+    cache = acdc.SliceCache(same_slice, split="train", deform=True, seed=11)
+    base = torch.from_numpy(img[:, :, 0]).float()
+    e0, e1 = _first_fields(cache, workers=2, n=16)
+    w0 = [x for x in e0[0::2] if not torch.equal(x, base)]
+    w1 = [x for x in e0[1::2] if not torch.equal(x, base)]
+    assert len(w0) >= 1 and len(w1) >= 1                                                  # p = 0.5 over 8 draws each
+    assert not any(torch.equal(a, b) for a in w0 for b in w1)                            # (a) workers do not share a displacement field
+    assert [torch.equal(x, base) for x in e0] != [torch.equal(x, base) for x in e1] or not any(
+        torch.equal(a, b) for a in e0 for b in e1 if not torch.equal(a, base))           # (b) epochs are not replays
+    d1 = [x for x in e1 if not torch.equal(x, base)]
+    assert not any(torch.equal(a, b) for a in w0 + w1 for b in d1)
+    # single-process loading keeps advancing ONE generator and stays reproducible from the seed
+    a = acdc.SliceCache(same_slice, split="train", deform=True, seed=11); b = acdc.SliceCache(same_slice, split="train", deform=True, seed=11)
+    assert all(torch.equal(a[i]["image"], b[i]["image"]) for i in range(6))
+
+
+def test_rescale_switches_reproduce_the_library_literal_behaviour():
+    """the two deliberate deviations of rescale_volume from skimage 0.15-0.18 and the switches that undo them."""
+    seg = np.zeros((40, 40, 1)); seg[10:30, 10:30] = 3.0
+    plain = acdc.rescale_volume(seg, 1.0, 1.25, order=0)
+    blur = acdc.rescale_volume(seg, 1.0, 1.25, order=0, anti_aliasing_labels=True)
+    assert plain.shape == blur.shape == (32, 32, 1) and set(np.unique(plain)) == {0.0, 3.0}
+    assert np.all(blur <= plain + 1e-12) and blur.max() > 2.9 and np.any((blur > 0) & (blur < 3))     # filtered labels erode at the boundary
+    assert np.array_equal(acdc.rescale_volume(seg, 1.5, 1.25, order=0, anti_aliasing_labels=True), acdc.rescale_volume(seg, 1.5, 1.25, order=0))  # never when enlarging
+    img = np.ones((10, 10, 1))
+    up_b = acdc.rescale_volume(img, 1.5, 1.25)                                  # 12 x 12: the outermost samples lie at -0.083 / 9.083
+    up_c = acdc.rescale_volume(img, 1.5, 1.25, edge_mode="cval")
+    assert abs(up_b[0, 5, 0] - (1 - 1 / 12.0)) < 1e-12 and up_c[0, 5, 0] == 0.0 and up_c[5, 0, 0] == 0.0
+    assert np.array_equal(up_b[1:-1, 1:-1], up_c[1:-1, 1:-1]) and np.all(up_c[1:-1, 1:-1] == 1.0)
