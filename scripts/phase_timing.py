@@ -24,6 +24,12 @@ elif case in ("dec4convtwgrad", "dec2convtwgrad"):
     ci, h = {"dec4convtwgrad": (512, 16), "dec2convtwgrad": (128, 64)}[case]
     x = act(ci, h); dy = act(ci, 2 * h); w = torch.nn.Parameter(torch.randn(ci, ci, 4, 4, device="cuda") * 0.03)
     run = lambda: (HF.GRADS.reset(), HF.conv_wgrad_raw(x, dy, w, 2, 1, transposed=True))
+elif case in ("dec3mm", "dec5mm", "dec4mm", "dec2mm"):
+    unit = "conv_mm"
+    cin, h, cout = {"dec3mm": (512, 64, 128), "dec5mm": (1536, 16, 512), "dec4mm": (1024, 32, 256), "dec2mm": (256, 128, 64)}[case]
+    x = act(cin, h); w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device="cuda") * 0.02)
+    out = HF.new_act(n, cout, h, h, dt, "cuda"); st = torch.zeros(HF.STAT_R, 2, cout, dtype=torch.float64, device="cuda")
+    run = lambda: HF.conv_forward_raw(x, w, None, 1, 1, out=out, stats=st)
 elif case in ("dec3fwd", "dec5fwd"):
     cin, h, cout = {"dec3fwd": (512, 64, 128), "dec5fwd": (1536, 16, 512)}[case]
     x = act(cin, h); w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device="cuda") * 0.02)

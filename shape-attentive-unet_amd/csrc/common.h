@@ -199,7 +199,10 @@ template <int NT> __device__ __forceinline__ void bn_prologue_fill(const saunet_
 #ifdef SAUNET_TIMING
 static __device__ unsigned long long g_timing[2048];
 #define TSTAMP_INIT() int tcount__ = 0
-#define TSTAMP(slot) do { if (blockIdx.x == SAUNET_TIMING_BLOCK && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && tcount__ < 2000) \
+#ifndef SAUNET_TIMING_TID
+#define SAUNET_TIMING_TID 0
+#endif
+#define TSTAMP(slot) do { if (blockIdx.x == SAUNET_TIMING_BLOCK && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == SAUNET_TIMING_TID && tcount__ < 2000) \
         g_timing[tcount__++] = ((unsigned long long)(slot) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); } while (0)
 #define SAUNET_TIMING_READER(unit) extern "C" int saunet_debug_timing_##unit(unsigned long long* out, int n) \
     { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(saunet::g_timing), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost); }

@@ -22,6 +22,8 @@ int igemm_forward(const saunet_conv_desc* d, const void* x, const void* w, const
                   void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st, const saunet_bn_prologue* bnp = nullptr);
 int igemm_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw, hipStream_t st);
 bool tile_fwd_supported(const saunet_conv_desc* d);
+bool mm_fwd_supported(const saunet_conv_desc* d, const void* x, const void* w, const void* y, const float* ps, const saunet_bn_epilogue* epi);
+int mm_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* ssum, double* ssq, hipStream_t st);
 bool tile_wgrad_supported(const saunet_conv_desc* d);
 bool tile_wgrad_unaligned_supported(const saunet_conv_desc* d);
 // MFMA tile wgrad with scalar staging for odd channel counts: correct, but measured SLOWER than pointwise_wgrad_kernel
@@ -552,6 +554,7 @@ int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const voi
     static const bool use_dense_dgrad = !(getenv("SAUNET_DENSE_DGRAD") && getenv("SAUNET_DENSE_DGRAD")[0] == '0');   // A/B switch for profiling
     if (use_dense_dgrad && ssum == nullptr && dense_dgrad_supported(d, bias, ps, epi)) return dense_dgrad_forward(d, x, w, y, epi, st);
     if (use_dense_dgrad && ssum == nullptr && dense_dgrad3_supported(d, bias, ps, epi)) return dense_dgrad3_forward(d, x, w, y, epi, st);
+    if (mm_fwd_supported(d, x, w, y, ps, epi)) return mm_forward(d, x, w, bias, y, ssum, ssq, st);
     if (igemm_supported(d)) {
         if (epi && (((uintptr_t)epi->bn_x & 15) || epi->ld_bn_x % (d->dtype == SAUNET_BF16 ? 8 : 4)))
             return set_error(SAUNET_BAD_ALIGN, "conv: bn epilogue tensor must be 16-byte aligned");

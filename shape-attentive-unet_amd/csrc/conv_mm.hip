@@ -1,0 +1,320 @@
+// 3x3 (stride 1, pad 1) convolution for the MFMA-bound layers of the decoder -- `c3x3rb` of the four DualAttBlocks
+// (/root/reference/models/attention_blocks.py:215-220: Cin 1536 / 1024 / 512 / 256), their data gradients (the same convolution over dy with
+// flipped weights, Cin <-> Cout) and every other 3x3 whose input needs no BatchNorm prologue and has Cin % 64 == 0.
+//
+// Structure (one workgroup per CU: 8 waves, two per SIMD; ~150 KB of LDS):
+//   * output tile 16x16 pixels x BN output channels, wave tile 64 pixels x (BN/2) channels (4 x 2 waves), mfma_f32_32x32x16_bf16;
+//   * the K loop runs over stages  (channel block of 64) x (tap):  16 MFMAs per wave and stage (8 with BN = 64);
+//   * ALL operands reach the LDS by LDS-DMA (global_load_lds_dwordx4): the input tile with its one-pixel halo (18 x 18 pixels x 128 B, two
+//     buffers: the next channel block is staged while the nine taps of the current one run) and one [BN][64] weight tile per stage in a ring
+//     of four.  Nothing passes through registers, no address or pack VALU work in the loop; zero padding = lanes that source a zero page;
+//   * the DMA destination is lane-linear, so the 16-byte XOR swizzle that keeps the ds_read_b128 fragment reads conflict-free is applied to
+//     the per-lane SOURCE address (and again on the read): image row r holds source chunk (slot ^ key);
+//   * one s_barrier per stage; loads are waited for with COUNTED vmcnt (a stage's weights were requested three stages earlier, the halo of
+//     the next channel block up to nine), and a stage's weights are certified one stage EARLY, so the first fragments of stage s+1 are read
+//     before the barrier that ends stage s: the ds_read -> MFMA software pipeline (two named fragment sets) runs straight through barriers.
+//
+// bf16 storage only; float32 storage keeps conv3x3_tile_fwd_kernel (exact f32 MFMA).
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace saunet {
+
+struct MmArgs {
+    const u16* x; const u16* w; u16* y; const float* bias;
+    double* stat_sum; double* stat_sumsq; int stat_replicas, stat_rstride;
+    int N, H, W, Cin, ldx, Cout, ldy, act_relu;
+    int tiles_x, tiles_y, ntiles, nnt;
+};
+
+static __device__ u32x4 g_mm_zeros[256];    // 4 KB of zeros: the source of every padding lane (a padding lane walks through it with the channel block: Cin <= 2048)
+
+constexpr int MM_HP = 18, MM_NPIX = MM_HP * MM_HP;          // halo pitch / pixels
+constexpr int MM_HALO_INSTR = (MM_NPIX + 7) / 8;            // 41 DMA instructions of 1 KB (8 pixels x 128 B)
+constexpr int MM_HALO_BYTES = MM_HALO_INSTR * 1024;         // 41 984
+constexpr int MM_HALO_PER_WAVE = 6;                         // 8 waves x 6 slots >= 41 (surplus slots go to the dummy region)
+constexpr int MM_RING = 4;
+
+__device__ __forceinline__ void mm_dma16(const void* gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void mm_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
+__device__ __forceinline__ void mm_barrier()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Where a stage's DMA requests are issued matters (round-4 phase stamps, profiles/r04_mm_kernel_notes.txt): one request blocks ITS wave for
+// ~110 cycles (the CU's memory front end accepts one about every 30 cycles from all waves together), so with all eight waves requesting right
+// behind the barrier every matrix pipe idled 330-700 cycles per stage.  Each wave now issues one request behind each of the first three
+// k-steps: the partner wave of the SIMD keeps the pipe busy meanwhile (MFMA-busy 60 -> 63 % at dec3).  Measured and rejected: two dedicated
+// loader waves (640-thread workgroups; a single wave sustains only one request per ~118 cycles, 12 per stage = 1400 cycles: slower, 55 %),
+// anti-phase halves (waves 0-3 behind the barrier, 4-7 at the end of the stage: 56 %), requests pinned a full k-step ahead and s_setprio
+// around the MFMA groups (both -2 %).
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
+{
+    TSTAMP_INIT();
+    TSTAMP(20);
+    constexpr int TJ = BN / 64;                       // 32-channel MFMA tiles per wave in N
+    constexpr int WSLOT = BN * 128;                   // one stage's weight tile: [BN][64] bf16
+    constexpr int WINSTR = BN / 64;                   // weight DMA instructions per wave and stage
+    constexpr int OFF_W = 2 * MM_HALO_BYTES;
+    constexpr int OFF_DUMMY = OFF_W + MM_RING * WSLOT;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves
+    // ---- workgroup -> (pixel tile, n tile): the n tiles of one pixel tile share its halo, so they run on the SAME XCD (block b -> XCD b % 8)
+    int t, nt;
+    {
+        const int b = blockIdx.x;
+        if ((a.ntiles & 7) == 0) { const int k = b >> 3; t = (k / a.nnt) * 8 + (b & 7); nt = k % a.nnt; }
+        else { t = b / a.nnt; nt = b % a.nnt; }
+    }
+    const int txi = t % a.tiles_x; const int r1 = t / a.tiles_x;
+    const int tyi = r1 % a.tiles_y; const int n = r1 / a.tiles_y;
+    const int ty0 = tyi * 16, tx0 = txi * 16, n0 = nt * BN;
+    const u16* __restrict__ xg = a.x + (size_t)n * a.H * a.W * a.ldx;
+    const int ncb = a.Cin >> 6;
+    const int nstage = ncb * 9;
+    const unsigned char* zsrc = (const unsigned char*)g_mm_zeros;
+
+    // ---- DMA source offsets of this lane (bytes; channel block / tap terms are added per issue)
+    // halo slot j of this wave = DMA instruction hidx = j * 8 + wave: LDS pixels 8 * hidx .. + 7, lane = (pixel, 16-byte slot)
+    // a padding lane's pointer stays inside the zero page
+    const unsigned char* hsrc[MM_HALO_PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < MM_HALO_PER_WAVE; ++j) {
+        const int hidx = j * 8 + wave;
+        const int hp = hidx * 8 + (lane >> 3), sl = lane & 7;
+        const int hy = hp / MM_HP, hx = hp - hy * MM_HP;
+        const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+        const bool ok = hidx < MM_HALO_INSTR && hp < MM_NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const int ch = sl ^ ((hx >> 1) & 7);
+        hsrc[j] = ok ? (const unsigned char*)xg + ((long)(iy * a.W + ix) * a.ldx + ch * 8) * 2 : zsrc + (lane & 7) * 16;
+    }
+    unsigned woff[WINSTR];
+#pragma unroll
+    for (int j = 0; j < WINSTR; ++j) {
+        const int q = j * 8 + wave;
+        const int r = q * 8 + (lane >> 3), sl = lane & 7;
+        int row = n0 + r; if (row >= a.Cout) row = a.Cout - 1;
+        woff[j] = (unsigned)(((size_t)row * 9 * a.Cin + (sl ^ ((r >> 1) & 7)) * 8) * 2);
+    }
+    // requests past the end of the K loop keep the per-wave request count uniform (the counted waits rely on it): they re-load the last
+    // channel block / stage into a buffer nobody reads any more
+    auto issue_halo = [&](int j, int cb) {           // slot j of channel block cb
+        const int hidx = j * 8 + wave;
+        const int cbc = cb < ncb ? cb : ncb - 1;
+        const unsigned dst = hidx < MM_HALO_INSTR ? lds0 + (cb & 1) * MM_HALO_BYTES + hidx * 1024 : lds0 + OFF_DUMMY;
+        mm_dma16(hsrc[j] + (long)cbc * 128, dst);
+    };
+    auto issue_w1 = [&](int s, int j) {              // rows j of the weight tile of stage s into ring slot s % 4
+        const int sc = s < nstage ? s : nstage - 1;
+        const int cb = sc / 9, tap = sc - cb * 9;
+        const unsigned sbase = lds0 + OFF_W + (s & (MM_RING - 1)) * WSLOT;
+        const unsigned char* wsrc = (const unsigned char*)a.w + ((size_t)tap * a.Cin + (size_t)cb * 64) * 2;
+        mm_dma16(wsrc + woff[j], sbase + (j * 8 + wave) * 1024);
+    };
+    auto issue_w = [&](int s) {
+#pragma unroll
+        for (int j = 0; j < WINSTR; ++j) issue_w1(s, j);
+    };
+
+    // ---- fragment addresses (bytes inside smem).  A: halo pixel (py + kh, px + kw), 16-byte slot (2 ks + lh) ^ key(px + kw)
+    const int py0 = wm * 4 + (lr >> 4), px = lr & 15;
+    int ak[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int key = ((px + kw) >> 1) & 7;
+        ak[kw] = (py0 * MM_HP + px + kw) * 128 + (((lh ^ key) & 1) << 4) + ((key & 6) << 4);
+    }
+    const int brow = wn * (BN / 2) + lr;
+    const int bkey = (brow >> 1) & 7;
+    const int bk = OFF_W + brow * 128 + (((lh ^ bkey) & 1) << 4) + ((bkey & 6) << 4);
+
+    f32x16 acc[2][TJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: halo of channel block 0, weights of stages 0, 1, 2
+#pragma unroll
+    for (int j = 0; j < MM_HALO_PER_WAVE; ++j) issue_halo(j, 0);
+    issue_w(0); issue_w(1); issue_w(2);
+    TSTAMP(21);
+    mm_wait_vm<2 * WINSTR>();                         // halo 0 + weights 0 landed (this wave's pieces); stages 1, 2 may be in flight
+    mm_barrier();
+    TSTAMP(22);
+
+    u32x4 fa0[2], fb0[TJ], fa1[2], fb1[TJ];
+    auto load_frags = [&](u32x4* fa, u32x4* fb, int hb_off, int ws_off, int tap, int ks) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int aaddr = (ak[kw] ^ (ks << 5)) + hb_off + kh * (MM_HP * 128);
+        const int baddr = (bk ^ (ks << 5)) + ws_off;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)(smem + aaddr + i * (2 * MM_HP * 128));
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) fb[j] = *(const u32x4*)(smem + baddr + j * (32 * 128));
+        // pin the request in front of the MFMAs that follow in program order: left alone, hipcc sinks the reads behind the previous k-step's
+        // MFMAs and waits for them right away (no fragment is then in flight while the matrix pipe works)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma = [&](const u32x4* fa, const u32x4* fb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[i]), __builtin_bit_cast(bf16x8_t, fb[j]), acc[i][j], 0, 0, 0);
+    };
+    load_frags(fa0, fb0, 0, 0, 0, 0);
+
+    int s = 0;
+    for (int cb = 0; cb < ncb; ++cb) {
+        const int hb_off = (cb & 1) * MM_HALO_BYTES, hb_next = ((cb + 1) & 1) * MM_HALO_BYTES;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++s) {
+            // ---- stage boundary.  Outstanding (per wave, oldest first): [halo piece of stage s-2] weights(s+1) [halo piece of s-1] weights(s+2);
+            // certify weights(s+1) (and with them every older halo piece): allow what stage s-1 issued to stay in flight
+            TSTAMP(23);
+            if (tap >= 1 && tap <= 6) mm_wait_vm<1 + WINSTR>(); else mm_wait_vm<WINSTR>();
+            TSTAMP(29);
+            mm_barrier();
+            TSTAMP(24);
+            // the stage's requests of this wave as pieces 0 .. 2: [halo piece (taps 0-5)] [weight rows] [weight rows (BN = 128)]
+            auto piece = [&](int k) {
+                if (k == 0) { if (tap < MM_HALO_PER_WAVE) issue_halo(tap, cb + 1); }
+                else if (k - 1 < WINSTR) issue_w1(s + 3, k - 1);
+            };
+            TSTAMP(25);
+            const int ws_off = (s & (MM_RING - 1)) * WSLOT, ws_next = ((s + 1) & (MM_RING - 1)) * WSLOT;
+            // 4 k-steps of 16 channels; fragments of the next k-step (or of the next stage's first) are requested before this one's MFMAs;
+            // one DMA request behind each of the first three k-steps
+            load_frags(fa1, fb1, hb_off, ws_off, tap, 1);
+            mma(fa0, fb0);
+            piece(0);
+            load_frags(fa0, fb0, hb_off, ws_off, tap, 2);
+            mma(fa1, fb1);
+            piece(1);
+            load_frags(fa1, fb1, hb_off, ws_off, tap, 3);
+            mma(fa0, fb0);
+            piece(2);
+            if (tap < 8) load_frags(fa0, fb0, hb_off, ws_next, tap + 1, 0);
+            else load_frags(fa0, fb0, hb_next, ws_next, 0, 0);
+            mma(fa1, fb1);
+        }
+    }
+    TSTAMP(26);
+    mm_wait_vm<0>();
+    __syncthreads();
+    TSTAMP(27);
+
+    // ---- epilogue: bias / ReLU, tile through LDS to 16-byte row stores, per-channel sums of the un-biased accumulator (BatchNorm statistics)
+    u16* so = (u16*)smem;                                          // [256][BN]
+    float* s_sum = (float*)(smem + 256 * BN * 2);                  // [4 row waves][2][BN]
+    const bool do_stats = a.stat_sum != nullptr;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int col = wn * (BN / 2) + j * 32 + lr;
+        const float bv = (a.bias != nullptr && n0 + col < a.Cout) ? a.bias[n0 + col] : 0.f;
+        float sv = 0.f, ssv = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][j][r];
+                sv += v; ssv += v * v;
+                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                Elem<u16>::store(so + row * BN + col, a.act_relu ? fmaxf(v + bv, 0.f) : v + bv);
+            }
+        if (do_stats) {
+            sv += __shfl_xor(sv, 32, 64); ssv += __shfl_xor(ssv, 32, 64);
+            if (lh == 0) { float* slot = s_sum + wm * 2 * BN; slot[col] = sv; slot[BN + col] = ssv; }
+        }
+    }
+    __syncthreads();
+    if (do_stats && tid < BN && n0 + tid < a.Cout) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { t1 += s_sum[w * 2 * BN + tid]; t2 += s_sum[w * 2 * BN + BN + tid]; }
+        const size_t ro = (size_t)(blockIdx.x % a.stat_replicas) * a.stat_rstride;
+        atomicAdd(&a.stat_sum[ro + n0 + tid], (double)t1);
+        atomicAdd(&a.stat_sumsq[ro + n0 + tid], (double)t2);
+    }
+    constexpr int CH = BN / 8;                                     // 16-byte chunks per row
+    u16* __restrict__ yg = a.y + (size_t)n * a.H * a.W * a.ldy;
+    constexpr int S_ITERS = 256 * CH / 512;
+    const int colv = n0 + (tid % CH) * 8;
+    if (colv < a.Cout) {
+#pragma unroll
+        for (int i = 0; i < S_ITERS; ++i) {
+            const int p = tid + i * 512;
+            const int row = p / CH, ch = p - row * CH;
+            const size_t opix = (size_t)(ty0 + (row >> 4)) * a.W + tx0 + (row & 15);
+            *(u32x4*)(yg + opix * a.ldy + colv) = *(const u32x4*)(so + row * BN + ch * 8);
+        }
+    }
+    TSTAMP(28);
+}
+
+
+template <int BN> static int launch_mm(const MmArgs& a, hipStream_t st)
+{
+    constexpr int LDS = 2 * MM_HALO_BYTES + MM_RING * BN * 128 + 1024;
+    auto kern = conv3x3_mm_kernel<BN>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    hipLaunchKernelGGL(kern, dim3(a.ntiles * a.nnt), dim3(512), LDS, st, a);
+    SAUNET_CHECK_LAUNCH("conv3x3_mm");
+    return SAUNET_OK;
+}
+
+// which of the two output-channel tiles: 128 unless that leaves CUs idle (fewer than 256 workgroups) and 64 does better
+static int mm_pick_bn(const saunet_conv_desc* d)
+{
+    static const int force = getenv("SAUNET_MM_BN") ? atoi(getenv("SAUNET_MM_BN")) : 0;      // A/B switch
+    if (force == 64 || force == 128) return force;
+    if (d->Cout <= 64) return 64;
+    const long tiles = (long)d->N * (d->H / 16) * (d->W / 16);
+    const long b128 = tiles * ((d->Cout + 127) / 128);
+    return b128 < 256 ? 64 : 128;
+}
+
+bool mm_fwd_supported(const saunet_conv_desc* d, const void* x, const void* w, const void* y, const float* ps, const saunet_bn_epilogue* epi)
+{
+    static const bool on = !(getenv("SAUNET_CONV_MM") && getenv("SAUNET_CONV_MM")[0] == '0');             // A/B switch
+    static const int min_cin = getenv("SAUNET_MM_MINCIN") ? atoi(getenv("SAUNET_MM_MINCIN")) : 128;
+    return on && d->dtype == SAUNET_BF16 && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->H % 16 == 0 &&
+           d->W % 16 == 0 && d->Ho == d->H && d->Wo == d->W && ps == nullptr && (epi == nullptr || epi->bn_x == nullptr) && d->Cin % 64 == 0 &&
+           d->Cin >= min_cin && d->Cin <= 2048 && d->Cout % 8 == 0 && d->Cout >= 64 && d->ldx % 8 == 0 && d->ldy % 8 == 0 &&
+           !(((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) && (long)d->N * d->H * d->W * d->ldx < (1L << 30);
+}
+
+int mm_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* ssum, double* ssq, hipStream_t st)
+{
+    MmArgs a;
+    a.x = (const u16*)x; a.w = (const u16*)w; a.y = (u16*)y; a.bias = bias; a.stat_sum = ssum; a.stat_sumsq = ssq;
+    a.stat_replicas = d->stat_replicas > 1 ? d->stat_replicas : 1; a.stat_rstride = d->stat_rstride;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Cout = d->Cout; a.ldy = d->ldy; a.act_relu = d->epi_relu;
+    a.tiles_y = d->H / 16; a.tiles_x = d->W / 16; a.ntiles = a.tiles_x * a.tiles_y * a.N;
+    const int bn = mm_pick_bn(d);
+    a.nnt = (d->Cout + bn - 1) / bn;
+    return bn == 64 ? launch_mm<64>(a, st) : launch_mm<128>(a, st);
+}
+
+}  // namespace saunet
+
+SAUNET_TIMING_READER(conv_mm)
