@@ -57,6 +57,51 @@ template <> struct Elem<u16> {  // bf16 stored as raw 16-bit words
     __device__ static __forceinline__ void store(u16* p, float v) { *p = __builtin_bit_cast(u16, (__bf16)v); }
 };
 
+// ---- float32 operands on the bf16 matrix cores -------------------------------------------------------------------------------------
+// gfx950 has no reduced-precision fast path for f32 inputs: mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate, 1/16 of the bf16 MFMA.
+// A float is the sum of three bf16 pieces to 2^-27 (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): 9 signed bits each), and the products
+// of bf16 pieces are exact in the float32 accumulator.  With the six products
+// hh, hm, mh, mm, hl, lh (what is dropped is below 2^-24 of |a||b|: float32 round-off class) one K = 8 step of the float path -- a lane
+// holds 4 floats of each operand -- is THREE mfma_f32_32x32x16_bf16 instead of four mfma_f32_32x32x2_f32: the 16 K slots of a bf16 MFMA
+// carry two product kinds at once (slots 0-3 / 4-7 of each lane half).  96 instead of 256 matrix-pipe cycles; the splits are VALU work
+// that runs beside the MFMAs and is shared by all tiles a fragment feeds.  SAUNET_F32_SPLIT=0 (compile time) restores the exact-f32 MFMA.
+#ifndef SAUNET_F32_SPLIT
+#define SAUNET_F32_SPLIT 1
+#endif
+struct F32Split { unsigned h01, h23, m01, m23, l01, l23; };
+// round-to-nearest splits (v_cvt_pk_bf16_f32): x = h + m + l + e with |e| <= 2^-27 |x| and NO bias -- truncation splits (and / perm) cost the
+// same number of VALU operations but drop a same-signed remainder from every product, which a K = 10^4 reduction turns into a relative error
+// of 1e-5 (measured: smoke()'s gradient error against the oracle doubled to 6e-4 of the gradient scale)
+__device__ __forceinline__ F32Split f32_split3(const u32x4& v)
+{
+    F32Split s;
+    float x[4], r[4], q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = __uint_as_float(v[i]);
+    s.h01 = pack_bf16x2(x[0], x[1]); s.h23 = pack_bf16x2(x[2], x[3]);
+    r[0] = x[0] - bf16_lo(s.h01); r[1] = x[1] - bf16_hi(s.h01); r[2] = x[2] - bf16_lo(s.h23); r[3] = x[3] - bf16_hi(s.h23);
+    s.m01 = pack_bf16x2(r[0], r[1]); s.m23 = pack_bf16x2(r[2], r[3]);
+    q[0] = r[0] - bf16_lo(s.m01); q[1] = r[1] - bf16_hi(s.m01); q[2] = r[2] - bf16_lo(s.m23); q[3] = r[3] - bf16_hi(s.m23);
+    s.l01 = pack_bf16x2(q[0], q[1]); s.l23 = pack_bf16x2(q[2], q[3]);
+    return s;
+}
+// c += A * B for one 16-byte chunk pair of float32 fragments (K = 8: 4 floats per lane and half)
+__device__ __forceinline__ void mma_f32_chunk(const u32x4& a, const u32x4& b, f32x16& c)
+{
+#if SAUNET_F32_SPLIT
+    const F32Split A = f32_split3(a), B = f32_split3(b);
+    const u32x4 a3 = {A.h01, A.h23, A.l01, A.l23}, b3 = {B.l01, B.l23, B.h01, B.h23};     // h*l + l*h   (smallest terms first)
+    const u32x4 a2 = {A.m01, A.m23, A.m01, A.m23}, b12 = {B.h01, B.h23, B.m01, B.m23};    // m*h + m*m
+    const u32x4 a1 = {A.h01, A.h23, A.h01, A.h23};                                         // h*h + h*m
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a3), __builtin_bit_cast(bf16x8_t, b3), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a2), __builtin_bit_cast(bf16x8_t, b12), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1), __builtin_bit_cast(bf16x8_t, b12), c, 0, 0, 0);
+#else
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+#endif
+}
+
 // 16-byte vector of T as floats: 4 f32 or 8 bf16
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {

@@ -37,9 +37,7 @@ template <> struct MmaT<u16> {
 template <> struct MmaT<float> {
     __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c)
     {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+        mma_f32_chunk(a, b, c);
     }
 };
 
