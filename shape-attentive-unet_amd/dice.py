@@ -122,6 +122,92 @@ def run(size=128, batch=8, steps=300, pool=64, eval_n=32, seed=304, optimizer="r
     return out
 
 
+def seeded_state_dict(seed, num_classes=4):
+    """Deterministic SAUNet weights from (seed, parameter name): numpy PCG64 seeded with [seed, crc32(name)], He-style fan-in scaling for
+    convolutions, non-trivial BatchNorm parameters and running statistics.  The SAME generator produced the initialisation of the reference
+    runs behind tests/golden/dice_ref.npz (oracle/make_golden_dice.py uses oracle.weights.make_state_dict; tests/test_hip_dice.py asserts that
+    the two agree bit for bit), so a HIP run started from it sees exactly the reference's weights and mini-batches."""
+    import zlib
+    net = M.SAUNet(num_classes=num_classes)
+    kinds = {}
+    for mname, m in net.named_modules():
+        pre = mname + "." if mname else ""
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            kinds[pre + "weight"] = "gamma"; kinds[pre + "bias"] = "beta"; kinds[pre + "running_mean"] = "rmean"; kinds[pre + "running_var"] = "rvar"
+        elif isinstance(m, (torch.nn.modules.conv._ConvNd, torch.nn.Linear)):
+            kinds[pre + "weight"] = "conv"
+            if m.bias is not None:
+                kinds[pre + "bias"] = "bias"
+    out, seen = {}, set()
+    for key, v in net.state_dict().items():
+        if v.data_ptr() in seen and v.numel() > 0:
+            continue                         # an alias of a tensor that already has its (first, torchvision-style) name: conv1.0 = encoder.features.conv0, ...
+        seen.add(v.data_ptr())
+        kind, shape = kinds.get(key), tuple(v.shape)
+        if kind is None:
+            out[key] = v.clone()             # counters (num_batches_tracked, _running_iter, ...)
+            continue
+        r = np.random.default_rng([seed, zlib.crc32(key.encode())])
+        if kind == "conv":
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+            if key.endswith("mrf.up.0.weight") or key == "dec1.block.1.weight":      # ConvTranspose2d [Cin, Cout, 4, 4]: 2 x 2 taps reach an output pixel
+                fan_in = shape[0] * 4
+            a = r.standard_normal(shape, dtype=np.float32) * np.float32(np.sqrt(2.0 / max(fan_in, 1)))
+        elif kind == "bias":
+            a = r.standard_normal(shape, dtype=np.float32) * np.float32(0.05)
+        elif kind == "gamma":
+            a = r.uniform(0.6, 1.4, shape).astype(np.float32)
+        elif kind in ("beta", "rmean"):
+            a = r.standard_normal(shape, dtype=np.float32) * np.float32(0.1)
+        else:
+            a = r.uniform(0.5, 1.5, shape).astype(np.float32)
+        out[key] = torch.from_numpy(np.ascontiguousarray(a))
+    return out
+
+
+def paired_study(seeds=(304, 305, 306, 307, 308), ref_npz=None, steps=300, size=128, batch=8, pool=64, eval_n=512, lr=2e-3, device="cuda"):
+    """The metric's second half as a STATISTIC: for every seed the HIP path is trained in float32 and in bf16 storage from seeded_state_dict(seed)
+    on the mini-batch schedule of `run` and evaluated on `eval_n` held-out phantoms; `ref_npz` (tests/golden/dice_ref.npz: the REAL reference
+    trained on the CPU from the same weights, batches and optimiser, /root/reference/train.py:25-64, 95-106, radam.py) supplies the third arm.
+    Returns per-seed per-class Dice of each arm and, for every pair of arms, the paired mean difference over seeds with its 95 % confidence
+    half-width (Student t) -- training is chaotic (two float32 runs from weights 1e-6 apart drift percent-level in Dice on a small validation
+    set), so single-seed differences mean nothing; the paired mean over seeds and a 512-slice validation set does."""
+    tcrit = {2: 12.706, 3: 4.303, 4: 3.182, 5: 2.776, 6: 2.571, 7: 2.447, 8: 2.365}
+    ref = None
+    if ref_npz is not None:
+        z = np.load(ref_npz)
+        if int(z["steps"]) == steps and int(z["size"]) == size and int(z["batch"]) == batch and int(z["pool"]) == pool and int(z["eval_n"]) == eval_n:
+            ref = {int(s_): (z["dice"][i], z["loss_curve"][i]) for i, s_ in enumerate(z["seeds"])}
+    rows = []
+    for sd_ in seeds:
+        res = run(size=size, batch=batch, steps=steps, pool=pool, eval_n=eval_n, seed=sd_, optimizer="radam", lr=lr, device=device,
+                  state_dict=seeded_state_dict(sd_))
+        row = {"seed": int(sd_), "f32": res["f32"]["dice"], "bf16": res["bf16"]["dice"], "loss_first_f32": res["f32"]["loss_curve"][:5],
+               "loss_last_f32": res["f32"]["loss_last"], "loss_last_bf16": res["bf16"]["loss_last"]}
+        if ref is not None and int(sd_) in ref:
+            row["ref"] = [round(float(v), 5) for v in ref[int(sd_)][0]]
+            row["loss_first_ref"] = [round(float(v), 5) for v in ref[int(sd_)][1][:5]]
+            row["loss_last_ref"] = round(float(np.mean(ref[int(sd_)][1][-10:])), 5)
+        rows.append(row)
+    out = {"protocol": "%d RAdam steps (lr %g, no weight decay) from seeded weights on %d synthetic %dx%d phantoms, batch %d; hard Dice of RV / MYO / LV on %d "
+                       "held-out phantoms (argmax of the scores, intersection / union histograms: train.py:25-64); arms: HIP float32, HIP bf16 storage, "
+                       "REFERENCE (CPU, tests/golden/dice_ref.npz); paired over seeds" % (steps, lr, pool, size, size, batch, eval_n),
+           "seeds": [int(s_) for s_ in seeds], "rows": rows, "pairs": {}}
+    arms = ["f32", "bf16"] + (["ref"] if all("ref" in r for r in rows) else [])
+    for a_ in arms:
+        out["mean_dice_" + a_] = round(float(np.mean([np.mean(r[a_]) for r in rows])), 5)
+    n = len(rows)
+    for a_, b_ in (("f32", "ref"), ("bf16", "ref"), ("bf16", "f32")):
+        if a_ not in arms or b_ not in arms:
+            continue
+        d = np.array([np.array(r[a_]) - np.array(r[b_]) for r in rows])             # [seeds, 3 classes]
+        dm = d.mean(1)                                                               # per-seed mean over classes
+        hw = (tcrit.get(n, 2.0) * dm.std(ddof=1) / np.sqrt(n)) if n > 1 else float("nan")
+        out["pairs"]["%s_minus_%s" % (a_, b_)] = {"mean": round(float(dm.mean()), 5), "ci95_halfwidth": round(float(hw), 5),
+                                                  "per_class_mean": [round(float(v), 5) for v in d.mean(0)], "max_abs_single": round(float(np.abs(d).max()), 5)}
+    return out
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
     ap.add_argument("--size", type=int, default=128)

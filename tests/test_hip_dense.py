@@ -12,17 +12,22 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-def ref_block(block, x):
+def ref_block(block, x, margin=None):
+    """margin: optional one-element list that receives the smallest |pre-activation| in front of any ReLU of the block"""
     d = torch.float64
     prm = {k: v.detach().to(d).requires_grad_(True) for k, v in block.named_parameters()}
     xr = x.detach().to(d).requires_grad_(True)
     feats = [xr]
+    lo = float("inf")
     for name, layer in block.items():
         cat = torch.cat(feats, 1)
-        a = F.relu(F.batch_norm(cat, None, None, prm[name + ".norm1.weight"], prm[name + ".norm1.bias"], True, 0.0, layer.norm1.eps))
-        z1 = F.conv2d(a, prm[name + ".conv1.weight"])
-        b = F.relu(F.batch_norm(z1, None, None, prm[name + ".norm2.weight"], prm[name + ".norm2.bias"], True, 0.0, layer.norm2.eps))
-        feats.append(F.conv2d(b, prm[name + ".conv2.weight"], padding=1))
+        pre1 = F.batch_norm(cat, None, None, prm[name + ".norm1.weight"], prm[name + ".norm1.bias"], True, 0.0, layer.norm1.eps)
+        z1 = F.conv2d(F.relu(pre1), prm[name + ".conv1.weight"])
+        pre2 = F.batch_norm(z1, None, None, prm[name + ".norm2.weight"], prm[name + ".norm2.bias"], True, 0.0, layer.norm2.eps)
+        feats.append(F.conv2d(F.relu(pre2), prm[name + ".conv2.weight"], padding=1))
+        lo = min(lo, float(pre1.detach().abs().min()), float(pre2.detach().abs().min()))
+    if margin is not None:
+        margin.append(lo)
     return torch.cat(feats, 1), xr, prm
 
 
@@ -36,9 +41,16 @@ def rel_l2(a, b):
     return float((a.detach().to(torch.float64) - b).norm() / b.norm().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("dtype,tol,beta", [(torch.float32, 2e-4, (4.0, 6.0)), (torch.float32, 2e-4, (-0.3, 0.3)), (torch.bfloat16, 1e-2, (-0.3, 0.3))])
 @pytest.mark.parametrize("layers,cin,shape", [(3, 64, (2, 32, 32)), (2, 96, (1, 16, 48)), (4, 40, (3, 16, 16))])
-def test_dense_block_fwd_bwd(dtype, tol, layers, cin, shape):
+def test_dense_block_fwd_bwd(dtype, tol, beta, layers, cin, shape):
+    """float32 is checked twice.  (a) beta in [4, 6]: (almost) every pre-activation is far from the ReLU kink, so the gradients are smooth
+    functions of the arithmetic and EVERY element must agree with float64 to 2e-4 of its tensor's scale -- this pins the linear algebra, the
+    BatchNorm backward and the deferred correction.  (b) beta in [-0.3, 0.3] (half of the units off): the forward is still held to 2e-4, but
+    a block has ~1.4 M pre-activations of density 0.4 around zero, i.e. about one within float32 round-off (1e-6) of the kink per run, and
+    whether THAT mask is 0 or 1 is decided by the last bits of the convolution (round 4: the 3 x bf16 split MFMA flipped one at seed 364
+    where the exact-f32 MFMA did not; both are 1e-6 from float64).  One flip moves a bias gradient by 3 % and everything upstream by 1e-3 in
+    L2, so (b) compares gradients in relative L2 with 2e-2: a wrong mask, slice or coefficient is an O(1) error there."""
     import saunet_amd as S
     torch.manual_seed(layers * 100 + cin)
     n, h, w = shape
@@ -46,7 +58,7 @@ def test_dense_block_fwd_bwd(dtype, tol, layers, cin, shape):
     with torch.no_grad():
         for m in block.modules():
             if isinstance(m, torch.nn.BatchNorm2d):
-                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(*beta)
     x = torch.randn(n, cin, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     y = block(x)
     cot = torch.randn(y.shape, device="cuda").to(dtype)
@@ -54,7 +66,8 @@ def test_dense_block_fwd_bwd(dtype, tol, layers, cin, shape):
     ry, xr, prm = ref_block(block, x)
     (ry * cot.double()).sum().backward()
     assert rel(y, ry) < tol, rel(y, ry)
-    err, gtol = (rel, tol) if dtype == torch.float32 else (rel_l2, 0.2)
+    strict = dtype == torch.float32 and beta[0] > 1.0
+    err, gtol = (rel, tol) if strict else (rel_l2, 2e-2 if dtype == torch.float32 else 0.2)
     assert err(x.grad, xr.grad) < gtol, err(x.grad, xr.grad)
     for k, v in block.named_parameters():
         assert err(v.grad, prm[k].grad) < gtol, (k, err(v.grad, prm[k].grad))
@@ -192,3 +205,4 @@ def test_grouped_weight_gradients_refuse_untiled_maps():
     dy = torch.randn(2, 32, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
     wt = torch.nn.Parameter(torch.empty(32, 32, 3, 3, device="cuda"))
     assert HF.conv_wgrad_grouped([(x, dy, wt, None)], 3, 1, False) is None
+
