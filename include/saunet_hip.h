@@ -169,36 +169,6 @@ int saunet_bn_finalize(int C, const double* sum, const double* sumsq, int replic
                        const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, float* scale, float* shift,
                        float* mean, float* invstd, int training, void* stream);
-/* ---- a whole DenseNet block forward in ONE persistent launch (training mode, bf16, low-resolution maps) ---------------------------
- * Replaces the per-layer launch sequence of torchvision's _DenseBlock / _DenseLayer as the reference uses it
- * (models/models.py:271 densenet121, :306-313 the four dense blocks):  per layer  BN1 finalize -> 1x1 conv (+ statistics of its output)
- * -> BN2 finalize -> 3x3 conv into the layer's 32-channel slice of the concat buffer (+ statistics of the new channels).
- * One workgroup per CU keeps its 8x16 pixel tiles for all layers; two device-wide barriers per layer (bounded spin: a barrier that
- * expires raises word 1 of sync_ws and the remaining barriers fall through -- wrong numbers, never a hung device).  Every workgroup must be
- * resident: do not run two of these launches concurrently on one device (two processes sharing a GPU).
- *   buf      [P][ldbuf] bf16 concat buffer, channels [0, c0) filled by the caller; channels [c0, c0 + 32*nl) are written here
- *   stats    float64 accumulators [reps][2][ctot] (sum, sum of squares; replica stride stat_rstride doubles) holding the statistics of the first
- *            c0 channels on entry, zero elsewhere; the new channels' statistics are added
- *   per layer: packed forward weights w1 [128][cin], w2 [32][3][3][128] (saunet_pack_weight FWD layout), BatchNorm parameters and running
- *            statistics (updated with `momentum`, unbiased variance), z1 [P][128] (output of the 1x1 conv, kept for backward), p1 [4][cin] and
- *            p2 [4][128] (scale, shift, mean, invstd: the saunet_bn_finalize layout), st2 zeroed float64 accumulators [st2_reps][2][128]
- *   sync_ws  >= 8192 bytes of device memory (zeroed by the call; word 0 unused, word 1 = abort flag, then the barrier's counter lines).  H % 8 == 0, W % 16 == 0, c0 % 32 == 0, c0 + 32*nl <= 1024. */
-#define SAUNET_DENSE_MAX_LAYERS 24
-typedef struct saunet_dense_fwd_layer {
-    const void* w1; const void* w2;
-    const float* gamma1; const float* beta1; float* rmean1; float* rvar1;
-    const float* gamma2; const float* beta2; float* rmean2; float* rvar2;
-    void* z1; float* p1; float* p2; double* st2;
-    int32_t st2_reps, st2_rstride;
-    float eps, momentum;
-} saunet_dense_fwd_layer;
-typedef struct saunet_dense_fwd_desc {
-    int32_t dtype, N, H, W, c0, nl, ldbuf, stat_reps, stat_rstride, reserved;
-    void* buf; double* stats;
-    saunet_dense_fwd_layer layer[SAUNET_DENSE_MAX_LAYERS];
-} saunet_dense_fwd_desc;
-int saunet_dense_block_forward(const saunet_dense_fwd_desc* d, void* sync_ws, void* stream);
-
 /* SynchronizedBatchNorm2d across data-parallel replicas (lib/nn/modules/batchnorm.py:118-139, _compute_mean_std):
  * (sum, sumsq, count) are the GLOBAL (all-reduced) statistics; inv_std = clamp(biased var, eps)^-1/2; the moving average is
  * the reference's accumulator pair  tmp = tmp*(1-momentum) + stat,  iter = iter*(1-momentum) + 1,  running = tmp / iter

@@ -35,16 +35,6 @@ elif case in ("dec3fwd", "dec5fwd"):
     x = act(cin, h); w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device="cuda") * 0.02)
     out = HF.new_act(n, cout, h, h, dt, "cuda"); st = torch.zeros(HF.STAT_R, 2, cout, dtype=torch.float64, device="cuda")
     run = lambda: HF.conv_forward_raw(x, w, None, 1, 1, out=out, stats=st)
-elif case in ("dense3fwd", "dense4fwd"):
-    unit = "dense_fwd"
-    layers, cin, h = {"dense3fwd": (24, 256, 32), "dense4fwd": (16, 512, 16)}[case]
-    S.set_compute_dtype(dt)
-    HF.DENSE_PERSIST = True                       # the persistent whole-block forward is opt-in
-    block = S.modules._DenseBlock(layers, cin).cuda().train()
-    x = act(cin, h)
-    def run():
-        with torch.no_grad():
-            block(x)
 elif case in ("conv1fwd", "conv1fwd3", "conv1fwd4"):
     unit = "conv_igemm"
     ci_, h_ = {"conv1fwd": (192, 128), "conv1fwd3": (640, 32), "conv1fwd4": (768, 16)}[case]

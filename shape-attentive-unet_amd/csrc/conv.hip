@@ -551,15 +551,13 @@ int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const voi
         if (ho != d->Ho || wo != d->Wo) return set_error(SAUNET_BAD_SHAPE, "conv: Ho/Wo %dx%d != %dx%d", d->Ho, d->Wo, ho, wo);
     }
     if ((ps == nullptr) != (psh == nullptr)) return set_error(SAUNET_BAD_SHAPE, "conv: prologue needs scale and shift");
-    static const bool use_dense_dgrad = !(getenv("SAUNET_DENSE_DGRAD") && getenv("SAUNET_DENSE_DGRAD")[0] == '0');   // A/B switch for profiling
-    if (use_dense_dgrad && ssum == nullptr && dense_dgrad_supported(d, bias, ps, epi)) return dense_dgrad_forward(d, x, w, y, epi, st);
-    if (use_dense_dgrad && ssum == nullptr && dense_dgrad3_supported(d, bias, ps, epi)) return dense_dgrad3_forward(d, x, w, y, epi, st);
+    if (ssum == nullptr && dense_dgrad_supported(d, bias, ps, epi)) return dense_dgrad_forward(d, x, w, y, epi, st);
+    if (ssum == nullptr && dense_dgrad3_supported(d, bias, ps, epi)) return dense_dgrad3_forward(d, x, w, y, epi, st);
     if (mm_fwd_supported(d, x, w, y, ps, epi)) return mm_forward(d, x, w, bias, y, ssum, ssq, st);
     if (igemm_supported(d)) {
         if (epi && (((uintptr_t)epi->bn_x & 15) || epi->ld_bn_x % (d->dtype == SAUNET_BF16 ? 8 : 4)))
             return set_error(SAUNET_BAD_ALIGN, "conv: bn epilogue tensor must be 16-byte aligned");
-        static const long tile_minpix = getenv("SAUNET_TILE_MINPIX") ? atol(getenv("SAUNET_TILE_MINPIX")) : 0;     // A/B switch for profiling
-        if (tile_fwd_supported(d) && (long)d->N * d->H * d->W >= tile_minpix) {
+        if (tile_fwd_supported(d)) {
             if (epi && epi->accumulate) return set_error(SAUNET_UNSUPPORTED, "conv: accumulating BN epilogue is implemented for 1x1 dgrads");
             return tile_forward(d, x, w, bias, ps, psh, y, ssum, ssq, epi, st);
         }
@@ -625,8 +623,7 @@ int saunet_conv2d_forward_bnpro(const saunet_conv_desc* d, const void* x, const 
         return set_error(SAUNET_BAD_SHAPE, "conv: bad shape N=%d Cin=%d ldx=%d Cout=%d ldy=%d", d->N, d->Cin, d->ldx, d->Cout, d->ldy);
     saunet_bn_prologue p = *pro;
     if (p.replicas < 1) p.replicas = 1;
-    static const bool fuse = !(getenv("SAUNET_BNPRO_FUSED") && getenv("SAUNET_BNPRO_FUSED")[0] == '0');      // A/B switch
-    if (fuse && !d->transposed && igemm_supported(d)) {
+    if (!d->transposed && igemm_supported(d)) {
         int ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
         if (ho != d->Ho || wo != d->Wo) return set_error(SAUNET_BAD_SHAPE, "conv: Ho/Wo %dx%d != %dx%d", d->Ho, d->Wo, ho, wo);
         if (tile_fwd_supported(d)) return tile_forward(d, x, w, bias, nullptr, nullptr, y, ssum, ssq, nullptr, st, &p);

@@ -395,19 +395,9 @@ template <typename T> static int dispatch_fwd(const IgemmArgs& a, int phases, hi
     } else {
         // small problems (low-resolution maps): 64x64 tiles so that the grid still covers the 256 CUs
         const long blocks128 = (long)cdiv(a.M, 128) * cdiv(a.Cout, 128) * phases;
-        // opt-in (SAUNET_IGEMM_T32=<workgroup threshold>): 32-row tiles of two waves for tiny problems (16 x 16 maps: 256 workgroups of 64 x 64
-        // tiles, one per CU) so that two K loops overlap on every CU.  Measured (same-box A/B, threshold 384): +0.1 ms per step
-        static const long t32 = getenv("SAUNET_IGEMM_T32") ? atol(getenv("SAUNET_IGEMM_T32")) : 0;
-        const long blocks64 = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64) * phases;
-        if (blocks64 < t32 && !a.epi.bn_x)
-            return narrow ? launch_fwd<T, 32, 64, 32, 32, 4>(a, phases, st) : launch_fwd<T, 32, 64, 32, 32, 8>(a, phases, st);
-        // A/B probe (SAUNET_IGEMM_T64X128=1): 64 pixels x 128 output channels per workgroup on the small maps -- the pixel rows are read once instead
-        // of once per 64-channel column tile
-        static const bool t64x128 = getenv("SAUNET_IGEMM_T64X128") && getenv("SAUNET_IGEMM_T64X128")[0] == '1';
-        if (blocks128 < 384 && t64x128 && a.Cout % 128 == 0 && !a.epi.bn_x)
-            return narrow ? launch_fwd<T, 64, 128, 32, 64, 4>(a, phases, st) : launch_fwd<T, 64, 128, 32, 64, 8>(a, phases, st);
-        static const long bigmin = getenv("SAUNET_IGEMM_BIGMIN") ? atol(getenv("SAUNET_IGEMM_BIGMIN")) : 384;      // A/B probe
-        if (blocks128 < bigmin)
+        // (measured slower and removed from the library in round 4: 32-row tiles of two waves for 16 x 16 maps, +0.1 ms per step; 64 pixels x 128
+        // output channels per workgroup on the small maps)
+        if (blocks128 < 384)
             return narrow ? launch_fwd<T, 64, 64, 32, 32, 4>(a, phases, st) : launch_fwd<T, 64, 64, 32, 32, 8>(a, phases, st);
         return narrow ? launch_fwd<T, 128, 128, 64, 64, 4>(a, phases, st) : launch_fwd<T, 128, 128, 64, 64, 8>(a, phases, st);
     }
@@ -444,9 +434,9 @@ int igemm_forward(const saunet_conv_desc* d, const void* x, const void* w, const
     if (d->dtype == SAUNET_BF16) {
         a.kpt = cdiv(d->Cin, (d->Cin <= 32) ? 32 : 64);
         // pointwise convs on large maps are memory bound with a short K loop: 32-channel K steps halve the LDS footprint, so twice as many
-        // workgroups are resident per CU to overlap each other's load / epilogue latencies (33.78 -> 33.69 ms/step; env switch for A/B runs)
-        static const long narrow_minpix = getenv("SAUNET_IGEMM_NARROW_MINPIX") ? atol(getenv("SAUNET_IGEMM_NARROW_MINPIX")) : 100000;
-        if (narrow_minpix >= 0 && d->KH == 1 && d->KW == 1 && !d->transposed && a.M >= narrow_minpix && d->Cin > 64) a.kpt = cdiv(d->Cin, 32);
+        // workgroups are resident per CU to overlap each other's load / epilogue latencies (33.78 -> 33.69 ms/step)
+        constexpr long narrow_minpix = 100000;
+        if (d->KH == 1 && d->KW == 1 && !d->transposed && a.M >= narrow_minpix && d->Cin > 64) a.kpt = cdiv(d->Cin, 32);
         return dispatch_fwd<u16>(a, phases, st);
     } else if (d->dtype == SAUNET_F32) {
         a.kpt = cdiv(d->Cin, (d->Cin <= 16) ? 16 : 32);

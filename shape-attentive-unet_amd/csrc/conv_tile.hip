@@ -351,9 +351,8 @@ template <typename T> static int dispatch_tile_fwd(const TileArgs& a, hipStream_
     const long blocks128 = (long)a.tiles_x * a.tiles_y * a.N * ((a.Cout + 127) / 128);
     // two resident workgroups per CU hide the fragment-read latency that one four-wave workgroup per CU exposes (MFMA pipe 19-28 % busy on
     // dec4 / dec5): below 512 workgroups the output-channel tile is halved (dec4 233 -> 196 us with 64-wide tiles, dec5 259 -> 233 us with 32-wide
-    // ones; the extra halo re-reads come from the L2).  Environment overrides for A/B runs.
-    static const long t128 = getenv("SAUNET_TILE_T128") ? atol(getenv("SAUNET_TILE_T128")) : 512;
-    static const long t64 = getenv("SAUNET_TILE_T64") ? atol(getenv("SAUNET_TILE_T64")) : 512;
+    // ones; the extra halo re-reads come from the L2).
+    constexpr long t128 = 512, t64 = 512;
     const long blocks64 = (long)a.tiles_x * a.tiles_y * a.N * ((a.Cout + 63) / 64);
     if (!a.epi.bn_x && blocks64 < t64) return narrow ? launch_tile_fwd<T, 32, 64, 32, 4>(a, st) : launch_tile_fwd<T, 32, 64, 32, 8>(a, st);
     if (a.Cout <= 64 || (blocks128 < t128 && !a.epi.bn_x))
@@ -1028,7 +1027,7 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
     };
     // register prefetch: the NEXT tile's global loads are issued right after this tile is in LDS and fly during its matrix-core loop
     // (without it every tile pays load latency -> LDS -> barrier -> MFMA in sequence; two resident blocks per CU hide only part of it)
-    constexpr bool PF = (SAUNET_WGRAD_PREFETCH || TS || KS == 2) && ALIGNED && sizeof(T) == 2 && (YI + XI) <= 16;
+    constexpr bool PF = (SAUNET_WGRAD_PREFETCH || (TS && WM == 32) || KS == 2) && ALIGNED && sizeof(T) == 2 && (YI + XI) <= 16;   // (the 64 x 64 tap-split tile has no registers to spare)
     u32x4 pyreg[PF ? YI : 1], pxreg[PF ? XI : 1];
     if constexpr (PF) {
         if (gx < a.ntiles) { int n, ty0, tx0; tile_coords(gx, n, ty0, tx0); load_y(n, ty0, tx0, pyreg); load_x(n, ty0, tx0, pxreg, 0, XI); }
@@ -1261,9 +1260,10 @@ template <typename T> static int dispatch_tile_wgrad(TileWgradArgs& a, int ks, b
     const bool small = (long)a.Cout * a.Cin <= 64 * 128;
     if constexpr (sizeof(T) == 2) {
         if (ks == 3) {
-            static const bool tapsplit = getenv("SAUNET_WGRAD3_TS") && getenv("SAUNET_WGRAD3_TS")[0] == '1';
-            if (small && tapsplit) return launch_tile_wgrad<T, 3, 16, 32, 32, 32, 32, -4>(a, wsb, need, st);
             if (small) return launch_tile_wgrad<T, 3, 16, 32, 32, 32, 32, 4>(a, wsb, need, st);
+            // measured and rejected (round 4): a 64 x 64 wave tile with the taps split 3/2/2/2 over the four waves (0.72 instead of 1.11 fragments per
+            // MFMA): dec4 267 -> 343 us, dec3 270 -> 333, dec2 275 -> 358 -- 192 accumulator registers spill the staging registers (29 VGPRs) and
+            // the wave holding three taps paces the other three
             return launch_tile_wgrad<T, 3, 8, 64, 64, 32, 32, 1>(a, wsb, need, st);
         }
         if (small) return launch_tile_wgrad<T, 1, 16, 64, 64, 64, 64, 4>(a, wsb, need, st);
@@ -1353,8 +1353,7 @@ static int launch_tile_wgrad_grouped(GroupedWgradArgs& g, const saunet_wgrad_gro
         capacity = per_cu * prop.multiProcessorCount;
         (void)hipGetLastError();
     }
-    static const long target_env = getenv("SAUNET_WGRAD_GROUP_BLOCKS") ? atol(getenv("SAUNET_WGRAD_GROUP_BLOCKS")) : 0;
-    const long target = target_env > 0 ? target_env : capacity;
+    const long target = capacity;
     long groups_l = target / chan_tiles;
     if (groups_l > g.ntiles) groups_l = g.ntiles;
     if (groups_l < 1) groups_l = 1;
@@ -1422,22 +1421,14 @@ int tile_wgrad_grouped(const saunet_wgrad_group* s, void* ws, size_t ws_bytes, s
     for (int i = s->count; i < SAUNET_WGRAD_GROUP_MAX; ++i) g.item[i] = GWItem{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
     if (s->dtype == SAUNET_BF16) {
         if (s->KH == 3) {
-            // opt-in (SAUNET_WGRAD3_WIDE=1), DenseNet conv2 (128 -> 32): one workgroup takes ALL 128 input channels of a pixel tile (its four
-            // waves 32 each), so the dy tile is staged once instead of once per 32-channel input tile.  Measured (same-box A/B): +0.15 ms per
-            // step -- two 66 KB workgroups per CU overlap less than four 37 KB ones
-            static const bool wide = getenv("SAUNET_WGRAD3_WIDE") && getenv("SAUNET_WGRAD3_WIDE")[0] == '1';
+            // measured slower and removed from the library in round 4 (scripts/build_variant.sh + git history reach them): all 128 input channels per
+            // workgroup (+0.15 ms per step: two 66 KB workgroups per CU overlap less than four 37 KB ones); tap split + register prefetch
+            // (block 1 90.6 -> 114.5 us per layer, blocks 2-4 5-15 % faster, step +0.25 ms)
             bool all_128_32 = true;
             for (int i = 0; i < s->count; ++i) if (s->item[i].Cout > 32 || s->item[i].Cin % 128) all_128_32 = false;
-            if (wide && all_128_32) return launch_tile_wgrad_grouped<u16, 3, 8, 32, 128, 32, 32, 1>(g, s, ws, ws_bytes, need, st);
-            // opt-in (SAUNET_WGRAD3_TS=1): tap split + register prefetch.  Measured: block 1 slower (90.6 -> 114.5 us per layer: every wave re-reads
-            // all 16 dy fragments and wave 0 carries 3 of the 9 taps), blocks 2-4 5-15 % faster; step +0.25 ms.  Off.
-            static const bool tapsplit = getenv("SAUNET_WGRAD3_TS") && getenv("SAUNET_WGRAD3_TS")[0] == '1';
-            if (small && tapsplit) return launch_tile_wgrad_grouped<u16, 3, 16, 32, 32, 32, 32, -4>(g, s, ws, ws_bytes, need, st);
             // DenseNet conv2 (128 -> 32): 64 input channels per workgroup (two channel waves x two K waves) -- the dy tile is re-read per 64 instead of per
-            // 32 input channels (the block-1 launch is HBM-bound at 1.47x its algorithmic bytes): 27.71 -> 27.50 ms per step.  SAUNET_WGRAD3_CI64=0 = the
-            // 32-channel tile with four K waves
-            static const bool ci64 = !(getenv("SAUNET_WGRAD3_CI64") && getenv("SAUNET_WGRAD3_CI64")[0] == '0');
-            if (small && ci64 && all_128_32) return launch_tile_wgrad_grouped<u16, 3, 16, 32, 64, 32, 32, 2>(g, s, ws, ws_bytes, need, st);
+            // 32 input channels (the block-1 launch is HBM-bound at 1.47x its algorithmic bytes): 27.71 -> 27.50 ms per step
+            if (small && all_128_32) return launch_tile_wgrad_grouped<u16, 3, 16, 32, 64, 32, 32, 2>(g, s, ws, ws_bytes, need, st);
             if (small) return launch_tile_wgrad_grouped<u16, 3, 16, 32, 32, 32, 32, 4>(g, s, ws, ws_bytes, need, st);
             return launch_tile_wgrad_grouped<u16, 3, 8, 64, 64, 32, 32, 1>(g, s, ws, ws_bytes, need, st);
         }

@@ -501,16 +501,11 @@ int dense_dgrad_forward(const saunet_conv_desc* d, const void* x, const void* w,
     // channels per block: 256 (weights copied to LDS once per block) when every wave gets many pixel tiles, fewer on the
     // low-resolution blocks where the copy would dominate and more blocks are needed to fill the chip
     const long ntp = ((long)a.P + 31) / 32;
-    static const int big_group = getenv("SAUNET_DG_GROUP") ? atoi(getenv("SAUNET_DG_GROUP")) : DG_GROUP;      // A/B switch: 64 / 128 / 192 / 256
-    a.group = ntp >= 4096 ? big_group : (ntp >= 1024 ? 128 : 64);
+    a.group = ntp >= 4096 ? DG_GROUP : (ntp >= 1024 ? 128 : 64);
     {   // equal groups: every group runs the same number of 64-channel steps (the step sequence is compiled per step count), so
         // Cin = 320 with at most 256 channels per group is 2 x 160, not 256 + 64
         const int ng = (a.Cin + a.group - 1) / a.group;
         a.group = ((a.Cin + ng - 1) / ng + 31) & ~31;
-    }
-    if (const char* e = getenv("SAUNET_DG_GROUP_SMALL")) {      // A/B switch for the small-map heuristic: "<group at ntp>=1024>,<group below>"
-        int g3 = 128, g4 = 64;
-        if (sscanf(e, "%d,%d", &g3, &g4) == 2 && ntp < 4096) a.group = ntp >= 1024 ? g3 : g4;
     }
     const int groups = (a.Cin + a.group - 1) / a.group;
     const int gcp = ((a.Cin < a.group ? a.Cin : a.group) + 31) & ~31;

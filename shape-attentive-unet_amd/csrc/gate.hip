@@ -702,7 +702,7 @@ static int gate_blocks(int64_t pixels)
 // streaming passes: a wave takes >= 8 pixel pairs (64 pixels each) so that building its weight fragments is amortised
 static unsigned gate_stream_blocks(int64_t pixels)
 {
-    static const long cap = getenv("SAUNET_GATE_BLOCKS") ? atol(getenv("SAUNET_GATE_BLOCKS")) : 512;    // measured: 512 < 1024 < 2048 (the per-wave fragment build)
+    constexpr long cap = 512;    // measured: 512 < 1024 < 2048 (the per-wave fragment build)
     long b = (pixels + 2047) / 2048;
     if (b > cap) b = cap;
     return (unsigned)(b < 1 ? 1 : b);

@@ -148,8 +148,6 @@ class GradientBuckets:
         return [g for g, _ in pairs], [v for _, v in pairs]
 
     def _launch(self, b):
-        from . import functional as HF
-        HF.WGRAD_SIDE.join()          # weight gradients are written on a side stream
         grads, views = self._present(b)
         if len(grads) != len(self.buckets[b]):
             self.flat[b].zero_()      # first step only: slots of gradient-less parameters travel as zeros (every rank agrees)

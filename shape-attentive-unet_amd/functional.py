@@ -354,7 +354,7 @@ def conv_forward_bnpro(x, weight, stride, pad, bn_stats_in, count, c_lo, xhat, g
     return out
 
 
-DENSE_BNPRO = os.environ.get("SAUNET_DENSE_BNPRO", "1") != "0"    # A/B switch: per-layer saunet_bn_finalize launches when "0"
+DENSE_BNPRO = True    # consumer-side BatchNorm finalize in the DenseNet layers (False: per-layer saunet_bn_finalize launches; module attribute for A/B runs and tests)
 
 
 def igemm_ok(t, cin, cout):
@@ -396,43 +396,7 @@ def conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed=False, out=None,
     return out
 
 
-class SideStream:
-    """Weight-gradient kernels depend only on tensors that already exist and nothing in the backward chain depends on
-    them, so they run on a second HIP stream and overlap the dgrad / BatchNorm-backward chain (which matters most on the
-    low-resolution layers whose grids do not fill 256 CUs).  `join()` makes the main stream wait for them."""
-
-    def __init__(self):
-        self.enabled = os.environ.get("SAUNET_WGRAD_SIDE_STREAM", "0") == "1"   # measured neutral on MI355X: off by default
-        self.max_pixels = int(os.environ.get("SAUNET_WGRAD_SIDE_MAXPIX", "0"))  # > 0: only launches with at most this many pixels
-        self.streams = {}
-        self.dirty = False
-
-    def get(self, device):
-        s = self.streams.get(device)
-        if s is None:
-            s = torch.cuda.Stream(device=device)
-            self.streams[device] = s
-        return s
-
-    def mark(self):
-        if not self.dirty:
-            self.dirty = True
-            try:   # join automatically when the running backward pass ends (safe for any optimiser / hook order)
-                torch.autograd.Variable._execution_engine.queue_callback(self.join)
-            except Exception:
-                pass
-
-    def join(self):
-        if not self.dirty:
-            return
-        for s in self.streams.values():
-            torch.cuda.current_stream(s.device).wait_stream(s)
-        self.dirty = False
-
-
-WGRAD_SIDE = SideStream()
-DENSE_WGRAD_DEFER = os.environ.get("SAUNET_DENSE_WGRAD_DEFER", "")
-DENSE_WGRAD_BATCH_REDUCE = os.environ.get("SAUNET_DENSE_WGRAD_BATCH_REDUCE", "1") != "0"   # A/B switch: per-conv reduce launches when "0"
+DENSE_WGRAD_BATCH_REDUCE = True   # the partial-gradient reductions of a dense block in one launch (False: one per convolution)
 
 
 class _ShapeOnly:
@@ -449,17 +413,6 @@ def conv_wgrad_raw(x, dy, weight, stride, pad, transposed=False, pro=None, pendi
     """pending: optional list collecting the deferred cross-workgroup reductions of the tiled kernels (flush_wgrad_reductions runs them in
     one launch); the returned gradient is complete only after that flush."""
     x = nhwc(x); dy = nhwc(dy)
-    if (WGRAD_SIDE.enabled and x.is_cuda and isinstance(weight, torch.nn.Parameter)   # leaf weights only: nothing in the
-            and (WGRAD_SIDE.max_pixels <= 0 or x.shape[0] * x.shape[2] * x.shape[3] <= WGRAD_SIDE.max_pixels)):
-        main = torch.cuda.current_stream(x.device)                                     # autograd graph reads their gradient
-        side = WGRAD_SIDE.get(x.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            dw = _conv_wgrad_impl(x, dy, weight, stride, pad, transposed, pro)
-        for t in (x, dy, dw) + ((pro[0], pro[1]) if pro else ()):
-            t.record_stream(side)
-        WGRAD_SIDE.mark()
-        return dw
     return _conv_wgrad_impl(x, dy, weight, stride, pad, transposed, pro, pending)
 
 
@@ -475,8 +428,8 @@ def flush_wgrad_reductions(pending):
     del pending[:]
 
 
-DENSE_WGRAD_GROUPED = os.environ.get("SAUNET_DENSE_WGRAD_GROUPED", "1") != "0"   # A/B switch: per-layer weight-gradient launches when "0"
-DENSE_COEFF_CORRECT = os.environ.get("SAUNET_DENSE_COEFF_CORRECT", "1") != "0"   # A/B switch: separate coeff / correct launches when "0"
+DENSE_WGRAD_GROUPED = True   # all weight gradients of a dense block as two grouped launches (False: per-layer launches)
+DENSE_COEFF_CORRECT = True   # coefficient + chunk correction of the linear BatchNorm backward in one launch (False: two)
 
 
 def conv_wgrad_grouped(problems, ksize, pad, pro_relu):
@@ -514,7 +467,7 @@ def conv_wgrad_grouped(problems, ksize, pad, pro_relu):
 
 # ConvTranspose2d(k4 s2 p1) weight gradients straight from the NHWC tensors on the tiled kernel (four parity sub-problems with 2x2 taps, csrc/conv_tile.hip
 # KS == 2); "0" = the round-2 path (im2col of dy + pointwise weight gradient), kept for maps that are not multiples of 16 and as the A/B reference
-CONVT_WGRAD_DIRECT = os.environ.get("SAUNET_CONVT_WGRAD_DIRECT", "1") != "0"
+CONVT_WGRAD_DIRECT = True
 
 
 def _conv_wgrad_impl(x, dy, weight, stride, pad, transposed=False, pro=None, pending=None):
@@ -864,10 +817,10 @@ class _BasicBlock(torch.autograd.Function):
         return dx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None, None
 
 
-# Default since round 3 (SAUNET_FUSED_BASIC_BLOCK=0 restores the two conv_bn_act calls).  Rounds 1 and 2 measured it SLOWER (33.45 -> 33.86 ms per
+# Default since round 3 (FUSED_BASIC_BLOCK = False restores the two conv_bn_act calls).  Rounds 1 and 2 measured it SLOWER (33.45 -> 33.86 ms per
 # step): the three full-resolution passes it saves (0.3 ms) were lost to the BN-backward epilogue of the narrow 3x3 kernels, whose partial sums
 # went through float atomics on LDS (12 cycles per active lane).  With the per-wave slot fold those epilogues are cheap: 30.23 -> 30.05 ms.
-FUSED_BASIC_BLOCK = os.environ.get("SAUNET_FUSED_BASIC_BLOCK", "1") == "1"
+FUSED_BASIC_BLOCK = True
 
 
 def basic_block(x, conv1, bn1, conv2, bn2):
@@ -1469,69 +1422,6 @@ def relu(x):
 
 
 # ------------------------------------------------------------------------------------------------ DenseNet
-# Opt-in (SAUNET_DENSE_PERSIST=1): measured at the bench geometry (hipGraph, scripts/dense_fwd_micro.py) the persistent block forward runs
-# 49.3 us / layer on block 3 against 53.5 for the per-layer launches and 47.5 against 42.9 on block 4 -- a wash, see DESIGN.md section 9 --
-# so the default stays with the launches that need no co-residency assumption.
-DENSE_PERSIST = os.environ.get("SAUNET_DENSE_PERSIST", "0") == "1"
-DENSE_PERSIST_MAXPIX = int(os.environ.get("SAUNET_DENSE_PERSIST_MAXPIX", "65536"))
-
-
-def _dense_persistent_ok(x0, c0, growth, nl, params):
-    """The whole-block persistent forward (csrc/dense_fwd.hip) serves the low-resolution training blocks in bf16 storage.  It is a kernel
-    with device-wide barriers: it is not used when several ranks share ONE device (SAUNET_SHARE_GPU=1, the data-parallel test rig), where two
-    such launches could starve each other; one rank per GPU is fine."""
-    if not (DENSE_PERSIST and x0.is_cuda and x0.dtype == torch.bfloat16):
-        return False
-    n, _, h, w = x0.shape
-    if h % 8 or w % 16 or c0 % 32 or growth != 32 or nl > L.DENSE_MAX_LAYERS or c0 + growth * nl > 1024 or n * h * w > DENSE_PERSIST_MAXPIX:
-        return False
-    if any(tuple(params[6 * l + 2].shape[2:]) != (1, 1) or params[6 * l + 2].shape[0] != 128 or tuple(params[6 * l + 5].shape[1:]) != (128, 3, 3)
-           for l in range(nl)):
-        return False
-    if os.environ.get("SAUNET_SHARE_GPU") == "1" and torch.distributed.is_available() and torch.distributed.is_initialized() \
-            and torch.distributed.get_world_size() > 1:
-        return False                      # the test rig's several ranks on ONE device (dp.init_from_env): two such launches could starve each other
-    return True
-
-
-def _dense_block_forward_persistent(buf, stats, c0, nl, params, bufs, cfgs):
-    """One launch for all layers of the block; returns what the per-layer loop saves for backward: [z1, BNParams(norm1), BNParams(norm2)] * nl."""
-    n, ctot, h, w = buf.shape
-    dev = buf.device
-    d = L.DenseFwdDesc()
-    d.dtype, d.N, d.H, d.W, d.c0, d.nl, d.ldbuf = L.dtype_code(buf), n, h, w, c0, nl, ld_of(buf)
-    d.stat_reps, d.stat_rstride = stats.shape[0], stats.stride(0)
-    d.buf, d.stats = buf.data_ptr(), stats.data_ptr()
-    PACKS.generation += 1                       # running statistics change through raw pointers (as in bn_finalize)
-    saved, keep = [], []
-    for l in range(nl):
-        n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
-        n1rm, n1rv, n2rm, n2rv = bufs[4 * l:4 * l + 4]
-        mom, eps = cfgs[l]
-        cin = c0 + 32 * l
-        w1p, w2p = PACKS.get(c1w, L.PACK_FWD, buf.dtype), PACKS.get(c2w, L.PACK_FWD, buf.dtype)
-        z1 = new_act(n, 128, h, w, buf.dtype, dev)
-        p1, p2 = BNParams(cin, dev), BNParams(128, dev)
-        st2 = new_stats(128, dev)
-        e = d.layer[l]
-        e.w1, e.w2 = w1p.data_ptr(), w2p.data_ptr()
-        e.gamma1, e.beta1, e.rmean1, e.rvar1 = n1w.data_ptr(), n1b.data_ptr(), n1rm.data_ptr(), n1rv.data_ptr()
-        e.gamma2, e.beta2, e.rmean2, e.rvar2 = n2w.data_ptr(), n2b.data_ptr(), n2rm.data_ptr(), n2rv.data_ptr()
-        e.z1, e.p1, e.p2, e.st2 = z1.data_ptr(), p1.buf.data_ptr(), p2.buf.data_ptr(), st2.data_ptr()
-        e.st2_reps, e.st2_rstride = st2.shape[0], st2.stride(0)
-        e.eps, e.momentum = float(eps), float(mom)
-        saved += [z1, p1.buf, p2.buf]
-        keep += [w1p, w2p, st2]
-    sync = torch.empty(2048, dtype=torch.int32, device=dev)
-    L.call("saunet_dense_block_forward", C.byref(d), sync.data_ptr(), L.stream())
-    global LAST_DENSE_SYNC
-    LAST_DENSE_SYNC = sync          # word 1: abort flag (tests assert it stayed 0); word 32 * 17: root counter of the barrier
-    return saved
-
-
-LAST_DENSE_SYNC = None
-
-
 class _DenseBlock(torch.autograd.Function):
     """One DenseNet block: L x [BN-ReLU-conv1x1(->128)-BN-ReLU-conv3x3(->32)] over a growing concat.
 
@@ -1558,11 +1448,7 @@ class _DenseBlock(torch.autograd.Function):
         if training:
             bn_stats(buf[:, :c0], stats[:, :, :c0])
         saved = []
-        if training and _dense_persistent_ok(x0, c0, growth, nl, params):
-            saved = _dense_block_forward_persistent(buf, stats, c0, nl, params, bufs, cfgs)
-            nl_loop = 0
-        else:
-            nl_loop = nl
+        nl_loop = nl
         # training on the GPU: BatchNorm coefficients are derived inside the consuming convolution (saunet_conv2d_forward_bnpro) -- two
         # launches per layer instead of four; the per-channel normalisation of the concat channels (xh rows: xs, xt, mean, invstd, var) is
         # published by the first kernel that needs it and reused by every later norm1
@@ -1635,17 +1521,10 @@ class _DenseBlock(torch.autograd.Function):
                        AB[1, lo:hi].data_ptr(), xh[0, lo:hi].data_ptr(), xh[1, lo:hi].data_ptr(), P, hi - lo, L.stream())
 
         grads = [None] * (6 * nl)
-        # SAUNET_DENSE_WGRAD_DEFER=1 (opt-in): the weight gradients of the whole block are issued AFTER its data-gradient chain, on
-        # the side stream -- two long independent branches with one fork / join per block, so the small launches of the low-resolution
-        # blocks overlap: 38.3 -> 36.9 ms/step in single-process eager mode.  Off by default: a captured graph replays its branches
-        # serially on this ROCm (no gain), and two ranks sharing one GPU (the gloo test rig) ran 6x SLOWER with the extra compute
-        # queue per process, which could not be re-checked against RCCL with one GPU per rank.
-        defer = buf.is_cuda and DENSE_WGRAD_DEFER == "1" and not torch.cuda.is_current_stream_capturing()
-        deferred = []
-        pend = [] if (buf.is_cuda and DENSE_WGRAD_BATCH_REDUCE and not WGRAD_SIDE.enabled) else None   # the 2 x L partial-gradient reductions: one launch
+        pend = [] if (buf.is_cuda and DENSE_WGRAD_BATCH_REDUCE) else None   # the 2 x L partial-gradient reductions: one launch
         # default: both weight gradients of every layer are deferred to the end of the block and issued as two GROUPED launches (every layer's
         # dz1 / corrected gradient chunk stays alive until then: 24 x 8 MB at block 3 -- nothing against 288 GB)
-        grouped = buf.is_cuda and DENSE_WGRAD_GROUPED and not defer and not WGRAD_SIDE.enabled
+        grouped = buf.is_cuda and DENSE_WGRAD_GROUPED
         wg1, wg2 = [], []
         for l in reversed(range(nl)):
             n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
@@ -1660,7 +1539,7 @@ class _DenseBlock(torch.autograd.Function):
             if grouped:
                 wg2.append((l, z1, dz2, c2w, (p2.scale, p2.shift)))
                 dw2 = None
-            elif not defer:
+            else:
                 dw2 = conv_wgrad_raw(z1, dz2, c2w, 1, 1, pro=(p2.scale, p2.shift, True), pending=pend)
             s2 = new_stats(z1.shape[1], dev)
             da2 = conv_dgrad_raw(dz2, c2w, z1.shape, 1, 1, bn_epi=(z1, p2, True, s2))
@@ -1668,11 +1547,8 @@ class _DenseBlock(torch.autograd.Function):
             if grouped:
                 wg1.append((l, xin, dz1, c1w, (p1.scale, p1.shift)))
                 dw1 = None
-            elif not defer:
-                dw1 = conv_wgrad_raw(xin, dz1, c1w, 1, 0, pro=(p1.scale, p1.shift, True), pending=pend)
             else:
-                dw1 = dw2 = None
-                deferred.append((l, z1, dz2, dz1, xin, p1, p2, c1w, c2w))
+                dw1 = conv_wgrad_raw(xin, dz1, c1w, 1, 0, pro=(p1.scale, p1.shift, True), pending=pend)
             s1 = new_stats(cin, dev)
             conv_dgrad_raw(dz1, c1w, (n, cin, h, w), 1, 0, out=dbuf[:, :cin], bn_epi=(xin, p1, True, s1, True))
             dgb = torch.empty(2, cin, dtype=torch.float32, device=dev)
@@ -1688,18 +1564,6 @@ class _DenseBlock(torch.autograd.Function):
                 L.call("saunet_bn_backward_coeff", cin, s1.data_ptr(), s1.shape[0], s1.stride(0), float(count), p1.scale.data_ptr(), AB[0].data_ptr(), AB[1].data_ptr(),
                        dgb[0].data_ptr(), dgb[1].data_ptr(), 1 if training else 0, L.stream())
             grads[6 * l:6 * l + 6] = [dgb[0], dgb[1], dw1, dg2, db2, dw2]
-        if defer:
-            main = torch.cuda.current_stream(dev)
-            side = WGRAD_SIDE.get(dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                for (l, z1, dz2, dz1, xin, p1, p2, c1w, c2w) in deferred:
-                    grads[6 * l + 5] = _conv_wgrad_impl(z1, dz2, c2w, 1, 1, pro=(p2.scale, p2.shift, True))
-                    grads[6 * l + 2] = _conv_wgrad_impl(xin, dz1, c1w, 1, 0, pro=(p1.scale, p1.shift, True))
-                    for t in (z1, dz1, grads[6 * l + 5], grads[6 * l + 2], p1.buf, p2.buf):
-                        t.record_stream(side)
-            buf.record_stream(side); dbuf.record_stream(side)
-            WGRAD_SIDE.mark()
         if grouped:
             for plist, slot, ks, pd in ((wg2, 5, 3, 1), (wg1, 2, 1, 0)):
                 dws = conv_wgrad_grouped([(x_, dy_, w_, pro_) for (_l, x_, dy_, w_, pro_) in plist], ks, pd, True)

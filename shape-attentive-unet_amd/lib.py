@@ -38,19 +38,6 @@ class PackList(C.Structure):
                 ("dst", C.c_void_p * 64)]
 
 
-DENSE_MAX_LAYERS = 24
-
-
-class DenseFwdLayer(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("w1 w2 gamma1 beta1 rmean1 rvar1 gamma2 beta2 rmean2 rvar2 z1 p1 p2 st2").split()] + \
-               [("st2_reps", C.c_int32), ("st2_rstride", C.c_int32), ("eps", C.c_float), ("momentum", C.c_float)]
-
-
-class DenseFwdDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in "dtype N H W c0 nl ldbuf stat_reps stat_rstride reserved".split()] + \
-               [("buf", C.c_void_p), ("stats", C.c_void_p), ("layer", DenseFwdLayer * DENSE_MAX_LAYERS)]
-
-
 WGRAD_REDUCE_MAX = 64
 
 
@@ -84,7 +71,6 @@ _SIGS = {
     "saunet_pack_weight": [i32, i32, vp, i32, i32, i32, i32, vp, vp],
     "saunet_pack_weight_multi": [C.POINTER(PackList), i32, vp],
     "saunet_conv2d_forward": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "saunet_dense_block_forward": [C.POINTER(DenseFwdDesc), vp, vp],
     "saunet_conv2d_forward_ex": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(BnEpilogue), vp],
     "saunet_conv2d_forward_bnpro": [C.POINTER(ConvDesc), vp, vp, vp, C.POINTER(BnPrologue), vp, vp, vp, vp],
     "saunet_bn_xhat": [i32, vp, vp, i32, i32, f64, f32, vp, i32, vp],

@@ -109,7 +109,6 @@ class _FusedBase(torch.optim.Optimizer):
         self.post_replay(-1)
 
     def _live(self, group):
-        HF.WGRAD_SIDE.join()      # weight gradients are produced on a side stream
         ps = [p for p in group["params"] if p.grad is not None]
         for p in ps:
             if not p.is_cuda:

@@ -73,94 +73,6 @@ def test_dense_block_fwd_bwd(dtype, tol, beta, layers, cin, shape):
         assert err(v.grad, prm[k].grad) < gtol, (k, err(v.grad, prm[k].grad))
 
 
-@pytest.mark.parametrize("layers,cin,shape", [(6, 256, (4, 32, 32)), (5, 512, (8, 16, 16)), (3, 64, (40, 16, 32))])
-def test_persistent_block_forward_matches_the_per_layer_launches(layers, cin, shape):
-    """csrc/dense_fwd.hip (one persistent launch with device-wide barriers for the whole block) against the per-layer launch sequence it
-    replaces, bf16 storage: concat buffer, its statistics, running statistics of every BatchNorm and all gradients.  Both paths round the same
-    tensors to bf16; they differ in the float32 summation order only (and in the ReLU masks that flips near zero), hence the tolerances.  The
-    abort word of the barrier workspace must stay clear and the root counter must have seen 2 barriers per layer."""
-    import saunet_amd as S
-    HF = S.functional
-    n, h, w = shape
-    torch.manual_seed(7 * layers + cin)
-    block = S.modules._DenseBlock(layers, cin).cuda().train()
-    with torch.no_grad():
-        for m in block.modules():
-            if isinstance(m, torch.nn.BatchNorm2d):
-                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
-    state0 = {k: v.clone() for k, v in block.state_dict().items()}
-    x0 = torch.randn(n, cin, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    cot = None
-    res = {}
-    saved_mode = HF.DENSE_PERSIST
-    try:
-        for mode in (True, False):
-            HF.DENSE_PERSIST = mode
-            HF.LAST_DENSE_SYNC = None
-            block.load_state_dict(state0)
-            HF.notify_params_changed()
-            block.zero_grad(set_to_none=True)
-            x = x0.clone().requires_grad_(True)
-            y = block(x)
-            if cot is None:
-                cot = torch.randn(y.shape, device="cuda").to(torch.bfloat16)
-            (y.float() * cot.float()).sum().backward()
-            torch.cuda.synchronize()
-            if mode:
-                assert HF.LAST_DENSE_SYNC is not None, "the persistent path did not run"
-                words = HF.LAST_DENSE_SYNC.cpu()
-                assert int(words[1]) == 0, "a device-wide barrier expired"
-                assert int(words[32 * 17]) > 0 and int(words[32 * 17]) % (2 * layers) == 0, int(words[32 * 17])      # root counter: groups x barriers
-            else:
-                assert HF.LAST_DENSE_SYNC is None
-            res[mode] = (y.detach().float().clone(), x.grad.float().clone(), {k: v.grad.float().clone() for k, v in block.named_parameters()},
-                         {k: v.float().clone() for k, v in block.state_dict().items() if "running" in k})
-    finally:
-        HF.DENSE_PERSIST = saved_mode
-    (ya, dxa, ga, ra), (yb, dxb, gb, rb) = res[True], res[False]
-    assert rel(ya, yb) < 2e-2, rel(ya, yb)
-    assert rel_l2(ya, yb) < 3e-3, rel_l2(ya, yb)
-    for k in ra:
-        assert rel(ra[k], rb[k]) < 2e-3, (k, rel(ra[k], rb[k]))
-    assert rel_l2(dxa, dxb) < 0.1, rel_l2(dxa, dxb)
-    for k in ga:
-        assert rel_l2(ga[k], gb[k]) < 0.1, (k, rel_l2(ga[k], gb[k]))
-
-
-def test_whole_network_with_the_persistent_block_forward():
-    """SAUNet forward + backward in bf16 storage with the opt-in persistent dense-block forward against the default per-layer launches: same
-    loss to bf16 noise, every parameter gradient strongly aligned (the two paths round the same tensors; they differ in summation order and in
-    the ReLU masks that flips near zero), abort word clear."""
-    import saunet_amd as S
-    from oracle import saunet_ref as R, weights as Wt
-    HF = S.functional
-    S.set_compute_dtype(torch.bfloat16)
-    sd = Wt.make_state_dict(R.state_dict_spec(), 21)
-    img, seg, edge = Wt.synthetic_batch(2, 128, 128, seed=77)
-    feed = {"image": img.cuda(), "mask": (seg.cuda(), edge.cuda())}
-    saved, out = HF.DENSE_PERSIST, {}
-    try:
-        for mode in (False, True):
-            HF.DENSE_PERSIST = mode
-            HF.LAST_DENSE_SYNC = None
-            net = S.SAUNet(num_classes=4).cuda()
-            net.load_state_dict(sd, strict=False); HF.notify_params_changed()
-            sm = S.SegmentationModule(S.DualLoss(mode="train"), net, 4).train()
-            loss, _ = sm(feed, 1)
-            loss.backward(); torch.cuda.synchronize()
-            if mode:
-                assert HF.LAST_DENSE_SYNC is not None and int(HF.LAST_DENSE_SYNC.cpu()[1]) == 0
-            out[mode] = (float(loss), {k: v.grad.float().clone() for k, v in net.named_parameters() if v.grad is not None})
-    finally:
-        HF.DENSE_PERSIST = saved
-        S.set_compute_dtype(torch.float32)
-    (la, ga), (lb, gb) = out[False], out[True]
-    assert abs(la - lb) < 2e-2 * abs(la), (la, lb)
-    num = sum(float((ga[k] * gb[k]).sum()) for k in ga)
-    den = (sum(float(ga[k].pow(2).sum()) for k in ga) * sum(float(gb[k].pow(2).sum()) for k in gb)) ** 0.5
-    assert num / den > 0.98, num / den
-
-
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("ksize,shape,chans", [(1, (4, 16, 16), [(64, 128), (96, 128), (160, 128), (288, 128)]),      # conv1 of a block: growing Cin
                                                (3, (4, 32, 32), [(128, 32)] * 5),                                      # conv2 of a block
