@@ -45,11 +45,19 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi)
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
 }
 
+struct f32s { float v; };                     // float32 storage whose matrix products run as 3 x bf16 splits (see mma_f32_chunk_split below)
+constexpr long SAUNET_F32_SPLIT_MINPIX = 16384;
+inline bool f32_split_wanted(long pixels) { return pixels >= SAUNET_F32_SPLIT_MINPIX; }
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int dtype = SAUNET_F32;
     __device__ static __forceinline__ float load(const float* p) { return *p; }
     __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct Elem<f32s> {
+    static constexpr int dtype = SAUNET_F32;
+    __device__ static __forceinline__ float load(const f32s* p) { return p->v; }
+    __device__ static __forceinline__ void store(f32s* p, float v) { p->v = v; }
 };
 template <> struct Elem<u16> {  // bf16 stored as raw 16-bit words
     static constexpr int dtype = SAUNET_BF16;
@@ -64,10 +72,13 @@ template <> struct Elem<u16> {  // bf16 stored as raw 16-bit words
 // hh, hm, mh, mm, hl, lh (what is dropped is below 2^-24 of |a||b|: float32 round-off class) one K = 8 step of the float path -- a lane
 // holds 4 floats of each operand -- is THREE mfma_f32_32x32x16_bf16 instead of four mfma_f32_32x32x2_f32: the 16 K slots of a bf16 MFMA
 // carry two product kinds at once (slots 0-3 / 4-7 of each lane half).  96 instead of 256 matrix-pipe cycles; the splits are VALU work
-// that runs beside the MFMAs and is shared by all tiles a fragment feeds.  SAUNET_F32_SPLIT=0 (compile time) restores the exact-f32 MFMA.
-#ifndef SAUNET_F32_SPLIT
-#define SAUNET_F32_SPLIT 1
-#endif
+// that runs beside the MFMAs and is shared by all tiles a fragment feeds.
+// The split result has the same rms error against float64 as the exact MFMA (scripts/f32_accuracy.py: 1.0e-6 vs 1.2e-6 of the output scale at
+// K = 4608) but a small same-signed bias (-2e-7: the bf16 MFMA's adder does not round its addends to nearest), and on launches with a few
+// hundred pixels per channel -- where BatchNorm amplifies float32 noise a thousand-fold -- that cost parity margin (smoke() at 64 x 64: gradient
+// error 3.4e-4 -> 8.4e-4 of scale; the two-rank SGD test's second loss 0.24 % off).  Those launches are latency-bound anyway, so the kernels
+// are instantiated for BOTH element tags: `float` = exact f32 MFMA, `f32s` = split, and the dispatchers take `f32s` from
+// SAUNET_F32_SPLIT_MINPIX pixels per launch upwards (f32_split_wanted).
 struct F32Split { unsigned h01, h23, m01, m23, l01, l23; };
 // round-to-nearest splits (v_cvt_pk_bf16_f32): x = h + m + l + e with |e| <= 2^-27 |x| and NO bias -- truncation splits (and / perm) cost the
 // same number of VALU operations but drop a same-signed remainder from every product, which a K = 10^4 reduction turns into a relative error
@@ -86,9 +97,8 @@ __device__ __forceinline__ F32Split f32_split3(const u32x4& v)
     return s;
 }
 // c += A * B for one 16-byte chunk pair of float32 fragments (K = 8: 4 floats per lane and half)
-__device__ __forceinline__ void mma_f32_chunk(const u32x4& a, const u32x4& b, f32x16& c)
+__device__ __forceinline__ void mma_f32_chunk_split(const u32x4& a, const u32x4& b, f32x16& c)
 {
-#if SAUNET_F32_SPLIT
     const F32Split A = f32_split3(a), B = f32_split3(b);
     const u32x4 a3 = {A.h01, A.h23, A.l01, A.l23}, b3 = {B.l01, B.l23, B.h01, B.h23};     // h*l + l*h   (smallest terms first)
     const u32x4 a2 = {A.m01, A.m23, A.m01, A.m23}, b12 = {B.h01, B.h23, B.m01, B.m23};    // m*h + m*m
@@ -96,10 +106,11 @@ __device__ __forceinline__ void mma_f32_chunk(const u32x4& a, const u32x4& b, f3
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a3), __builtin_bit_cast(bf16x8_t, b3), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a2), __builtin_bit_cast(bf16x8_t, b12), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1), __builtin_bit_cast(bf16x8_t, b12), c, 0, 0, 0);
-#else
+}
+__device__ __forceinline__ void mma_f32_chunk_exact(const u32x4& a, const u32x4& b, f32x16& c)
+{
 #pragma unroll
     for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
-#endif
 }
 
 // 16-byte vector of T as floats: 4 f32 or 8 bf16
@@ -119,6 +130,7 @@ template <> struct Vec16<float> {
         return v;
     }
 };
+template <> struct Vec16<f32s> : Vec16<float> {};
 template <> struct Vec16<u16> {
     static constexpr int N = 8;
     __device__ static __forceinline__ void unpack(const u32x4& v, float* f)

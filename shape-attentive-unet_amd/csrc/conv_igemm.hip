@@ -40,10 +40,10 @@ template <> struct Mma<u16> {
     }
 };
 template <> struct Mma<float> {
-    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c)
-    {
-        mma_f32_chunk(a, b, c);
-    }
+    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) { mma_f32_chunk_exact(a, b, c); }
+};
+template <> struct Mma<f32s> {
+    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) { mma_f32_chunk_split(a, b, c); }
 };
 
 // byte offset of 16-byte chunk `c` of row `r` in a [rows][CPR] chunk image, XOR-swizzled so that
@@ -440,6 +440,7 @@ int igemm_forward(const saunet_conv_desc* d, const void* x, const void* w, const
         return dispatch_fwd<u16>(a, phases, st);
     } else if (d->dtype == SAUNET_F32) {
         a.kpt = cdiv(d->Cin, (d->Cin <= 16) ? 16 : 32);
+        if (f32_split_wanted((long)a.M)) return dispatch_fwd<f32s>(a, phases, st);
         return dispatch_fwd<float>(a, phases, st);
     }
     return set_error(SAUNET_BAD_DTYPE, "conv: dtype %d", d->dtype);

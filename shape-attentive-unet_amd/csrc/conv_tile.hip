@@ -35,10 +35,10 @@ template <> struct MmaT<u16> {
     }
 };
 template <> struct MmaT<float> {
-    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c)
-    {
-        mma_f32_chunk(a, b, c);
-    }
+    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) { mma_f32_chunk_exact(a, b, c); }
+};
+template <> struct MmaT<f32s> {
+    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) { mma_f32_chunk_split(a, b, c); }
 };
 
 template <int CPR> __device__ __forceinline__ int swz_off(int r, int c)
@@ -811,6 +811,7 @@ int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const 
         return SAUNET_OK;
     };
     if (d->dtype == SAUNET_BF16) { int rc = dispatch_res_fwd<u16>(a, st, &handled); if (handled) return rc; if ((rc = unfuse())) return rc; return dispatch_tile_fwd<u16>(a, st); }
+    if (d->dtype == SAUNET_F32 && f32_split_wanted((long)d->N * d->H * d->W)) { int rc = dispatch_res_fwd<f32s>(a, st, &handled); if (handled) return rc; if ((rc = unfuse())) return rc; return dispatch_tile_fwd<f32s>(a, st); }
     if (d->dtype == SAUNET_F32) { int rc = dispatch_res_fwd<float>(a, st, &handled); if (handled) return rc; if ((rc = unfuse())) return rc; return dispatch_tile_fwd<float>(a, st); }
     return set_error(SAUNET_BAD_DTYPE, "conv: dtype %d", d->dtype);
 }
