@@ -131,6 +131,43 @@ def kernel_roofline(S, dtype, batch, size, launch_mix=True):
     return out
 
 
+def weakest_family_roofline(S, dtype, batch, size):
+    """Second roofline entry: the WEAKEST large kernel family of the step next to the healthiest one -- the tiled 3x3 weight
+    gradient of the MFMA-bound decoder convolutions (conv_tile_wgrad_kernel<bf16, 3, 8, 64, 64, 32, 32, 1>: 17-24 % of the matrix-core peak;
+    bound by its transposing LDS fragment reads, one fresh fragment per MFMA).  Probe: dec3.c3x3rb (512 -> 128 at (size/4)^2), timed live with
+    HIP events; FLOPs 2 * P * 9 * Cin * Cout, arithmetic intensity far above the ridge, so it is priced against the MFMA peak.  Also the
+    LDS-DMA forward kernel of the same layer (conv3x3_mm_kernel) for comparison."""
+    HF = S.functional
+    h = size // 4
+    cin, cout = 512, 128
+    x = torch.randn(batch, cin, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(batch, cout, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device="cuda") * 0.03)
+    out = HF.new_act(batch, cout, h, h, dtype, "cuda")
+    st = torch.zeros(HF.STAT_R, 2, cout, dtype=torch.float64, device="cuda")
+    fl = 2.0 * batch * h * h * 9 * cin * cout
+    peak = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
+
+    def timed(fn, reps=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    ms_w = timed(lambda: (HF.GRADS.reset(), HF.conv_wgrad_raw(x, dy, w, 1, 1)))
+    ms_f = timed(lambda: HF.conv_forward_raw(x, w, None, 1, 1, out=out, stats=st))
+    HF.GRADS.reset()
+    tf_w, tf_f = fl / (ms_w * 1e-3) / 1e12, fl / (ms_f * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(tf_w, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf_w / peak, 4), "ms": round(ms_w, 4),
+            "kernel": "conv_tile_wgrad 3x3 %d->%d @%dx%d B%d (dec3.c3x3rb weight gradient, incl. its partial-gradient reduce)" % (cin, cout, h, h, batch),
+            "flops": fl, "same_layer_forward": {"kernel": "conv3x3_mm_kernel (LDS-DMA staged)", "ms": round(ms_f, 4), "achieved": round(tf_f, 1),
+                                               "frac": round(tf_f / peak, 4)}}
+
+
 def step_roofline(args, ms_per_step):
     """Whole-step roofline against SURVEY 8(d)'s ideal-fusion algorithmic bytes (1.086 GB per 256x256 slice in bf16, 2.171 GB in float32:
     every conv reads its input once and writes its output once, forward + backward) and the measured HBM traffic of the committed
@@ -608,6 +645,8 @@ def main():
                 out["roofline"] = kernel_roofline(S, dtype, args.batch, args.size, launch_mix=not args.no_launch_mix)
                 out["roofline"]["traffic"] = pmc_traffic(out["roofline"]["kernel"])
                 out["roofline"]["step"] = step_roofline(args, ms)     # per-GPU step: weak scaling, every rank does this work
+                if rank == 0:
+                    out["roofline"]["weakest_large_family"] = weakest_family_roofline(S, dtype, args.batch, args.size)
             except Exception as e:
                 out["roofline"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_extras:
