@@ -421,3 +421,35 @@ def test_conv_transpose_weight_packings(dtype, shape):
         out = torch.full((w.numel(),), float("nan"), dtype=dtype, device="cuda")
         L.call("saunet_pack_weight", mode, L.BF16 if dtype == torch.bfloat16 else L.F32, w.data_ptr(), co, ci, 4, 4, out.data_ptr(), L.stream())
         assert torch.equal(out, ref.contiguous().reshape(-1).to(dtype)), (mode, shape)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_multi_tensor_packing_matches_torch_permutes(dtype):
+    """saunet_pack_weight_multi (LDS-tiled since round 4): all four packings, 1x1 / 3x3 / 4x4 / 7x7 / 5x5 (generic path) kernels, channel counts
+    that are not multiples of the tile, against the permutations written with torch; bit-exact (a packing is a rounding + a permutation)."""
+    import ctypes as C
+    from saunet_amd import lib as L
+    cases = []                                   # (mode, weight, reference)
+    for co, ci, k in ((128, 160, 1), (37, 70, 1), (32, 128, 3), (72, 40, 3), (512, 96, 3), (64, 8, 7), (10, 6, 5)):
+        w = rnd(co, ci, k, k, seed=k).cuda()
+        cases.append((L.PACK_FWD, w, w.permute(0, 2, 3, 1), (co, ci, k, k)))
+        cases.append((L.PACK_DGRAD, w, w.flip(2, 3).permute(1, 2, 3, 0), (co, ci, k, k)))
+    for ci, co in ((48, 32), (128, 128), (20, 70)):
+        w = rnd(ci, co, 4, 4, seed=9).cuda()
+        v = w.view(ci, co, 2, 2, 2, 2)
+        cases.append((L.PACK_CONVT_FWD, w, v.flip(3, 5).permute(3, 5, 1, 2, 4, 0), (co, ci, 4, 4)))
+        cases.append((L.PACK_CONVT_DGRAD, w, w.permute(0, 2, 3, 1), (co, ci, 4, 4)))
+    pl = L.PackList()
+    pl.count = len(cases)
+    outs = []
+    for i, (mode, w, ref, dims) in enumerate(cases):
+        out = torch.full((w.numel(),), float("nan"), dtype=dtype, device="cuda")
+        pl.mode[i] = mode
+        for j in range(4):
+            pl.dims[i][j] = dims[j]
+        pl.src[i] = w.data_ptr(); pl.dst[i] = out.data_ptr()
+        outs.append(out)
+    L.call("saunet_pack_weight_multi", C.byref(pl), L.BF16 if dtype == torch.bfloat16 else L.F32, L.stream())
+    torch.cuda.synchronize()
+    for (mode, w, ref, dims), out in zip(cases, outs):
+        assert torch.equal(out, ref.contiguous().reshape(-1).to(dtype)), (mode, dims)
