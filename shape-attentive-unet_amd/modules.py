@@ -285,16 +285,21 @@ class _DenseBlock(nn.ModuleDict):
         buf, stats = HF.dense_block(x, list(self.values()), self.training)
         return (buf, stats) if with_stats else buf
 
+    def total_channels(self):
+        """channels of the block's concat buffer (input + growth * layers): what its producer may reserve (HF.reserve_dense_input)"""
+        first = next(iter(self.values()))
+        return first.norm1.num_features + sum(l.conv2.out_channels for l in self.values())
+
 
 class _Transition(nn.Sequential):
     def __init__(self, cin, cout):
         super().__init__(OrderedDict([("norm", nn.BatchNorm2d(cin)), ("relu", nn.ReLU(inplace=True)),
                                       ("conv", nn.Conv2d(cin, cout, 1, bias=False)), ("pool", nn.AvgPool2d(2, 2))]))
 
-    def forward(self, x, stats=None):
+    def forward(self, x, stats=None, reserve=0):
         if stats is None and self.training:
             stats = HF.bn_stats(x)
-        return HF.transition(x, stats, self, self.training)
+        return HF.transition(x, stats, self, self.training, reserve)
 
 
 class DenseNet121(nn.Module):
@@ -334,13 +339,18 @@ class _Stem(nn.Sequential):
     channels (16-byte chunks), lowered by im2col to a [P, 7*7*8] matrix and multiplied on the 1x1 MFMA kernels
     (forward and weight gradient; the image needs no input gradient)."""
 
-    def forward(self, x):
+    def forward(self, x, reserve=0):
+        """reserve: total channels of the dense block that consumes the result -- the output is then written as the first channel slice of
+        that block's concat buffer (HF.reserve_dense_input) instead of being copied into it"""
         conv, bn = self[0], self[1]
         co, ci, kh, kw = conv.weight.shape
         w8 = torch.nn.functional.pad(conv.weight, (0, 0, 0, 0, 0, 8 - ci))                 # [64, 8, 7, 7]
         wk = w8.permute(0, 2, 3, 1).reshape(co, kh * kw * 8, 1, 1)                          # K order (kh, kw, c)
         cols = HF.im2col(x, kh, kw, conv.stride[0], conv.padding[0])
-        return HF.conv_bn_act(cols, wk, None, bn, relu=False)
+        out = None
+        if reserve and reserve > co and x.is_cuda:
+            out = HF.reserve_dense_input(cols.shape[0], co, cols.shape[2], cols.shape[3], reserve, cols.dtype, cols.device)
+        return HF.conv_bn_act(cols, wk, None, bn, relu=False, out=out)
 
 
 class _Tail(nn.Sequential):
@@ -444,10 +454,11 @@ class SAUNet(nn.Module):
         cat2 = HF.new_act(n, 128 + 128, 8 * h16, 8 * w16, dt, dev)
         nf = self.final.in_channels
         cat0 = HF.new_act(n, 2 * nf, size[0], size[1], dt, dev)
-        conv1 = self.conv1(self._prep_input(x))
-        buf, st = self.conv2(conv1, with_stats=True); conv2 = self.conv2t(buf, st)
-        buf, st = self.conv3(conv2, with_stats=True); conv3 = self.conv3t(buf, st)
-        buf, st = self.conv4(conv3, with_stats=True); conv4 = self.conv4t(buf, st)
+        grad = torch.is_grad_enabled() or self.training            # (the inference block builds its own buffer)
+        conv1 = self.conv1(self._prep_input(x), reserve=self.conv2.total_channels() if grad else 0)
+        buf, st = self.conv2(conv1, with_stats=True); conv2 = self.conv2t(buf, st, reserve=self.conv3.total_channels() if grad else 0)
+        buf, st = self.conv3(conv2, with_stats=True); conv3 = self.conv3t(buf, st, reserve=self.conv4.total_channels() if grad else 0)
+        buf, st = self.conv4(conv3, with_stats=True); conv4 = self.conv4t(buf, st, reserve=self.conv5[0].total_channels() if grad else 0)
         conv5 = self.conv5(conv4, out=cat5[:, :1024])
 
         def conv(m, t):
