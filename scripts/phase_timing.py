@@ -24,6 +24,9 @@ elif case in ("dec4convtwgrad", "dec2convtwgrad"):
     ci, h = {"dec4convtwgrad": (512, 16), "dec2convtwgrad": (128, 64)}[case]
     x = act(ci, h); dy = act(ci, 2 * h); w = torch.nn.Parameter(torch.randn(ci, ci, 4, 4, device="cuda") * 0.03)
     run = lambda: (HF.GRADS.reset(), HF.conv_wgrad_raw(x, dy, w, 2, 1, transposed=True))
+elif case in ("dec3wgradmm",):
+    x = act(512, 64); dy = act(128, 64); w = torch.nn.Parameter(torch.randn(128, 512, 3, 3, device="cuda") * 0.03)
+    run = lambda: (HF.GRADS.reset(), HF.conv_wgrad_raw(x, dy, w, 1, 1))
 elif case in ("dec3mm", "dec5mm", "dec4mm", "dec2mm"):
     unit = "conv_mm"
     cin, h, cout = {"dec3mm": (512, 64, 128), "dec5mm": (1536, 16, 512), "dec4mm": (1024, 32, 256), "dec2mm": (256, 128, 64)}[case]

@@ -249,6 +249,23 @@ template <int NT> __device__ __forceinline__ void bn_prologue_fill(const saunet_
     }
 }
 
+// ---- LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land lane-linear at the LDS address in M0) and the counted waits that go with it.
+// Inline asm: hipcc neither counts these requests nor waits for them -- the kernels do, with vmcnt(N) + s_barrier (cdna guide 5.7).
+__device__ __forceinline__ void mm_dma16(const void* gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void mm_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
+__device__ __forceinline__ void mm_barrier()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+
 // ---- phase timing (profiling builds only: python -m saunet_amd._build --timing -> scripts/_ab/libsaunet_timing.so) -------------------
 // TSTAMP(slot) records (slot, s_memtime) from thread 0 of ONE block into a per-translation-unit device array that
 // saunet_debug_timing_<unit>() copies out; scripts/phase_timing.py prints the per-phase cycle deltas.  This is how the serialised

@@ -36,20 +36,6 @@ constexpr int MM_HALO_BYTES = MM_HALO_INSTR * 1024;         // 41 984
 constexpr int MM_HALO_PER_WAVE = 6;                         // 8 waves x 6 slots >= 41 (surplus slots go to the dummy region)
 constexpr int MM_RING = 4;
 
-__device__ __forceinline__ void mm_dma16(const void* gsrc, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-template <int N> __device__ __forceinline__ void mm_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
-__device__ __forceinline__ void mm_barrier()
-{
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
 // Where a stage's DMA requests are issued matters (round-4 phase stamps, profiles/r04_mm_kernel_notes.txt): one request blocks ITS wave for
 // ~110 cycles (the CU's memory front end accepts one about every 30 cycles from all waves together), so with all eight waves requesting right
 // behind the barrier every matrix pipe idled 330-700 cycles per stage.  Each wave now issues one request behind each of the first three

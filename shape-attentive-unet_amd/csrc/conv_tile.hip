@@ -1110,6 +1110,36 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
                 }
             }
         };
+        // 3x3, bf16, one wave per 32 x 32 channel tile holding all nine taps (ROLL): the x fragments of a halo row serve THREE consecutive tile rows
+        // (as kh = 2, 1, 0) and the kw = 1 fragment is the kw = 0 one shifted by a pixel -- lane (channel, k half) holds 8 consecutive pixels, so
+        // columns 1..8 are elements 1..7 of the kw = 0 fragment plus element 6 of the kw = 2 fragment (columns 2..9) of the SAME lane: three
+        // v_alignbit and one more, no LDS.  Per tile row the loop reads the dy fragment and TWO x fragments (kw = 0, 2 of halo row ty + 2) instead
+        // of nine: the transposing reads (one fresh 1 KB fragment per MFMA, 75 B/clk per CU) capped this loop at half the matrix-core rate.
+        constexpr bool ROLL = KS == 3 && sizeof(T) == 2 && !TS && KSP == 1 && MI == 1 && NI == 1 && TR <= 8;
+        if constexpr (ROLL) {
+            const int lx = (8 * khalf + (li >> 2)) * PX + (wn0 + 16 * nhalf + 4 * (li & 3)) * 2;
+            auto load_row = [&](int hy, u32x4* f) {          // f[0], f[2] from LDS, f[1] derived
+                const unsigned char* base = s_x + hy * HC * PX + lx;
+                tr_read2(base, 4 * PX, f[0]);
+                tr_read2(base + 2 * PX, 4 * PX, f[2]);
+                f[1][0] = __builtin_amdgcn_alignbit(f[0][1], f[0][0], 16); f[1][1] = __builtin_amdgcn_alignbit(f[0][2], f[0][1], 16);
+                f[1][2] = __builtin_amdgcn_alignbit(f[0][3], f[0][2], 16); f[1][3] = __builtin_amdgcn_alignbit(f[2][3], f[0][3], 16);
+            };
+            u32x4 rows[3][3];
+            load_row(0, rows[0]); load_row(1, rows[1]);
+#pragma unroll
+            for (int ty = 0; ty < TR; ++ty) {
+                load_row(ty + 2, rows[(ty + 2) % 3]);
+                u32x4 af;
+                tr_read2(s_y + (ty * TILE + 8 * khalf + (li >> 2)) * PY + (wm0 + 16 * nhalf + 4 * (li & 3)) * 2, 4 * PY, af);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        acc[0][0][kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, rows[(ty + kh) % 3][kw]),
+                                                                                       acc[0][0][kh * 3 + kw], 0, 0, 0);
+            }
+        } else
         if constexpr (KS == 2) {       // two tile rows per iteration: the second row's fragment reads are in flight behind the first row's MFMAs
             static_assert(KS != 2 || (KSP == 1 && TR % 2 == 0), "conv-transpose variant: unsplit K, even tile rows");
             for (int ty = 0; ty < TR; ty += 2) { k_step(ty); k_step(ty + 1); }
@@ -1276,6 +1306,212 @@ template <typename T> static int dispatch_tile_wgrad(TileWgradArgs& a, int ks, b
         }
         return launch_tile_wgrad<T, 1, 8, 64, 64, 32, 32, 1>(a, wsb, need, st);
     }
+}
+
+
+// =====================================================================================================
+// conv3x3_wgrad_mm_kernel: weight gradient of the 3x3 convolutions whose input needs no prologue and has Cin % 128 == 0, Cout % 64 == 0 (the
+// decoder's c3x3rb, models/attention_blocks.py:215-220) -- the tiled kernel above spent 57 % of a pixel tile's time staging it (global ->
+// registers -> LDS, synchronously; profiles/r03_phase_timing_raw.txt dec3wgrad) and half of the rest waiting for transposing fragment reads.
+//   * 8 waves = 2 (output channels) x 4 (input channels) tiles of 32 x 32 channels x 9 taps; channel tile 64 x 128 per workgroup;
+//   * pixel tile 8 rows x 16 columns; dy tile (16 KB) and x halo (10 x 18 pixels, 45 KB) arrive by LDS-DMA into one of TWO buffers: the next
+//     tile's 61 requests are issued (two per wave behind each of the first four tile rows) while the matrix cores work on this one;
+//     ONE barrier per tile, vmcnt(0) in front of it (nothing else is ever outstanding);
+//   * the 64-byte segments of a pixel row are XOR-swizzled by the pixel's column (source address + fragment address), which puts the four pixel
+//     rows of a transposing read on disjoint banks without padding (the DMA destination is lane-linear: no pad possible);
+//   * the K loop is the rolling-row loop of tile_wgrad_body: one dy fragment + two x fragments read per tile row, the other seven x fragments
+//     are the previous rows' and a one-pixel register shift.
+struct WgradMmArgs {
+    const u16* x; const u16* dy; float* ws;
+    int N, H, W, Cin, ldx, Cout, lddy, tiles_x, tiles_y, ntiles, ncit;
+    long wsize;
+};
+static __device__ u32x4 g_wg_zeros[4];
+
+constexpr int WM_DYB = 128 * 128, WM_XPIX = 10 * 18, WM_XB = WM_XPIX * 256, WM_BUF = WM_DYB + WM_XB;      // 16384 + 46080 = 62464
+constexpr int WM_PIECES = 16 + WM_XPIX / 4;                                                               // 61
+
+__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mm_kernel(WgradMmArgs a)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4, nhalf = lg & 1, khalf = lg >> 1;
+    const int wm0 = (wave & 1) * 32, wn0 = (wave >> 1) * 32;
+    const int gx = blockIdx.x, ngroups = gridDim.x;
+    const int cot = blockIdx.y / a.ncit, cit = blockIdx.y - cot * a.ncit;
+    const int co0 = cot * 64, ci0 = cit * 128;
+    const unsigned char* zsrc = (const unsigned char*)g_wg_zeros;
+
+    // ---- DMA slots of this wave: piece id = j * 8 + wave; 0..15 = dy (8 pixels x 128 B), 16..60 = x halo (4 pixels x 256 B), 61..63 = nothing
+    int prel[8];            // byte offset of this lane's 16 bytes relative to the tile origin of its operand
+    int phy[8], phx[8];     // x pieces: halo coordinates (for the border test)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int id = j * 8 + wave;
+        if (id < 16) {
+            const int pix = id * 8 + (lane >> 3), sl = lane & 7, row = pix >> 4, col = pix & 15;
+            const int ch = sl ^ (((col >> 1) & 1) << 2);
+            prel[j] = ((row * a.W + col) * a.lddy + co0 + ch * 8) * 2; phy[j] = 1; phx[j] = 1;
+        } else {
+            const int hp = (id - 16) * 4 + (lane >> 4), sl = lane & 15;
+            const int hy = hp / 18, hx = hp - hy * 18;
+            const int ch = sl ^ ((hx & 3) << 2);
+            prel[j] = (((hy - 1) * a.W + (hx - 1)) * a.ldx + ci0 + ch * 8) * 2; phy[j] = hy; phx[j] = hx;
+        }
+    }
+    // per tile: origin pointers and the border tests are wave-uniform / cheap; the decode of the tile index (two runtime divisions) is done ONCE
+    struct TileOrg { const unsigned char* xb; const unsigned char* yb; int ty0, tx0; };
+    auto origin = [&](int tile) {
+        int bt = tile;
+        const int txi = bt % a.tiles_x; bt /= a.tiles_x;
+        const int tyi = bt % a.tiles_y; const int n = bt / a.tiles_y;
+        TileOrg o;
+        o.ty0 = tyi * 8; o.tx0 = txi * 16;
+        o.yb = (const unsigned char*)a.dy + (((size_t)n * a.H + o.ty0) * a.W + o.tx0) * a.lddy * 2;
+        o.xb = (const unsigned char*)a.x + (((long)n * a.H + o.ty0) * a.W + o.tx0) * a.ldx * 2;
+        return o;
+    };
+    auto issue = [&](int j, const TileOrg& o, int buf) {
+        const int id = j * 8 + wave;
+        if (id >= WM_PIECES) return;                                    // wave-uniform
+        const unsigned char* src;
+        if (id < 16) src = o.yb + prel[j];
+        else {
+            const bool ok = (unsigned)(o.ty0 + phy[j] - 1) < (unsigned)a.H && (unsigned)(o.tx0 + phx[j] - 1) < (unsigned)a.W;
+            src = ok ? o.xb + prel[j] : zsrc + (lane & 3) * 16;
+        }
+        mm_dma16(src, lds0 + buf * WM_BUF + id * 1024);
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // fragment addresses inside a buffer (lo part; the hi part is 4 pixels further: same swizzle key)
+    const int prow = 8 * khalf + (li >> 2);                              // pixel (column) of the lo part
+    const int ab = (wm0 + 16 * nhalf + 4 * (li & 3)) * 2, bb = (wn0 + 16 * nhalf + 4 * (li & 3)) * 2;
+    const int a_off = prow * 128 + (ab ^ ((((prow >> 1) & 1)) << 6));                                   // + ty * 16 * 128
+    const int b0_off = WM_DYB + prow * 256 + (bb ^ ((prow & 3) << 6));                                  // + hy * 18 * 256   (kw = 0)
+    const int b2_off = WM_DYB + (prow + 2) * 256 + (bb ^ (((prow + 2) & 3) << 6));                      // (kw = 2)
+
+    TSTAMP_INIT();
+    TSTAMP(80);
+    int tile = gx;
+    if (tile < a.ntiles) {
+        const TileOrg o = origin(tile);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) issue(j, o, 0);
+    }
+    // the two waves of a SIMD (w, w + 4) request in ANTI-PHASE: one behind tile rows 0, 2, 4, the other behind rows 1, 3, 5 -- a request blocks its
+    // wave ~100 cycles and the CU accepts one per ~40, so eight waves requesting at once stall every matrix pipe for the whole burst
+    const int phase = wave >> 2;
+    int buf = 0;
+    for (; tile < a.ntiles; tile += ngroups, buf ^= 1) {
+        TSTAMP(81);
+        mm_wait_vm<0>();
+        TSTAMP(82);
+        mm_barrier();                  // this tile has landed (every wave waited for its own requests); everybody is done with the other buffer
+        const unsigned char* sb = smem + buf * WM_BUF;
+        const int nxt = tile + ngroups;
+        TileOrg on;
+        if (nxt < a.ntiles) on = origin(nxt);
+        auto load_row = [&](int hy, u32x4* f) {
+            tr_read2(sb + b0_off + hy * (18 * 256), 4 * 256, f[0]);
+            tr_read2(sb + b2_off + hy * (18 * 256), 4 * 256, f[2]);
+            f[1][0] = __builtin_amdgcn_alignbit(f[0][1], f[0][0], 16); f[1][1] = __builtin_amdgcn_alignbit(f[0][2], f[0][1], 16);
+            f[1][2] = __builtin_amdgcn_alignbit(f[0][3], f[0][2], 16); f[1][3] = __builtin_amdgcn_alignbit(f[2][3], f[0][3], 16);
+        };
+        TSTAMP(83);
+        u32x4 rows[3][3];
+        load_row(0, rows[0]); load_row(1, rows[1]);
+#pragma unroll
+        for (int ty = 0; ty < 8; ++ty) {
+            if (ty == 4) TSTAMP(84);
+            load_row(ty + 2, rows[(ty + 2) % 3]);
+            u32x4 af;
+            tr_read2(sb + a_off + ty * (16 * 128), 4 * 128, af);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, rows[(ty + kh) % 3][kw]),
+                                                                             acc[kh * 3 + kw], 0, 0, 0);
+            if (ty < 6 && (ty & 1) == phase && nxt < a.ntiles) {
+                constexpr int first[3] = {0, 3, 6};
+                const int k = ty >> 1;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (first[k] + j < 8) issue(first[k] + j, on, buf ^ 1);
+            }
+        }
+    }
+    TSTAMP(85);
+    // ---- partial gradient of this pixel group: ws[gx][tap][co][ci]
+    const int lr = lane & 31, lh = lane >> 5;
+    const int ci = ci0 + wn0 + lr;
+    float* wsg = a.ws + (size_t)gx * a.wsize;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            wsg[((size_t)t * a.Cout + co) * a.Cin + ci] = acc[t][r];       // [tap][co][ci]: a wave row = 128 contiguous bytes (the reduce kernel permutes)
+        }
+    TSTAMP(86);
+}
+
+// dw[co][ci][tap] += sum_g ws[g][tap][co][ci]: reads in workspace order (coalesced, the bulk), writes the 9-strided parameter layout
+__global__ __launch_bounds__(256) void wgrad_reduce_tco_kernel(const float* __restrict__ ws, long wsize, int groups, int cc, float* __restrict__ dw)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < wsize; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        int g = 0;
+        for (; g + 8 <= groups; g += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(g + u) * wsize + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; g < groups; ++g) s += ws[(size_t)g * wsize + i];
+        const long t = i / cc, r = i - t * cc;          // cc = Cout * Cin
+        dw[r * 9 + t] += s;
+    }
+}
+
+bool wgrad_mm_supported(const TileWgradArgs& a, int ks, int dtype, bool aligned)
+{
+    static const bool on = !(getenv("SAUNET_WGRAD_MM") && getenv("SAUNET_WGRAD_MM")[0] == '0');                // A/B switch
+    return on && aligned && dtype == SAUNET_BF16 && ks == 3 && a.pro_scale == nullptr && a.pend == nullptr && a.Cout % 64 == 0 && a.Cin % 128 == 0 && a.H % 8 == 0 && a.W % 16 == 0 &&
+           a.ldx % 8 == 0 && a.lddy % 8 == 0 && (long)a.N * a.H * a.W * (a.ldx > a.lddy ? a.ldx : a.lddy) < (1L << 30);
+}
+
+int launch_wgrad_mm(TileWgradArgs& t, size_t ws_bytes, size_t* need, hipStream_t st)
+{
+    WgradMmArgs a;
+    a.x = (const u16*)t.x; a.dy = (const u16*)t.dy; a.ws = t.ws;
+    a.N = t.N; a.H = t.H; a.W = t.W; a.Cin = t.Cin; a.ldx = t.ldx; a.Cout = t.Cout; a.lddy = t.lddy;
+    a.tiles_y = t.H / 8; a.tiles_x = t.W / 16; a.ntiles = t.N * a.tiles_y * a.tiles_x; a.ncit = t.Cin / 128;
+    const int chan_tiles = (t.Cout / 64) * a.ncit;
+    int groups = 256 / chan_tiles; if (groups < 1) groups = 1;          // one 8-wave workgroup per CU
+    if (groups > a.ntiles) groups = a.ntiles;
+    a.wsize = (long)t.Cout * t.Cin * 9;
+    const size_t bytes = (size_t)groups * a.wsize * sizeof(float);
+    if (need) { *need = bytes; return SAUNET_OK; }
+    if (a.ws == nullptr || ws_bytes < bytes) return set_error(SAUNET_BAD_SHAPE, "wgrad: workspace %zu < %zu bytes", ws_bytes, bytes);
+    constexpr int LDS = 2 * WM_BUF;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_mm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    hipLaunchKernelGGL(conv3x3_wgrad_mm_kernel, dim3(groups, chan_tiles), dim3(512), LDS, st, a);
+    SAUNET_CHECK_LAUNCH("conv3x3_wgrad_mm");
+    long rb = (a.wsize + 255) / 256; if (rb > 4096) rb = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_tco_kernel, dim3((unsigned)rb), dim3(256), 0, st, t.ws, a.wsize, groups, t.Cout * t.Cin, t.dw);
+    SAUNET_CHECK_LAUNCH("wgrad_reduce_tco");
+    return SAUNET_OK;
 }
 
 bool tile_wgrad_unaligned_supported(const saunet_conv_desc* d)
@@ -1454,6 +1690,16 @@ int tile_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const f
     a.sM = (long)d->Cin * d->KH * d->KW; a.sN = (long)d->KH * d->KW;
     a.xs_n = a.xs_r = a.xs_p = 0; a.ncot = 0; a.Wo = 0;
     if (aligned && !need && (((uintptr_t)x | (uintptr_t)dy) & 15)) return set_error(SAUNET_BAD_ALIGN, "wgrad: pointers must be 16-byte aligned");
+    if (wgrad_mm_supported(a, d->KH, d->dtype, aligned)) {
+        if (need) {      // the workspace query has no operands: it cannot know whether a prologue will come -- size for both kernels
+            size_t n1 = 0, n2 = 0;
+            if (int rc = launch_wgrad_mm(a, 0, &n1, st)) return rc;
+            if (int rc = dispatch_tile_wgrad<u16>(a, d->KH, aligned, 0, &n2, st)) return rc;
+            *need = n1 > n2 ? n1 : n2;
+            return SAUNET_OK;
+        }
+        return launch_wgrad_mm(a, ws_bytes, need, st);
+    }
     if (d->dtype == SAUNET_BF16) return dispatch_tile_wgrad<u16>(a, d->KH, aligned, ws_bytes, need, st);
     if (d->dtype == SAUNET_F32) return dispatch_tile_wgrad<float>(a, d->KH, aligned, ws_bytes, need, st);
     return set_error(SAUNET_BAD_DTYPE, "wgrad: dtype %d", d->dtype);

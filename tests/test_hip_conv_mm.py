@@ -76,3 +76,23 @@ def test_conv_mm_dgrad_matches_float64(case):
     F.conv2d(xr, wt.detach().to(dt).double().cpu(), None, padding=1).backward(dy.double().cpu())
     scale = float(xr.grad.abs().max())
     assert float((dx.double().cpu() - xr.grad).abs().max()) <= 6e-3 * scale
+
+
+@pytest.mark.parametrize("case", [(2, 128, 16, 16, 64), (1, 256, 24, 48, 128), (3, 128, 8, 32, 192), (8, 256, 32, 32, 64), (2, 384, 16, 16, 64)])
+def test_wgrad_mm_matches_float64(case):
+    """conv3x3_wgrad_mm_kernel (LDS-DMA staged weight gradient of the prologue-free 3x3 convolutions, csrc/conv_tile.hip): every tap of every
+    (co, ci), image borders, several pixel groups (the partial-gradient reduce), odd tile counts -- against float64 autograd on the bf16 operands."""
+    n, cin, h, w, cout = case
+    H = HF()
+    dt = torch.bfloat16
+    x = _rnd(n, cin, h, w, seed=11).cuda().to(dt).contiguous(memory_format=torch.channels_last)
+    dy = _rnd(n, cout, h, w, seed=12).cuda().to(dt).contiguous(memory_format=torch.channels_last)
+    wt = torch.nn.Parameter(torch.zeros(cout, cin, 3, 3, device="cuda"))
+    H.GRADS.reset()
+    dw = H.conv_wgrad_raw(x, dy, wt, 1, 1)
+    torch.cuda.synchronize()
+    wr = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double().cpu(), wr, None, padding=1).backward(dy.double().cpu())
+    scale = float(wr.grad.abs().max())
+    err = float((dw.double().cpu() - wr.grad).abs().max())
+    assert err <= 2e-5 * scale + 1e-6 * (n * h * w) ** 0.5, (err, scale)          # float32 accumulation of exact bf16 products
