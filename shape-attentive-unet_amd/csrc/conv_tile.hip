@@ -1115,7 +1115,8 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
         // columns 1..8 are elements 1..7 of the kw = 0 fragment plus element 6 of the kw = 2 fragment (columns 2..9) of the SAME lane: three
         // v_alignbit and one more, no LDS.  Per tile row the loop reads the dy fragment and TWO x fragments (kw = 0, 2 of halo row ty + 2) instead
         // of nine: the transposing reads (one fresh 1 KB fragment per MFMA, 75 B/clk per CU) capped this loop at half the matrix-core rate.
-        constexpr bool ROLL = KS == 3 && sizeof(T) == 2 && !TS && KSP == 1 && MI == 1 && NI == 1 && TR <= 8;
+        constexpr int RPW = TR / KSP;                 // tile rows per K wave (a contiguous block of rows when ROLL)
+        constexpr bool ROLL = KS == 3 && sizeof(T) == 2 && !TS && MI == 1 && NI == 1 && TR % KSP == 0 && RPW <= 8;
         if constexpr (ROLL) {
             const int lx = (8 * khalf + (li >> 2)) * PX + (wn0 + 16 * nhalf + 4 * (li & 3)) * 2;
             auto load_row = [&](int hy, u32x4* f) {          // f[0], f[2] from LDS, f[1] derived
@@ -1126,17 +1127,19 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
                 f[1][2] = __builtin_amdgcn_alignbit(f[0][3], f[0][2], 16); f[1][3] = __builtin_amdgcn_alignbit(f[2][3], f[0][3], 16);
             };
             u32x4 rows[3][3];
-            load_row(0, rows[0]); load_row(1, rows[1]);
+            const int r0 = kwave * RPW;
+            load_row(r0, rows[0]); load_row(r0 + 1, rows[1]);
 #pragma unroll
-            for (int ty = 0; ty < TR; ++ty) {
-                load_row(ty + 2, rows[(ty + 2) % 3]);
+            for (int tr = 0; tr < RPW; ++tr) {
+                const int ty = r0 + tr;
+                load_row(ty + 2, rows[(tr + 2) % 3]);
                 u32x4 af;
                 tr_read2(s_y + (ty * TILE + 8 * khalf + (li >> 2)) * PY + (wm0 + 16 * nhalf + 4 * (li & 3)) * 2, 4 * PY, af);
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw)
-                        acc[0][0][kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, rows[(ty + kh) % 3][kw]),
+                        acc[0][0][kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, rows[(tr + kh) % 3][kw]),
                                                                                        acc[0][0][kh * 3 + kw], 0, 0, 0);
             }
         } else
