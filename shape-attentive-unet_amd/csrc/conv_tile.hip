@@ -1468,7 +1468,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mm_kernel(WgradMmArgs a)
 }
 
 // dw[co][ci][tap] += sum_g ws[g][tap][co][ci]: reads in workspace order (coalesced, the bulk), writes the 9-strided parameter layout
-__global__ __launch_bounds__(256) void wgrad_reduce_tco_kernel(const float* __restrict__ ws, long wsize, int groups, int cc, float* __restrict__ dw)
+__global__ __launch_bounds__(256) void wgrad_reduce_tco_kernel(const float* __restrict__ ws, long wsize, int groups, int cc, int taps, float* __restrict__ dw)
 {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < wsize; i += (long)gridDim.x * 256) {
         float s = 0.f;
@@ -1481,8 +1481,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tco_kernel(const float* __re
             for (int u = 0; u < 8; ++u) s += v[u];
         }
         for (; g < groups; ++g) s += ws[(size_t)g * wsize + i];
-        const long t = i / cc, r = i - t * cc;          // cc = Cout * Cin
-        dw[r * 9 + t] += s;
+        const long t = i / cc, r = i - t * cc;          // cc = channel pairs of the parameter (its first two dimensions)
+        dw[r * taps + t] += s;
     }
 }
 
@@ -1512,7 +1512,194 @@ int launch_wgrad_mm(TileWgradArgs& t, size_t ws_bytes, size_t* need, hipStream_t
     hipLaunchKernelGGL(conv3x3_wgrad_mm_kernel, dim3(groups, chan_tiles), dim3(512), LDS, st, a);
     SAUNET_CHECK_LAUNCH("conv3x3_wgrad_mm");
     long rb = (a.wsize + 255) / 256; if (rb > 4096) rb = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_tco_kernel, dim3((unsigned)rb), dim3(256), 0, st, t.ws, a.wsize, groups, t.Cout * t.Cin, t.dw);
+    hipLaunchKernelGGL(wgrad_reduce_tco_kernel, dim3((unsigned)rb), dim3(256), 0, st, t.ws, a.wsize, groups, t.Cout * t.Cin, 9, t.dw);
+    SAUNET_CHECK_LAUNCH("wgrad_reduce_tco");
+    return SAUNET_OK;
+}
+
+
+// =====================================================================================================
+// convt_wgrad_mm_kernel: weight gradient of ConvTranspose2d(k = 4, s = 2, p = 1) (the decoder's mrf.up, models/attention_blocks.py:179-186) with the
+// machinery of conv3x3_wgrad_mm_kernel.  Per output parity (py, px) it is a 2 x 2-tap problem between x (un-haloed operand, K = its pixels) and the
+// parity sub-image D[i][j] = dy[2 i + 1 - kh0][2 j + 1 - kw0] (kh0 = 1 - py, kw0 = 1 - px; see tile_wgrad_body KS == 2):
+//     dW[ci][co][kh0 + 2 th][kw0 + 2 tw] = sum x[n, i, j, ci] * D[n, i + th + kh0 - 1, j + tw + kw0 - 1, co]
+//   * channel tile 128 (Cin) x 128 (Cout), 8 waves = 4 x 2 tiles of 32 x 64 channels x 4 taps (8 accumulators);
+//   * pixel tile 8 x 16 of x; LDS per buffer: x tile 32 KB + 9 x 18 pixels of D (read IN PLACE from dy with stride-2 pixel addresses) 41 KB, two
+//     buffers; one D row serves two consecutive tile rows (th = 1, 0), the tw = 1 fragment is the register shift of the tw = 0 one;
+//   * blockIdx.y = parity x channel tile; partial gradients [tap][ci][co] per pixel group, permuted by wgrad_reduce_tco_kernel.
+struct ConvtWgradMmArgs {
+    const u16* x; const u16* dy; float* ws;
+    int N, H, W, Cin, ldx, Cout, lddy, tiles_x, tiles_y, ntiles, nbt, nct;
+    long wsize;
+};
+constexpr int CW_AB = 128 * 256, CW_BPIX = 9 * 18, CW_BPIECES = (CW_BPIX + 3) / 4, CW_BB = CW_BPIECES * 1024, CW_BUF = CW_AB + CW_BB;      // 32768 + 41984
+constexpr int CW_PIECES = 32 + CW_BPIECES;                                                                                                 // 73
+
+__global__ __launch_bounds__(512, 2) void convt_wgrad_mm_kernel(ConvtWgradMmArgs a)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4, nhalf = lg & 1, khalf = lg >> 1;
+    const int wa0 = (wave & 3) * 32, wb0 = (wave >> 2) * 64;
+    const int gx = blockIdx.x, ngroups = gridDim.x;
+    const int par = blockIdx.y / a.nct, ct = blockIdx.y - par * a.nct;
+    const int kh0 = 1 - (par >> 1), kw0 = 1 - (par & 1);
+    const int at = ct / a.nbt, bt = ct - at * a.nbt;
+    const int a0 = at * 128, b0 = bt * 128;
+    const int Wo = 2 * a.W;
+    const unsigned char* zsrc = (const unsigned char*)g_wg_zeros;
+
+    int prel[10], pr[10], pc[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const int id = j * 8 + wave;
+        const int sl = lane & 15;
+        if (id < 32) {
+            const int pix = id * 4 + (lane >> 4), row = pix >> 4, col = pix & 15;
+            prel[j] = ((row * a.W + col) * a.ldx + a0 + (sl ^ ((col & 3) << 2)) * 8) * 2; pr[j] = 0; pc[j] = 1;
+        } else {
+            const int hp = (id - 32) * 4 + (lane >> 4);
+            const int r = hp / 18, c = hp - r * 18;
+            prel[j] = (((2 * r + kh0 - 1) * Wo + 2 * c - 1 - kw0) * a.lddy + b0 + (sl ^ ((c & 3) << 2)) * 8) * 2;
+            pr[j] = hp < CW_BPIX ? r + kh0 - 1 : -100000; pc[j] = c - 1;
+        }
+    }
+    struct TileOrg { const unsigned char* xb; const unsigned char* yb; int ty0, tx0; };
+    auto origin = [&](int tile) {
+        int q = tile;
+        const int txi = q % a.tiles_x; q /= a.tiles_x;
+        const int tyi = q % a.tiles_y; const int n = q / a.tiles_y;
+        TileOrg o;
+        o.ty0 = tyi * 8; o.tx0 = txi * 16;
+        o.xb = (const unsigned char*)a.x + (((size_t)n * a.H + o.ty0) * a.W + o.tx0) * a.ldx * 2;
+        o.yb = (const unsigned char*)a.dy + (((long)n * 2 * a.H + 2 * o.ty0) * Wo + 2 * o.tx0) * a.lddy * 2;
+        return o;
+    };
+    auto issue = [&](int j, const TileOrg& o, int buf) {
+        const int id = j * 8 + wave;
+        if (id >= CW_PIECES) return;                                    // wave-uniform
+        const unsigned char* src;
+        if (id < 32) src = o.xb + prel[j];
+        else {
+            const bool ok = (unsigned)(o.ty0 + pr[j]) < (unsigned)a.H && (unsigned)(o.tx0 + pc[j]) < (unsigned)a.W;
+            src = ok ? o.yb + prel[j] : zsrc + (lane & 3) * 16;
+        }
+        mm_dma16(src, lds0 + buf * CW_BUF + id * 1024);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+
+    const int prow = 8 * khalf + (li >> 2);
+    const int ab = (wa0 + 16 * nhalf + 4 * (li & 3)) * 2, bb = (wb0 + 16 * nhalf + 4 * (li & 3)) * 2;
+    const int a_off = prow * 256 + (ab ^ ((prow & 3) << 6));                                            // + ty * 16 * 256
+    const int ca = prow + kw0, cc = ca + 2;                                                             // D columns of the tw = 0 fragment and of the one two pixels on
+    const int ba_off = CW_AB + ca * 256, bc_off = CW_AB + cc * 256;                                     // + r' * 18 * 256 + swizzled channel offset
+    const int ka = (ca & 3) << 6, kc = (cc & 3) << 6;
+
+    int tile = gx;
+    if (tile < a.ntiles) {
+        const TileOrg o = origin(tile);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) issue(j, o, 0);
+    }
+    const int phase = wave >> 2;
+    int buf = 0;
+    for (; tile < a.ntiles; tile += ngroups, buf ^= 1) {
+        mm_wait_vm<0>();
+        mm_barrier();
+        const unsigned char* sb = smem + buf * CW_BUF;
+        const int nxt = tile + ngroups;
+        TileOrg on;
+        if (nxt < a.ntiles) on = origin(nxt);
+        auto load_row = [&](int r, u32x4 (*f)[3]) {          // f[j][0] = tw 0, f[j][1] = tw 1 (derived), f[j][2] = helper (two pixels on)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int chb = bb + j * 64;
+                tr_read2(sb + ba_off + r * (18 * 256) + (chb ^ ka), 4 * 256, f[j][0]);
+                tr_read2(sb + bc_off + r * (18 * 256) + (chb ^ kc), 4 * 256, f[j][2]);
+                f[j][1][0] = __builtin_amdgcn_alignbit(f[j][0][1], f[j][0][0], 16); f[j][1][1] = __builtin_amdgcn_alignbit(f[j][0][2], f[j][0][1], 16);
+                f[j][1][2] = __builtin_amdgcn_alignbit(f[j][0][3], f[j][0][2], 16); f[j][1][3] = __builtin_amdgcn_alignbit(f[j][2][3], f[j][0][3], 16);
+            }
+        };
+        u32x4 rows[2][2][3];
+        load_row(0, rows[0]);
+#pragma unroll
+        for (int ty = 0; ty < 8; ++ty) {
+            load_row(ty + 1, rows[(ty + 1) & 1]);
+            u32x4 af;
+            tr_read2(sb + a_off + ty * (16 * 256), 4 * 256, af);
+#pragma unroll
+            for (int th = 0; th < 2; ++th)
+#pragma unroll
+                for (int tw = 0; tw < 2; ++tw)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[th * 2 + tw][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, rows[(ty + th) & 1][j][tw]),
+                                                                                    acc[th * 2 + tw][j], 0, 0, 0);
+            if (ty < 6 && (ty & 1) == phase && nxt < a.ntiles) {
+                constexpr int first[3] = {0, 4, 7};
+                const int k = ty >> 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (first[k] + j < (k == 2 ? 10 : first[k + 1 > 2 ? 2 : k + 1])) issue(first[k] + j, on, buf ^ 1);
+            }
+        }
+    }
+    // ---- partial gradient: ws[gx][tap = kh * 4 + kw][ci][co]
+    const int lr = lane & 31, lh = lane >> 5;
+    float* wsg = a.ws + (size_t)gx * a.wsize;
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+        for (int tw = 0; tw < 2; ++tw) {
+            const int toff = (kh0 + 2 * th) * 4 + kw0 + 2 * tw;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int co = b0 + wb0 + j * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = a0 + wa0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    wsg[((size_t)toff * a.Cin + ci) * a.Cout + co] = acc[th * 2 + tw][j][r];
+                }
+            }
+        }
+}
+
+bool convt_wgrad_mm_supported(const saunet_conv_desc* d, const saunet_wgrad_pending* pend)
+{
+    static const bool on = !(getenv("SAUNET_WGRAD_MM") && getenv("SAUNET_WGRAD_MM")[0] == '0');                // A/B switch
+    return on && pend == nullptr && d->Cin % 128 == 0 && d->Cout % 128 == 0 && d->H % 8 == 0 && d->W % 16 == 0 &&
+           (long)d->N * d->Ho * d->Wo * d->ldy < (1L << 30) && (long)d->N * d->H * d->W * d->ldx < (1L << 30);
+}
+
+int launch_convt_wgrad_mm(const saunet_conv_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, size_t* need, hipStream_t st)
+{
+    ConvtWgradMmArgs a;
+    a.x = (const u16*)x; a.dy = (const u16*)dy; a.ws = (float*)ws;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Cout = d->Cout; a.lddy = d->ldy;
+    a.tiles_y = d->H / 8; a.tiles_x = d->W / 16; a.ntiles = d->N * a.tiles_y * a.tiles_x;
+    a.nbt = d->Cout / 128; a.nct = (d->Cin / 128) * a.nbt;
+    int groups = 256 / (a.nct * 4); if (groups < 1) groups = 1;
+    if (groups > a.ntiles) groups = a.ntiles;
+    a.wsize = (long)d->Cin * d->Cout * 16;
+    const size_t bytes = (size_t)groups * a.wsize * sizeof(float);
+    if (need) { *need = bytes; return SAUNET_OK; }
+    if (ws == nullptr || ws_bytes < bytes) return set_error(SAUNET_BAD_SHAPE, "conv-transpose wgrad: workspace %zu < %zu bytes", ws_bytes, bytes);
+    constexpr int LDS = 2 * CW_BUF;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)convt_wgrad_mm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    hipLaunchKernelGGL(convt_wgrad_mm_kernel, dim3(groups, a.nct * 4), dim3(512), LDS, st, a);
+    SAUNET_CHECK_LAUNCH("convt_wgrad_mm");
+    long rb = (a.wsize + 255) / 256; if (rb > 4096) rb = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_tco_kernel, dim3((unsigned)rb), dim3(256), 0, st, (const float*)ws, a.wsize, groups, d->Cin * d->Cout, 16, dw);
     SAUNET_CHECK_LAUNCH("wgrad_reduce_tco");
     return SAUNET_OK;
 }
@@ -1727,6 +1914,16 @@ int tile_wgrad_convt(const saunet_conv_desc* d, const void* x, const void* dy, f
     a.xs_p = 2L * d->ldy; a.xs_r = 2L * d->Wo * d->ldy; a.xs_n = (long)d->Ho * d->Wo * d->ldy; a.Wo = d->Wo; a.ncot = 0;
     a.sM = (long)d->Cout * 16; a.sN = 16;     // dw[ci][co][kh][kw]
     if (!need && (((uintptr_t)x | (uintptr_t)dy) & 15)) return set_error(SAUNET_BAD_ALIGN, "conv-transpose wgrad: pointers must be 16-byte aligned");
+    if (convt_wgrad_mm_supported(d, pend)) {
+        if (need) {      // (a deferred call -- pend -- takes the tiled kernel: size for both)
+            size_t n1 = 0, n2 = 0;
+            if (int rc = launch_convt_wgrad_mm(d, x, dy, dw, ws, 0, &n1, st)) return rc;
+            if (int rc = launch_tile_wgrad<u16, 2, 8, 64, 64, 32, 32, 1>(a, 0, &n2, st)) return rc;
+            *need = n1 > n2 ? n1 : n2;
+            return SAUNET_OK;
+        }
+        return launch_convt_wgrad_mm(d, x, dy, dw, ws, ws_bytes, nullptr, st);
+    }
     // (measured at dec4, 189 us: a 128 x 64 channel tile with 64 x 32 per wave -- each haloed-operand fragment feeding two MFMAs -- 264 us; the register
     // prefetch of the next tile, which fits here without spills, 194 us: the tile loop is bound by the transposing LDS fragment reads, not by load latency)
     return launch_tile_wgrad<u16, 2, 8, 64, 64, 32, 32, 1>(a, ws_bytes, need, st);

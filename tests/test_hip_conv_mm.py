@@ -96,3 +96,23 @@ def test_wgrad_mm_matches_float64(case):
     scale = float(wr.grad.abs().max())
     err = float((dw.double().cpu() - wr.grad).abs().max())
     assert err <= 2e-5 * scale + 1e-6 * (n * h * w) ** 0.5, (err, scale)          # float32 accumulation of exact bf16 products
+
+
+@pytest.mark.parametrize("case", [(2, 128, 128, 16, 16), (1, 256, 128, 8, 32), (4, 128, 256, 16, 16), (16, 128, 128, 32, 32)])
+def test_convt_wgrad_mm_matches_float64(case):
+    """convt_wgrad_mm_kernel: dW of ConvTranspose2d(k4 s2 p1) (attention_blocks.py:179-186 `mrf.up`) from x and the stride-2 parity images of dy read in
+    place; every (ci, co, kh, kw), all four parities, borders, several pixel groups -- against float64 autograd on the bf16 operands."""
+    n, ci, co, h, w = case
+    H = HF()
+    dt = torch.bfloat16
+    x = _rnd(n, ci, h, w, seed=21).cuda().to(dt).contiguous(memory_format=torch.channels_last)
+    dy = _rnd(n, co, 2 * h, 2 * w, seed=22).cuda().to(dt).contiguous(memory_format=torch.channels_last)
+    wt = torch.nn.Parameter(torch.zeros(ci, co, 4, 4, device="cuda"))
+    H.GRADS.reset()
+    dw = H.conv_wgrad_raw(x, dy, wt, 2, 1, transposed=True)
+    torch.cuda.synchronize()
+    wr = torch.zeros(ci, co, 4, 4, dtype=torch.float64, requires_grad=True)
+    F.conv_transpose2d(x.double().cpu(), wr, None, stride=2, padding=1).backward(dy.double().cpu())
+    scale = float(wr.grad.abs().max())
+    err = float((dw.double().cpu() - wr.grad).abs().max())
+    assert err <= 2e-5 * scale + 1e-6 * (n * h * w) ** 0.5, (err, scale)
