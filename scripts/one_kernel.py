@@ -7,6 +7,22 @@ HF = S.functional
 which = sys.argv[1]; reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dt = torch.bfloat16
 n = 32
+if which in ("conv2dgrad", "conv1dgrad"):        # DenseNet data gradients with their BatchNorm-backward reduction epilogues, block-1 geometry
+    dbuf = torch.randn(n, 256, 128, 128, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+    z1 = torch.randn(n, 128, 128, 128, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+    p = HF.BNParams(128 if which == "conv2dgrad" else 192, "cuda")
+    p.buf[0].uniform_(0.5, 1.5); p.buf[1].normal_(0, 0.3); p.buf[2].normal_(0, 0.3); p.buf[3].uniform_(0.5, 1.5)
+    if which == "conv2dgrad":
+        w = torch.nn.Parameter(torch.randn(32, 128, 3, 3, device="cuda") * 0.05)
+        for _ in range(reps):
+            HF.conv_dgrad_raw(dbuf[:, 64:96], w, z1.shape, 1, 1, bn_epi=(z1, p, True, HF.new_stats(128, "cuda")))
+    else:
+        w = torch.nn.Parameter(torch.randn(128, 192, 1, 1, device="cuda") * 0.05)
+        xin = torch.randn(n, 256, 128, 128, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+        for _ in range(reps):
+            HF.conv_dgrad_raw(z1, w, (n, 192, 128, 128), 1, 0, out=dbuf[:, :192], bn_epi=(xin[:, :192], p, True, HF.new_stats(192, "cuda"), True))
+    torch.cuda.synchronize()
+    sys.exit(0)
 if which == "conv2":
     cin, h, cout, k, pro = 128, 128, 32, 3, True
 elif which == "conv1":

@@ -311,15 +311,49 @@ struct DenseDgrad3Args {
     FastDiv dW, dHW;
 };
 constexpr int D3_WPITCH = 296;
+// HALO variant (maps whose H and W are multiples of 16): the workgroup (8 waves) owns a 16 x 16 pixel tile, wave w its rows 2w, 2w + 1;
+// the 18 x 18 x 64 B gradient halo is staged by LDS-DMA (21 requests per tile instead of 18 fragment-shaped global loads per wave:
+// those were the texture-addresser bound of the kernel), double-buffered across the tiles of the persistent loop, one barrier per tile.
+// LDS pixel hp = hy * 18 + hx holds its four 16-byte channel chunks at slot chunk ^ ((hp >> 2) & 3): 16 consecutive pixels read by a
+// 16-lane group of ds_read_b128 then cover all 16 bank groups.  Padding pixels are DMA'd from a zero page.
+// Measured (block 1, 32 x 128 x 128): 132 -> 115 us with the halo, -> 100 us with z1 requested one step ahead (both variants); PMC: VALU
+// 35 %, MFMA 17 % busy, 1.6 of 2 waves per SIMD resident, 25 % of wave cycles waiting on memory.  Skewing the two waves of a SIMD by
+// s_sleep made no difference.  SAUNET_DGRAD3_HALO=0 selects the per-wave variant everywhere (A/B).
+constexpr int D3_HALO_PIECES = 21, D3_HALO_BYTES = D3_HALO_PIECES * 1024;
+static __device__ u32x4 g_dg_zeros[4];
 
-__global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgrad3Args a)
+template <bool HALO>
+__global__ __launch_bounds__((HALO ? 8 : DG_WAVES) * 64, HALO ? 1 : 2) void dense_dgrad3_kernel(DenseDgrad3Args a)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char d_smem[];
+    extern __shared__ __attribute__((aligned(1024))) unsigned char d_smem[];
     TSTAMP_INIT();
     TSTAMP(50);
-    u16* s_w = (u16*)d_smem;                                        // [128][D3_WPITCH]
-    float* s_par = (float*)(d_smem + (size_t)128 * D3_WPITCH * 2);  // [4][128]
-    constexpr int NT = DG_WAVES * 64;
+    constexpr int WAVES = HALO ? 8 : DG_WAVES;
+    constexpr int OFF_W = HALO ? 2 * D3_HALO_BYTES : 0;              // the halo buffers first: their DMA destinations are 1 KB aligned
+    u16* s_w = (u16*)(d_smem + OFF_W);                               // [128][D3_WPITCH]
+    float* s_par = (float*)(d_smem + OFF_W + (size_t)128 * D3_WPITCH * 2);  // [4][128]
+    constexpr int NT = WAVES * 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 31, lh = lane >> 5;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)d_smem;
+    const unsigned tilesX = (unsigned)a.W >> 4, tilesY = (unsigned)a.H >> 4, ntile = HALO ? (unsigned)a.N * tilesX * tilesY : 0u;
+    auto issue = [&](unsigned t, int buf) {
+        const unsigned txi = t % tilesX, r1 = t / tilesX, tyi = r1 % tilesY, n = r1 / tilesY;
+        const unsigned char* img = (const unsigned char*)(a.g + (size_t)n * a.H * a.W * a.ldg);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int piece = wave + 8 * j;
+            if (piece < D3_HALO_PIECES) {
+                const int hp = piece * 16 + (lane >> 2), sl = lane & 3;
+                const int hy = hp / 18, hx = hp - hy * 18;
+                const int iy = (int)tyi * 16 + hy - 1, ix = (int)txi * 16 + hx - 1;
+                const bool ok = hp < 324 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const int ch = sl ^ ((hp >> 2) & 3);
+                const unsigned char* src = ok ? img + ((size_t)(iy * a.W + ix) * a.ldg + ch * 8) * 2 : (const unsigned char*)g_dg_zeros + sl * 16;
+                mm_dma16(src, lds0 + buf * D3_HALO_BYTES + piece * 1024);
+            }
+        }
+    };
+    if constexpr (HALO) { if (blockIdx.x < ntile) issue(blockIdx.x, 0); }
     for (int i0 = threadIdx.x; i0 < 128 * 36; i0 += NT * 9) {     // 9 loads in flight per thread
         u32x4 v[9];
 #pragma unroll
@@ -338,7 +372,6 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgr
         s_par[i] = a.scale[i]; s_par[128 + i] = a.shift[i]; s_par[256 + i] = is; s_par[384 + i] = -a.mean[i] * is;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lh = lane >> 5;
     const unsigned ntp = (a.P + 31) / 32;
     // the two BN-backward sums in registers for the wave's lifetime (see dense_dgrad_kernel): red[step][2t + r]
     float red[2][4];
@@ -347,26 +380,67 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgr
 #pragma unroll
         for (int k = 0; k < 4; ++k) red[i][k] = 0.f;
     const bool sd0 = lane & 8, sd1 = lane & 4, sd2 = lane & 1, sd3 = lane & 2;
-    for (unsigned tp = blockIdx.x * DG_WAVES + wave; tp < ntp; tp += gridDim.x * DG_WAVES) {
-        const unsigned p = tp * 32u + lr;
-        const bool live = p < a.P;
-        const unsigned pc = live ? p : a.P - 1;
-        const unsigned n = a.dHW.div(pc), rem = pc - n * (unsigned)(a.H * a.W);
-        const int py = (int)a.dW.div(rem), px = (int)(rem - (unsigned)py * a.W);
-        TSTAMP(51);
-        // B fragments: [tap][k half]  (k = 16*h + 8*lh .. +8 of the 32 gradient channels)
-        u32x4 gf[18];
+    // the unit of the persistent loop: HALO -> 16 x 16 tile of the workgroup; else a 32-pixel run of the wave
+    const unsigned u_first = HALO ? blockIdx.x : blockIdx.x * WAVES + wave, u_step = HALO ? gridDim.x : gridDim.x * WAVES, u_end = HALO ? ntile : ntp;
+    int kbuf = 0;
+    // clamped pixel of this lane in unit tp (the z1 / out row it owns)
+    auto unit_pixel = [&](unsigned tp) -> unsigned {
+        if constexpr (HALO) {
+            const unsigned txi = tp % tilesX, r1 = tp / tilesX, tyi = r1 % tilesY, n = r1 / tilesY;
+            return ((n * a.H + tyi * 16 + 2 * wave + (lr >> 4)) * a.W) + txi * 16 + (lr & 15);
+        } else {
+            return min(tp * 32u + lr, a.P - 1);
+        }
+    };
+    // z1 runs one 64-channel step ahead of its use (two waves per SIMD do not hide an HBM round trip behind 18 MFMAs)
+    u32x4 znext[4];
+    if (u_first < u_end) {
+        const u16* z0 = a.z + (size_t)unit_pixel(u_first) * a.ldz + 8 * lh;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
-            const bool ok = live && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-            const u16* row = a.g + ((size_t)n * a.H * a.W + (size_t)(ok ? yy : py) * a.W + (ok ? xx : px)) * a.ldg + lh * 8;
-            const u32x4 v0 = *(const u32x4*)row, v1 = *(const u32x4*)(row + 16);
-            gf[2 * tap] = ok ? v0 : u32x4{0u, 0u, 0u, 0u};
-            gf[2 * tap + 1] = ok ? v1 : u32x4{0u, 0u, 0u, 0u};
+        for (int i = 0; i < 4; ++i) znext[i] = *(const u32x4*)(z0 + 16 * i);
+    }
+    for (unsigned tp = u_first; tp < u_end; tp += u_step) {
+        unsigned p; bool live;
+        u32x4 gf[18];       // B fragments: [tap][k half]  (k = 16*h + 8*lh .. +8 of the 32 gradient channels)
+        if constexpr (HALO) {
+            p = unit_pixel(tp);
+            live = true;
+            mm_wait_vm<0>();
+            mm_barrier();
+            TSTAMP(51);
+            const unsigned char* hb = d_smem + kbuf * D3_HALO_BYTES;
+            const int hp0 = (2 * wave + (lr >> 4)) * 18 + (lr & 15);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int hp = hp0 + (tap / 3) * 18 + tap % 3, key = (hp >> 2) & 3;
+                gf[2 * tap] = *(const u32x4*)(hb + hp * 64 + ((lh ^ key) << 4));
+                gf[2 * tap + 1] = *(const u32x4*)(hb + hp * 64 + (((2 + lh) ^ key) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (tp + u_step < u_end) issue(tp + u_step, kbuf ^ 1);
+            kbuf ^= 1;
+        } else {
+            p = tp * 32u + lr;
+            live = p < a.P;
+        }
+        const unsigned pc = live ? p : a.P - 1;
+        if constexpr (!HALO) {
+            const unsigned n = a.dHW.div(pc), rem = pc - n * (unsigned)(a.H * a.W);
+            const int py = (int)a.dW.div(rem), px = (int)(rem - (unsigned)py * a.W);
+            TSTAMP(51);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+                const bool ok = live && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+                const u16* row = a.g + ((size_t)n * a.H * a.W + (size_t)(ok ? yy : py) * a.W + (ok ? xx : px)) * a.ldg + lh * 8;
+                const u32x4 v0 = *(const u32x4*)row, v1 = *(const u32x4*)(row + 16);
+                gf[2 * tap] = ok ? v0 : u32x4{0u, 0u, 0u, 0u};
+                gf[2 * tap + 1] = ok ? v1 : u32x4{0u, 0u, 0u, 0u};
+            }
         }
         TSTAMP(52);
         const u16* zrow = a.z + (size_t)pc * a.ldz + 8 * lh;
+        const u16* zrow_next = a.z + (size_t)unit_pixel(min(tp + u_step, u_end - 1)) * a.ldz + 8 * lh;
         u16* yrow = a.y + (size_t)pc * a.ldy + 8 * lh;
         // opaque per-tile bases: with the two steps written out the weight / parameter addresses are tile-invariant and the compiler would
         // hoist all 72 weight fragments + 32 parameter vectors out of the tile loop (spills)
@@ -376,7 +450,12 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgr
             constexpr int step = decltype(step_c)::value;
             u32x4 zv[4], outv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) zv[i] = *(const u32x4*)(zrow + step * 64 + 16 * i);
+            for (int i = 0; i < 4; ++i) zv[i] = znext[i];
+            {
+                const u16* nz = step == 0 ? zrow + 64 : zrow_next;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) znext[i] = *(const u32x4*)(nz + 16 * i);
+            }
             TSTAMP(53);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -444,7 +523,7 @@ __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad3_kernel(DenseDgr
         const int l0 = 32 * ((c >> 3) & 1) + 4 * (c & 1) + 2 * ((c >> 2) & 1) + ((c >> 1) & 1);
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < DG_WAVES; ++w)
+        for (int w = 0; w < WAVES; ++w)
 #pragma unroll
             for (int row = 0; row < 2; ++row) {
                 const float* q = s_red + (w * 8 + reg) * 64 + l0 + 16 * row;
@@ -474,10 +553,22 @@ int dense_dgrad3_forward(const saunet_conv_desc* d, const void* x, const void* w
     a.dW = FastDiv::make((unsigned)d->W); a.dHW = FastDiv::make((unsigned)(d->H * d->W));
     const size_t lds = (size_t)128 * D3_WPITCH * 2 + sizeof(float) * 4 * 128;
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
-    long bx = 512; const long maxbx = ((long)a.P + 32 * DG_WAVES - 1) / (32 * DG_WAVES);
-    if (bx > maxbx) bx = maxbx; if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(dense_dgrad3_kernel, dim3((unsigned)bx), dim3(DG_WAVES * 64), lds, st, a);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
+        attr_set = true;
+    }
+    static const bool halo_env = !(getenv("SAUNET_DGRAD3_HALO") && getenv("SAUNET_DGRAD3_HALO")[0] == '0');     // A/B switch
+    const long ntile = (long)d->N * (d->H >> 4) * (d->W >> 4);
+    if (halo_env && d->H % 16 == 0 && d->W % 16 == 0 && ntile >= 256) {
+        // one 8-wave workgroup per CU, 16 x 16 tiles: only for maps with at least one tile per CU
+        const long bx = ntile < 256 ? ntile : 256;
+        hipLaunchKernelGGL(dense_dgrad3_kernel<true>, dim3((unsigned)bx), dim3(512), lds + 2 * D3_HALO_BYTES, st, a);
+    } else {
+        long bx = 512; const long maxbx = ((long)a.P + 32 * DG_WAVES - 1) / (32 * DG_WAVES);
+        if (bx > maxbx) bx = maxbx; if (bx < 1) bx = 1;
+        hipLaunchKernelGGL(dense_dgrad3_kernel<false>, dim3((unsigned)bx), dim3(DG_WAVES * 64), lds, st, a);
+    }
     SAUNET_CHECK_LAUNCH("dense_dgrad3");
     return SAUNET_OK;
 }

@@ -118,3 +118,38 @@ def test_grouped_weight_gradients_refuse_untiled_maps():
     wt = torch.nn.Parameter(torch.empty(32, 32, 3, 3, device="cuda"))
     assert HF.conv_wgrad_grouped([(x, dy, wt, None)], 3, 1, False) is None
 
+
+
+@pytest.mark.parametrize("shape,relu", [((4, 128, 128), True), ((8, 64, 128), True), ((16, 64, 64), False), ((2, 32, 32), True)])
+def test_conv2_data_gradient_with_norm2_reduction_matches_float64(shape, relu):
+    """dense_dgrad3_kernel, both tilings (csrc/dense_dgrad.hip): maps with >= 256 16 x 16 tiles take the LDS-DMA halo variant, the last
+    case the per-wave one.  dz1 = mask * conv_transpose(dz2 chunk, w) out of a channel slice of the block buffer, plus the two BatchNorm
+    backward sums of norm2, against float64 on the bf16-rounded operands (/root/reference/models/models.py:35-41)."""
+    import saunet_amd as S
+    H = S.functional
+    n, h, w_ = shape
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    dbuf = (torch.randn(n, 96, h, w_, generator=g)).cuda().to(dt).contiguous(memory_format=torch.channels_last)
+    z1 = torch.randn(n, 128, h, w_, generator=g).cuda().to(dt).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(32, 128, 3, 3, generator=g) * 0.05).cuda()
+    p = H.BNParams(128, "cuda")
+    p.buf[0].uniform_(0.5, 1.5); p.buf[1].normal_(0, 0.3); p.buf[2].normal_(0, 0.3); p.buf[3].uniform_(0.5, 1.5)
+    st = H.new_stats(128, "cuda")
+    dy = dbuf[:, 32:64]
+    out = H.conv_dgrad_raw(dy, wt, z1.shape, 1, 1, bn_epi=(z1, p, relu, st))
+    sums = H.collapse_stats(st).double().cpu()
+    torch.cuda.synchronize()
+    wq = wt.to(dt).double().cpu()
+    G = F.conv_transpose2d(dy.double().cpu(), wq, padding=1)
+    zf = z1.float()
+    sc, sh, mean, invstd = (p.scale.view(1, -1, 1, 1), p.shift.view(1, -1, 1, 1), p.mean.view(1, -1, 1, 1), p.invstd.view(1, -1, 1, 1))
+    if relu:
+        G = G * (torch.addcmul(sh, zf, sc) > 0).cpu()
+    xhat = ((zf - mean) * invstd).double().cpu()
+    ref_s1, ref_s2 = G.sum((0, 2, 3)), (G * xhat).sum((0, 2, 3))
+    err = (out.double().cpu() - G).abs().max().item()
+    assert err <= 1e-2 * G.abs().max().item() + 1e-6                     # bf16 store of an fp32 accumulator
+    scale1 = G.abs().sum((0, 2, 3)).max().item()
+    assert (sums[:128] - ref_s1).abs().max().item() <= 2e-5 * scale1     # sums are taken before the store rounding
+    assert (sums[128:] - ref_s2).abs().max().item() <= 2e-5 * (G * xhat).abs().sum((0, 2, 3)).max().item() + 1e-4 * scale1
