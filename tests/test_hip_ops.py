@@ -114,10 +114,14 @@ def test_conv_transpose_fwd_bwd(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_conv_prologue_stats_and_channel_slices(dtype):
-    """DenseNet pattern: read a channel slice, BN+ReLU in the operand load, write into another slice with stats."""
+@pytest.mark.parametrize("geom", [(2, 16, 16, 96), (8, 32, 32, 128), (3, 48, 64, 96), (5, 32, 48, 64)])
+def test_conv_prologue_stats_and_channel_slices(dtype, geom):
+    """DenseNet pattern: read a channel slice, BN+ReLU in the operand load, write into another slice with stats.
+    >= 32 pixel tiles take the persistent resident-weight kernel; in bf16 with Cin in {64, 96, 128} its double-buffered variant
+    (odd unit counts, ragged per-workgroup tile shares, 2-4 channel blocks)."""
     hf = HF()
-    n, h, w, ctot, cin, co = 2, 16, 16, 160, 96, 32
+    n, h, w, cin = geom
+    ctot, co = 160, 32
     buf = rnd(n, ctot, h, w)
     wt = rnd(co, cin, 3, 3, scale=0.05)
     scale, shift = rnd(cin, seed=3).abs() + 0.5, rnd(cin, seed=4) * 0.3
