@@ -214,6 +214,29 @@ __device__ __forceinline__ void rep_sum2(const double* __restrict__ a, const dou
     sa = va; sb = vb;
 }
 
+// keep + (send of the partner lane under the DPP permutation CTRL)
+template <int CTRL> __device__ __forceinline__ float dpp_exchange_add(float keep, float send)
+{
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xf, 0xf, true));
+}
+// TRANSPOSING reduction of the two BN-backward sums of 8 channels over the 16 lanes (pixels) of a DPP row: every stage pairs two values, a lane
+// keeps one of the pair and receives the partner lane's copy of the same one, so the 16 inputs shrink 8 -> 4 -> 2 -> 1 while the lanes
+// spread over the outputs: 15 DPP adds (+ 30 selects) instead of the 80 DPP adds of sixteen separate 5-step reductions -- a DPP add issues
+// every 8 cycles per wave, an LDS float atomic costs ~12 cycles per active lane (scripts/probes/valu_probe.hip).  Stage order = row_mirror,
+// row_half_mirror, quad_perm xor 1, quad_perm xor 2, so that the lanes a later stage pairs made the same choices in all earlier stages.
+// Result: lane l of the row holds the 16-lane partial sum of  (l & 8 ? e2 : e1)[4 * ((l >> 1) & 1) + 2 * (l & 1) + ((l >> 2) & 1)].
+__device__ __forceinline__ float row_transpose_sum(const float (&e1)[8], const float (&e2)[8], bool s0, bool s1, bool s2, bool s3)
+{
+    float w0[8], w1[4], w2[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w0[j] = dpp_exchange_add<0x140>(s0 ? e2[j] : e1[j], s0 ? e1[j] : e2[j]);                 // row_mirror
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w1[k] = dpp_exchange_add<0x141>(s1 ? w0[2 * k + 1] : w0[2 * k], s1 ? w0[2 * k] : w0[2 * k + 1]);   // row_half_mirror
+#pragma unroll
+    for (int k = 0; k < 2; ++k) w2[k] = dpp_exchange_add<0xB1>(s2 ? w1[2 * k + 1] : w1[2 * k], s2 ? w1[2 * k] : w1[2 * k + 1]);    // quad_perm [1,0,3,2]
+    return dpp_exchange_add<0x4E>(s3 ? w2[1] : w2[0], s3 ? w2[0] : w2[1]);                                                // quad_perm [2,3,0,1]
+}
+
 // Consumer-side BatchNorm finalize (saunet_bn_prologue): fills s_pro[0 .. cpad) = scale and s_pro[cpad .. 2*cpad) = shift of the input
 // channels (zero beyond Cin) with the arithmetic of bn_finalize_kernel; `writer` (one workgroup of the launch) also publishes the xhat rows
 // of the channels finalised here, the [4][Cin] parameter block the backward pass reads and the running statistics.
