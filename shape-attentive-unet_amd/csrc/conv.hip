@@ -748,7 +748,10 @@ int saunet_conv2d_wgrad_deferred(const saunet_conv_desc* d, const void* x, const
 {
     hipStream_t st = (hipStream_t)stream;
     if (pending) { pending->ws = nullptr; pending->dw = nullptr; pending->wsize = 0; pending->groups = 0; pending->reserved = 0; }
-    if (ps == nullptr && convt_direct(d)) return tile_wgrad_convt(d, x, dy, dw, workspace, (size_t)workspace_bytes, nullptr, st, pending);
+    // (operands that are not 16-byte aligned -- an odd channel slice handed in through the C API -- take the generic path below; the workspace
+    // query cannot see pointers and sizes for the direct kernel, which is the larger of the two)
+    if (ps == nullptr && convt_direct(d) && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0)
+        return tile_wgrad_convt(d, x, dy, dw, workspace, (size_t)workspace_bytes, nullptr, st, pending);
     saunet_conv_desc flat;
     if (is_pointwise(d) && dense_pointwise_rows(d, &flat)) d = &flat;     // pixels are just rows for a 1x1 conv: any map shape tiles
     if (igemm_supported(d)) {

@@ -472,6 +472,7 @@ CONVT_WGRAD_DIRECT = True
 
 def _conv_wgrad_impl(x, dy, weight, stride, pad, transposed=False, pro=None, pending=None):
     direct_t = (CONVT_WGRAD_DIRECT and transposed and pro is None and x.dtype == torch.bfloat16 and tuple(weight.shape[2:]) == (4, 4)
+                and stride == 2 and pad == 1            # (tile_wgrad_convt_supported's own conditions, mirrored)
                 and x.shape[2] % 16 == 0 and x.shape[3] % 16 == 0 and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0 and ld_of(x) % 8 == 0
                 and ld_of(dy) % 8 == 0 and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0)
     if transposed and not direct_t and pro is None and weight.shape[2:] == (4, 4) and weight.shape[1] % 8 == 0 and weight.shape[0] % 8 == 0:
@@ -1623,6 +1624,11 @@ def dense_block(x0, layers, training):
     """layers: list of modules with norm1, conv1, norm2, conv2.  Returns (concat buffer, its channel statistics)."""
     if not training and not torch.is_grad_enabled() and x0.is_cuda:
         return dense_block_infer(x0, layers), None
+    eps = {float(n.eps) for m in layers for n in (m.norm1, m.norm2)}
+    if len(eps) > 1:
+        # the block shares one set of normalised-input rows (invstd computed once per concat channel) between all its norm1 layers, forward and
+        # backward: that is only the BatchNorm of every layer when they agree on eps (torchvision's _DenseLayer always does)
+        raise RuntimeError("dense_block: the BatchNorm layers of one dense block must share eps, got %s" % sorted(eps))
     params, bufs, cfgs = [], [], []
     for m in layers:
         params += [m.norm1.weight, m.norm1.bias, m.conv1.weight, m.norm2.weight, m.norm2.bias, m.conv2.weight]

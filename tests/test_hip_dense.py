@@ -153,3 +153,37 @@ def test_conv2_data_gradient_with_norm2_reduction_matches_float64(shape, relu):
     scale1 = G.abs().sum((0, 2, 3)).max().item()
     assert (sums[:128] - ref_s1).abs().max().item() <= 2e-5 * scale1     # sums are taken before the store rounding
     assert (sums[128:] - ref_s2).abs().max().item() <= 2e-5 * (G * xhat).abs().sum((0, 2, 3)).max().item() + 1e-4 * scale1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_whole_block_grouped_weight_gradients_match_the_per_layer_launches(dtype):
+    """the same eager dense block run twice: all weight gradients in the two grouped launches at the end of the block's backward (the default,
+    and what a captured step runs) against one launch per layer.  Same arithmetic per problem, so the weight gradients must agree to
+    accumulation-order noise; the data gradient does not depend on the switch at all."""
+    import saunet_amd as S
+    HF = S.functional
+    torch.manual_seed(5)
+    block = S.modules._DenseBlock(4, 64).cuda().train()
+    with torch.no_grad():
+        for m in block.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(4.0, 6.0)       # away from the ReLU kink: no mask flips between the two runs
+    x0 = torch.randn(4, 64, 32, 32, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    cot = None
+    grads = {}
+    assert HF.DENSE_WGRAD_GROUPED is True
+    try:
+        for grouped in (True, False):
+            HF.DENSE_WGRAD_GROUPED = grouped
+            block.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            y = block(x)
+            if cot is None:
+                cot = torch.randn(y.shape, device="cuda").to(dtype)
+            (y.float() * cot.float()).sum().backward()
+            grads[grouped] = {"x": x.grad.float().clone(), **{k: v.grad.float().clone() for k, v in block.named_parameters()}}
+    finally:
+        HF.DENSE_WGRAD_GROUPED = True
+    tol = 2e-5 if dtype == torch.float32 else 2e-3
+    for k in grads[True]:
+        assert rel(grads[True][k], grads[False][k]) < tol, (k, rel(grads[True][k], grads[False][k]))
