@@ -26,15 +26,97 @@ struct MmArgs {
     double* stat_sum; double* stat_sumsq; int stat_replicas, stat_rstride;
     int N, H, W, Cin, ldx, Cout, ldy, act_relu;
     int tiles_x, tiles_y, ntiles, nnt;
+    int splits; float* ws;      // CELL only: split-K over channel blocks (partials in accumulator layout, conv3x3_mm_finish_kernel)
 };
 
 static __device__ u32x4 g_mm_zeros[256];    // 4 KB of zeros: the source of every padding lane (a padding lane walks through it with the channel block: Cin <= 2048)
 
-constexpr int MM_HP = 18, MM_NPIX = MM_HP * MM_HP;          // halo pitch / pixels
-constexpr int MM_HALO_INSTR = (MM_NPIX + 7) / 8;            // 41 DMA instructions of 1 KB (8 pixels x 128 B)
-constexpr int MM_HALO_BYTES = MM_HALO_INSTR * 1024;         // 41 984
-constexpr int MM_HALO_PER_WAVE = 6;                         // 8 waves x 6 slots >= 41 (surplus slots go to the dummy region)
+// Halo geometry.  Plain: one 16 x 16 pixel tile of one image, 18 x 18 halo = 41 DMA instructions of 1 KB (8 pixels x 128 B), 6 request slots per
+// wave (8 x 6 >= 41; surplus slots go to the dummy region).  CELL (8 x 8 maps: `center`): the 16 x 16 tile is a 2 x 2 cell of FOUR images, each
+// quadrant with its own zero border -- a 20 x 20 halo (two 10-wide halos side by side, two stacked), 50 instructions, 7 slots per wave; an output
+// pixel (py, px) reads halo pixel (py + kh + 2 * (py >> 3), px + kw + 2 * (px >> 3)): still lane base + per-tap constant.
+template <bool CELL> struct MmHalo {
+    static constexpr int HP = CELL ? 20 : 18, NPIX = HP * HP;
+    static constexpr int INSTR = (NPIX + 7) / 8;
+    static constexpr int BYTES = INSTR * 1024;
+    static constexpr int PER_WAVE = (INSTR + 7) / 8;
+};
 constexpr int MM_RING = 4;
+
+// bias / ReLU, tile through LDS to 16-byte row stores, per-channel sums of the un-biased accumulator (BatchNorm statistics)
+template <int BN, bool CELL>
+__device__ __forceinline__ void mm_epilogue(const MmArgs& a, f32x16 (&acc)[2][BN / 64], unsigned char* smem, int n, int ty0, int tx0, int n0)
+{
+    constexpr int TJ = BN / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    u16* so = (u16*)smem;                                          // [256][BN]
+    float* s_sum = (float*)(smem + 256 * BN * 2);                  // [4 row waves][2][BN]
+    const bool do_stats = a.stat_sum != nullptr;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int col = wn * (BN / 2) + j * 32 + lr;
+        const float bv = (a.bias != nullptr && n0 + col < a.Cout) ? a.bias[n0 + col] : 0.f;
+        float sv = 0.f, ssv = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][j][r];
+                sv += v; ssv += v * v;
+                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                Elem<u16>::store(so + row * BN + col, a.act_relu ? fmaxf(v + bv, 0.f) : v + bv);
+            }
+        if (do_stats) {
+            sv += __shfl_xor(sv, 32, 64); ssv += __shfl_xor(ssv, 32, 64);
+            if (lh == 0) { float* slot = s_sum + wm * 2 * BN; slot[col] = sv; slot[BN + col] = ssv; }
+        }
+    }
+    __syncthreads();
+    if (do_stats && tid < BN && n0 + tid < a.Cout) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { t1 += s_sum[w * 2 * BN + tid]; t2 += s_sum[w * 2 * BN + BN + tid]; }
+        const size_t ro = (size_t)(blockIdx.x % a.stat_replicas) * a.stat_rstride;
+        atomicAdd(&a.stat_sum[ro + n0 + tid], (double)t1);
+        atomicAdd(&a.stat_sumsq[ro + n0 + tid], (double)t2);
+    }
+    constexpr int CH = BN / 8;                                     // 16-byte chunks per row
+    u16* __restrict__ yg = a.y + (size_t)n * (CELL ? 4 : 1) * a.H * a.W * a.ldy;
+    constexpr int S_ITERS = 256 * CH / 512;
+    const int colv = n0 + (tid % CH) * 8;
+    if (colv < a.Cout) {
+#pragma unroll
+        for (int i = 0; i < S_ITERS; ++i) {
+            const int p = tid + i * 512;
+            const int row = p / CH, ch = p - row * CH;
+            const int py = row >> 4, px = row & 15;
+            const size_t opix = CELL ? (size_t)(2 * (py >> 3) + (px >> 3)) * 64 + (py & 7) * 8 + (px & 7) : (size_t)(ty0 + py) * a.W + tx0 + px;
+            *(u32x4*)(yg + opix * a.ldy + colv) = *(const u32x4*)(so + row * BN + ch * 8);
+        }
+    }
+}
+
+// second half of a split-K cell-mode launch: one workgroup per (cell, n tile) sums the partials in split order and finishes the tile
+__global__ __launch_bounds__(512) void conv3x3_mm_finish_kernel(MmArgs a)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, item = blockIdx.x, t = item / a.nnt, nt = item - t * a.nnt;
+    const float* wsb = a.ws + (size_t)item * a.splits * (32 * 512);
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    for (int sp = 0; sp < a.splits; ++sp) {          // split order (deterministic); the 32 loads of one split are independent and in flight together
+        const float* q = wsb + (size_t)sp * (32 * 512) + tid;
+        float v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = q[k * 512];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc[k >> 4][0][k & 15] += v[k];
+    }
+    mm_epilogue<64, true>(a, acc, smem, t, 0, 0, nt * 64);
+}
 
 // Where a stage's DMA requests are issued matters (round-4 phase stamps, profiles/r04_mm_kernel_notes.txt): one request blocks ITS wave for
 // ~110 cycles (the CU's memory front end accepts one about every 30 cycles from all waves together), so with all eight waves requesting right
@@ -43,9 +125,11 @@ constexpr int MM_RING = 4;
 // loader waves (640-thread workgroups; a single wave sustains only one request per ~118 cycles, 12 per stage = 1400 cycles: slower, 55 %),
 // anti-phase halves (waves 0-3 behind the barrier, 4-7 at the end of the stage: 56 %), requests pinned a full k-step ahead and s_setprio
 // around the MFMA groups (both -2 %).
-template <int BN>
+template <int BN, bool CELL>
 __global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
 {
+    constexpr int MM_HP = MmHalo<CELL>::HP, MM_NPIX = MmHalo<CELL>::NPIX, MM_HALO_INSTR = MmHalo<CELL>::INSTR, MM_HALO_BYTES = MmHalo<CELL>::BYTES;
+    constexpr int MM_HALO_PER_WAVE = MmHalo<CELL>::PER_WAVE;
     TSTAMP_INIT();
     TSTAMP(20);
     constexpr int TJ = BN / 64;                       // 32-channel MFMA tiles per wave in N
@@ -62,16 +146,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
     const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves
     // ---- workgroup -> (pixel tile, n tile): the n tiles of one pixel tile share its halo, so they run on the SAME XCD (block b -> XCD b % 8)
     int t, nt;
+    const int split = CELL ? (int)(blockIdx.x % (unsigned)a.splits) : 0;
     {
-        const int b = blockIdx.x;
+        const int b = CELL ? (int)(blockIdx.x / (unsigned)a.splits) : (int)blockIdx.x;
         if ((a.ntiles & 7) == 0) { const int k = b >> 3; t = (k / a.nnt) * 8 + (b & 7); nt = k % a.nnt; }
         else { t = b / a.nnt; nt = b % a.nnt; }
     }
     const int txi = t % a.tiles_x; const int r1 = t / a.tiles_x;
     const int tyi = r1 % a.tiles_y; const int n = r1 / a.tiles_y;
     const int ty0 = tyi * 16, tx0 = txi * 16, n0 = nt * BN;
-    const u16* __restrict__ xg = a.x + (size_t)n * a.H * a.W * a.ldx;
-    const int ncb = a.Cin >> 6;
+    // CELL: a.tiles_x = a.tiles_y = 1 and n counts cells of four 8 x 8 images
+    const u16* __restrict__ xg = a.x + (size_t)n * (CELL ? 4 : 1) * a.H * a.W * a.ldx;
+    // CELL: this workgroup reduces channel blocks [cb0, cb0 + ncb) of the layer's Cin / 64
+    const int ncb = CELL ? (a.Cin >> 6) / a.splits : a.Cin >> 6;
+    const int cb0 = split * ncb;
     const int nstage = ncb * 9;
     const unsigned char* zsrc = (const unsigned char*)g_mm_zeros;
 
@@ -84,10 +172,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
         const int hidx = j * 8 + wave;
         const int hp = hidx * 8 + (lane >> 3), sl = lane & 7;
         const int hy = hp / MM_HP, hx = hp - hy * MM_HP;
-        const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+        int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+        long img = 0;
+        if constexpr (CELL) {            // quadrant (hy / 10, hx / 10) = image 2 * qy + qx of the cell, its own 10 x 10 halo
+            const int qy = hy / 10, qx = hx / 10;
+            iy = hy - 10 * qy - 1; ix = hx - 10 * qx - 1;
+            img = (long)(2 * qy + qx) * a.H * a.W;
+        }
         const bool ok = hidx < MM_HALO_INSTR && hp < MM_NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        const int ch = sl ^ ((hx >> 1) & 7);
-        hsrc[j] = ok ? (const unsigned char*)xg + ((long)(iy * a.W + ix) * a.ldx + ch * 8) * 2 : zsrc + (lane & 7) * 16;
+        const int ch = sl ^ (((CELL && hx >= 10 ? hx - 2 : hx) >> 1) & 7);       // CELL: key of the un-gapped column, so that 16 lanes still cover the 16 bank groups
+        hsrc[j] = ok ? (const unsigned char*)xg + ((img + iy * a.W + ix) * a.ldx + ch * 8) * 2 : zsrc + (lane & 7) * 16;
     }
     unsigned woff[WINSTR];
 #pragma unroll
@@ -103,13 +197,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
         const int hidx = j * 8 + wave;
         const int cbc = cb < ncb ? cb : ncb - 1;
         const unsigned dst = hidx < MM_HALO_INSTR ? lds0 + (cb & 1) * MM_HALO_BYTES + hidx * 1024 : lds0 + OFF_DUMMY;
-        mm_dma16(hsrc[j] + (long)cbc * 128, dst);
+        mm_dma16(hsrc[j] + (long)(cbc + cb0) * 128, dst);
     };
     auto issue_w1 = [&](int s, int j) {              // rows j of the weight tile of stage s into ring slot s % 4
         const int sc = s < nstage ? s : nstage - 1;
         const int cb = sc / 9, tap = sc - cb * 9;
         const unsigned sbase = lds0 + OFF_W + (s & (MM_RING - 1)) * WSLOT;
-        const unsigned char* wsrc = (const unsigned char*)a.w + ((size_t)tap * a.Cin + (size_t)cb * 64) * 2;
+        const unsigned char* wsrc = (const unsigned char*)a.w + ((size_t)tap * a.Cin + (size_t)(cb + cb0) * 64) * 2;
         mm_dma16(wsrc + woff[j], sbase + (j * 8 + wave) * 1024);
     };
     auto issue_w = [&](int s) {
@@ -119,11 +213,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
 
     // ---- fragment addresses (bytes inside smem).  A: halo pixel (py + kh, px + kw), 16-byte slot (2 ks + lh) ^ key(px + kw)
     const int py0 = wm * 4 + (lr >> 4), px = lr & 15;
+    const int hy0 = CELL ? py0 + 2 * (py0 >> 3) : py0, hx0 = CELL ? px + 2 * (px >> 3) : px;      // (the wave's four rows sit in one half of the cell)
     int ak[3];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-        const int key = ((px + kw) >> 1) & 7;
-        ak[kw] = (py0 * MM_HP + px + kw) * 128 + (((lh ^ key) & 1) << 4) + ((key & 6) << 4);
+        const int hxk = hx0 + kw;
+        const int key = ((CELL && hxk >= 10 ? hxk - 2 : hxk) >> 1) & 7;
+        ak[kw] = (hy0 * MM_HP + hxk) * 128 + (((lh ^ key) & 1) << 4) + ((key & 6) << 4);
     }
     const int brow = wn * (BN / 2) + lr;
     const int bkey = (brow >> 1) & 7;
@@ -176,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
             // ---- stage boundary.  Outstanding (per wave, oldest first): [halo piece of stage s-2] weights(s+1) [halo piece of s-1] weights(s+2);
             // certify weights(s+1) (and with them every older halo piece): allow what stage s-1 issued to stay in flight
             TSTAMP(23);
-            if (tap >= 1 && tap <= 6) mm_wait_vm<1 + WINSTR>(); else mm_wait_vm<WINSTR>();
+            if (tap >= 1 && tap <= MM_HALO_PER_WAVE) mm_wait_vm<1 + WINSTR>(); else mm_wait_vm<WINSTR>();
             TSTAMP(29);
             mm_barrier();
             TSTAMP(24);
@@ -207,63 +303,35 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
     mm_wait_vm<0>();
     __syncthreads();
     TSTAMP(27);
-
-    // ---- epilogue: bias / ReLU, tile through LDS to 16-byte row stores, per-channel sums of the un-biased accumulator (BatchNorm statistics)
-    u16* so = (u16*)smem;                                          // [256][BN]
-    float* s_sum = (float*)(smem + 256 * BN * 2);                  // [4 row waves][2][BN]
-    const bool do_stats = a.stat_sum != nullptr;
+    if constexpr (CELL) {
+        // split-K: every workgroup stores its accumulators in ACCUMULATOR layout (value k of thread tid at [k][tid]: coalesced, and the same
+        // thread of the finishing workgroup re-reads them); conv3x3_mm_finish_kernel adds the partials in split order and runs the epilogue.
+        // (An in-kernel finish by the last arriver -- __threadfence + ticket -- cost 30-75 us: a device-scope fence writes back and
+        // invalidates the XCD's whole L2 on this chip.  The kernel boundary is the cheap fence.)
+        if (a.splits > 1) {
+            float* mine = a.ws + ((size_t)(t * a.nnt + nt) * a.splits + split) * (32 * TJ * 512);
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-        const int col = wn * (BN / 2) + j * 32 + lr;
-        const float bv = (a.bias != nullptr && n0 + col < a.Cout) ? a.bias[n0 + col] : 0.f;
-        float sv = 0.f, ssv = 0.f;
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < TJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc[i][j][r];
-                sv += v; ssv += v * v;
-                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                Elem<u16>::store(so + row * BN + col, a.act_relu ? fmaxf(v + bv, 0.f) : v + bv);
-            }
-        if (do_stats) {
-            sv += __shfl_xor(sv, 32, 64); ssv += __shfl_xor(ssv, 32, 64);
-            if (lh == 0) { float* slot = s_sum + wm * 2 * BN; slot[col] = sv; slot[BN + col] = ssv; }
+                    for (int r = 0; r < 16; ++r) mine[((i * TJ + j) * 16 + r) * 512 + tid] = acc[i][j][r];
+            return;
         }
     }
-    __syncthreads();
-    if (do_stats && tid < BN && n0 + tid < a.Cout) {
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { t1 += s_sum[w * 2 * BN + tid]; t2 += s_sum[w * 2 * BN + BN + tid]; }
-        const size_t ro = (size_t)(blockIdx.x % a.stat_replicas) * a.stat_rstride;
-        atomicAdd(&a.stat_sum[ro + n0 + tid], (double)t1);
-        atomicAdd(&a.stat_sumsq[ro + n0 + tid], (double)t2);
-    }
-    constexpr int CH = BN / 8;                                     // 16-byte chunks per row
-    u16* __restrict__ yg = a.y + (size_t)n * a.H * a.W * a.ldy;
-    constexpr int S_ITERS = 256 * CH / 512;
-    const int colv = n0 + (tid % CH) * 8;
-    if (colv < a.Cout) {
-#pragma unroll
-        for (int i = 0; i < S_ITERS; ++i) {
-            const int p = tid + i * 512;
-            const int row = p / CH, ch = p - row * CH;
-            const size_t opix = (size_t)(ty0 + (row >> 4)) * a.W + tx0 + (row & 15);
-            *(u32x4*)(yg + opix * a.ldy + colv) = *(const u32x4*)(so + row * BN + ch * 8);
-        }
-    }
+    mm_epilogue<BN, CELL>(a, acc, smem, n, ty0, tx0, n0);
     TSTAMP(28);
 }
 
 
-template <int BN> static int launch_mm(const MmArgs& a, hipStream_t st)
+template <int BN, bool CELL = false> static int launch_mm(const MmArgs& a, hipStream_t st)
 {
-    constexpr int LDS = 2 * MM_HALO_BYTES + MM_RING * BN * 128 + 1024;
-    auto kern = conv3x3_mm_kernel<BN>;
+    constexpr int LDS = 2 * MmHalo<CELL>::BYTES + MM_RING * BN * 128 + 1024;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    auto kern = conv3x3_mm_kernel<BN, CELL>;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3(a.ntiles * a.nnt), dim3(512), LDS, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.ntiles * a.nnt * (CELL ? a.splits : 1)), dim3(512), LDS, st, a);
     SAUNET_CHECK_LAUNCH("conv3x3_mm");
     return SAUNET_OK;
 }
@@ -283,8 +351,10 @@ bool mm_fwd_supported(const saunet_conv_desc* d, const void* x, const void* w, c
 {
     static const bool on = !(getenv("SAUNET_CONV_MM") && getenv("SAUNET_CONV_MM")[0] == '0');             // A/B switch
     static const int min_cin = getenv("SAUNET_MM_MINCIN") ? atoi(getenv("SAUNET_MM_MINCIN")) : 128;
-    return on && d->dtype == SAUNET_BF16 && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->H % 16 == 0 &&
-           d->W % 16 == 0 && d->Ho == d->H && d->Wo == d->W && ps == nullptr && (epi == nullptr || epi->bn_x == nullptr) && d->Cin % 64 == 0 &&
+    static const bool cell_on = !(getenv("SAUNET_MM_CELL") && getenv("SAUNET_MM_CELL")[0] == '0');        // A/B switch
+    const bool cell = cell_on && d->H == 8 && d->W == 8 && d->N % 4 == 0;          // 8 x 8 maps: 2 x 2 image cells
+    return on && d->dtype == SAUNET_BF16 && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
+           ((d->H % 16 == 0 && d->W % 16 == 0) || cell) && d->Ho == d->H && d->Wo == d->W && ps == nullptr && (epi == nullptr || epi->bn_x == nullptr) && d->Cin % 64 == 0 &&
            d->Cin >= min_cin && d->Cin <= 2048 && d->Cout % 8 == 0 && d->Cout >= 64 && d->ldx % 8 == 0 && d->ldy % 8 == 0 &&
            !(((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) && (long)d->N * d->H * d->W * d->ldx < (1L << 30);
 }
@@ -295,6 +365,36 @@ int mm_forward(const saunet_conv_desc* d, const void* x, const void* w, const fl
     a.x = (const u16*)x; a.w = (const u16*)w; a.y = (u16*)y; a.bias = bias; a.stat_sum = ssum; a.stat_sumsq = ssq;
     a.stat_replicas = d->stat_replicas > 1 ? d->stat_replicas : 1; a.stat_rstride = d->stat_rstride;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Cout = d->Cout; a.ldy = d->ldy; a.act_relu = d->epi_relu;
+    a.splits = 1; a.ws = nullptr;
+    if (d->H == 8 && d->W == 8) {          // cell mode: four images per 16 x 16 tile, 64-wide output tiles (the 20 x 20 halos leave no room for the 128-wide ring)
+        a.tiles_y = a.tiles_x = 1; a.ntiles = d->N / 4; a.nnt = (d->Cout + 63) / 64;
+        // few pixels, long K: split the channel blocks over workgroups until the chip is full.  The partials live in a library-owned buffer
+        // (one stream at a time, like every workspace of this library); if it cannot be had (first use inside a stream capture) the layer runs unsplit.
+        static const int max_splits = getenv("SAUNET_MM_SPLITS") ? atoi(getenv("SAUNET_MM_SPLITS")) : 8;      // A/B switch
+        const int ncb = d->Cin / 64, items = a.ntiles * a.nnt;
+        int splits = 1;
+        while (splits * 2 <= max_splits && ncb % (splits * 2) == 0 && ncb / (splits * 2) >= 2 && items * splits * 2 <= 256) splits *= 2;
+        if (splits > 1) {
+            static float* ws = nullptr; static size_t ws_bytes = 0;
+            const size_t need = (size_t)items * splits * 32 * 512 * sizeof(float);
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(st, &cap);
+            if (cap == hipStreamCaptureStatusNone && need > ws_bytes) {
+                (void)hipDeviceSynchronize();
+                if (ws) (void)hipFree(ws);
+                ws = nullptr; ws_bytes = 0;
+                if (hipMalloc((void**)&ws, need) == hipSuccess) ws_bytes = need;
+                (void)hipGetLastError();
+            }
+            if (ws != nullptr && need <= ws_bytes) { a.splits = splits; a.ws = ws; }
+        }
+        if (int rc = launch_mm<64, true>(a, st)) return rc;
+        if (a.splits > 1) {
+            hipLaunchKernelGGL(conv3x3_mm_finish_kernel, dim3(items), dim3(512), 256 * 64 * 2 + 4 * 2 * 64 * 4 + 1024, st, a);
+            SAUNET_CHECK_LAUNCH("conv3x3_mm_finish");
+        }
+        return SAUNET_OK;
+    }
     a.tiles_y = d->H / 16; a.tiles_x = d->W / 16; a.ntiles = a.tiles_x * a.tiles_y * a.N;
     const int bn = mm_pick_bn(d);
     a.nnt = (d->Cout + bn - 1) / bn;

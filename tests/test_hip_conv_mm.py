@@ -28,6 +28,10 @@ CASES = [
     (9, 128, 32, 32, 256, 0, 0, False, False),     # 36 pixel tiles: not a multiple of 8 (plain block order), two n tiles
     (8, 128, 64, 64, 128, 0, 0, True, False),      # 128 x 1 workgroups >= 256? no: 128 -> BN 64 path with 2 n tiles; XCD-grouped order
     (16, 128, 64, 64, 128, 0, 0, False, False),    # 256 workgroups at BN = 128: the wide tile
+    # 8 x 8 maps (`center`): 2 x 2 image cells, every quadrant with its own zero border
+    (4, 128, 8, 8, 64, 0, 0, False, False),        # one cell, one n tile
+    (8, 256, 8, 8, 192, 64, 64, True, True),       # two cells, three n tiles, channel-slice views, bias + ReLU
+    (12, 1024, 8, 8, 512, 0, 0, True, False),      # the layer itself (16 channel blocks), 3 cells: plain block order
 ]
 
 
@@ -62,7 +66,7 @@ def test_conv_mm_forward_matches_float64(case):
         assert float((yw[:, :lye // 2].float() - 7).abs().max()) == 0 and float((yw[:, lye // 2 + cout:].float() - 7).abs().max()) == 0
 
 
-@pytest.mark.parametrize("case", [(2, 256, 32, 32, 128), (4, 512, 16, 16, 192), (2, 128, 16, 48, 128)])
+@pytest.mark.parametrize("case", [(2, 256, 32, 32, 128), (4, 512, 16, 16, 192), (2, 128, 16, 48, 128), (8, 256, 8, 8, 128)])     # last: 8 x 8 maps, cell mode
 def test_conv_mm_dgrad_matches_float64(case):
     """dx of y = conv3x3(x, w): Cin(dy side) = the forward's Cout >= 128 routes through the same kernel with the flipped packing"""
     n, cin, h, w, cout = case
