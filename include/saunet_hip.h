@@ -85,6 +85,11 @@ typedef struct saunet_bn_epilogue {
 int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                              const float* pro_scale, const float* pro_shift, void* y,
                              double* stat_sum, double* stat_sumsq, const saunet_bn_epilogue* epi, void* stream);
+/* saunet_bn_epilogue with bn_x == NULL and accumulate == 1 asks saunet_conv2d_forward_ex for  y += conv(x, w)  with no BatchNorm epilogue:
+ * the data gradient of a residual block's first convolution lands on top of the skip branch's gradient instead of being added by a separate
+ * pass (BasicBlock.forward `out += residual`, /root/reference/models/resnet.py:30-59 as used at models/models.py:316,322).  Only some
+ * geometries have a kernel for it; this returns 1 when `d` does (saunet_conv2d_forward_ex fails with SAUNET_UNSUPPORTED otherwise). */
+int saunet_conv2d_accumulate_supported(const saunet_conv_desc* d);
 /* Consumer-side BatchNorm finalize: y = conv(relu?(BN(x)), w) where the BatchNorm coefficients are derived INSIDE the convolution kernel from
  * the raw batch statistics its producer accumulated -- no saunet_bn_finalize launch in between (a DenseNet layer is then two launches
  * instead of four; torchvision _DenseLayer norm1/norm2 as used at /root/reference/models/models.py:306-313).

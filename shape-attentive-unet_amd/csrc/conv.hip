@@ -22,6 +22,7 @@ int igemm_forward(const saunet_conv_desc* d, const void* x, const void* w, const
                   void* y, double* ssum, double* ssq, const saunet_bn_epilogue* epi, hipStream_t st, const saunet_bn_prologue* bnp = nullptr);
 int igemm_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw, hipStream_t st);
 bool tile_fwd_supported(const saunet_conv_desc* d);
+bool tile_fwd_accumulate_supported(const saunet_conv_desc* d);
 bool mm_fwd_supported(const saunet_conv_desc* d, const void* x, const void* w, const void* y, const float* ps, const saunet_bn_epilogue* epi);
 int mm_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* ssum, double* ssq, hipStream_t st);
 bool tile_wgrad_supported(const saunet_conv_desc* d);
@@ -592,6 +593,11 @@ int saunet_conv2d_forward(const saunet_conv_desc* d, const void* x, const void* 
     return saunet_conv2d_forward_ex(d, x, w, bias, ps, psh, y, ssum, ssq, nullptr, stream);
 }
 
+int saunet_conv2d_accumulate_supported(const saunet_conv_desc* d)
+{
+    return igemm_supported(d) && tile_fwd_accumulate_supported(d) ? 1 : 0;
+}
+
 int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const void* w, const float* bias,
                              const float* ps, const float* psh, void* y, double* ssum, double* ssq,
                              const saunet_bn_epilogue* epi, void* stream)
@@ -606,6 +612,14 @@ int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const voi
     if ((ps == nullptr) != (psh == nullptr)) return set_error(SAUNET_BAD_SHAPE, "conv: prologue needs scale and shift");
     if (ssum == nullptr && dense_dgrad_supported(d, bias, ps, epi)) return dense_dgrad_forward(d, x, w, y, epi, st);
     if (ssum == nullptr && dense_dgrad3_supported(d, bias, ps, epi)) return dense_dgrad3_forward(d, x, w, y, epi, st);
+    if (epi && epi->bn_x == nullptr) {
+        // no BatchNorm epilogue: the structure only carries `accumulate` (y += conv), which the resident 3x3 kernel implements
+        if (!epi->accumulate) epi = nullptr;
+        else {
+            if (!saunet_conv2d_accumulate_supported(d)) return set_error(SAUNET_UNSUPPORTED, "conv: y += conv has no kernel for this geometry (saunet_conv2d_accumulate_supported)");
+            return tile_forward(d, x, w, bias, ps, psh, y, ssum, ssq, epi, st);
+        }
+    }
     if (mm_fwd_supported(d, x, w, y, ps, epi)) return mm_forward(d, x, w, bias, y, ssum, ssq, st);
     if (igemm_supported(d)) {
         if (epi && (((uintptr_t)epi->bn_x & 15) || epi->ld_bn_x % (d->dtype == SAUNET_BF16 ? 8 : 4)))

@@ -721,7 +721,17 @@ __global__ __launch_bounds__((256 / WM) * (BN / WN) * 64) void conv3x3_res_fwd_k
                 int p = tid + i * NT;
                 int row = p / CH, ch = p - row * CH;
                 size_t opix = (size_t)(ty0 + (row >> 4)) * a.W + tx0 + (row & 15);
-                if (cok) *(u32x4*)(yg + opix * a.ldy + colv) = *(const u32x4*)(so + row * BN + ch * EPC);
+                if (cok) {
+                    u32x4 v = *(const u32x4*)(so + row * BN + ch * EPC);
+                    if (a.epi.accumulate) {        // y += conv: the residual branch's gradient is already in y (block-uniform)
+                        float f[EPC], g[EPC];
+                        Vec16<T>::unpack(v, f); Vec16<T>::unpack(*(const u32x4*)(yg + opix * a.ldy + colv), g);
+#pragma unroll
+                        for (int j = 0; j < EPC; ++j) f[j] += g[j];
+                        v = Vec16<T>::pack(f);
+                    }
+                    *(u32x4*)(yg + opix * a.ldy + colv) = v;
+                }
             }
         }
         if (++c_txi == a.tiles_x) { c_txi = 0; if (++c_tyi == a.tiles_y) { c_tyi = 0; if (++c_n == a.N) { c_n = 0; ++c_nt; } } }
@@ -763,17 +773,25 @@ template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI> static int la
 }
 
 // does the resident-weight kernel apply, and with which tile?  (weights of one n-tile + one halo must fit in 160 KB)
+static bool res_fwd_applies(int elem_bytes, int Cin, int Cout, long tiles)
+{
+    const int EPC = 16 / elem_bytes;
+    const bool narrow = Cin <= 4 * EPC;
+    const int cpr = narrow ? 4 : 8;
+    const int ncb = (Cin + cpr * EPC - 1) / (cpr * EPC);
+    const int pitch = cpr * 16 + 16;
+    const int bn = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
+    const long halo_b = (long)HPITCH * res_halo_rowb(cpr), epi_b = 256L * bn * elem_bytes;
+    long lds = (halo_b > epi_b ? halo_b : epi_b) + (long)ncb * 9 * bn * pitch + 8 * 2 * bn * 4 + 2L * ncb * cpr * EPC * 4;   // (at most 8 wave slots)
+    return lds <= 154 * 1024 && tiles >= 32;   // even at one tile per block a single bulk weight load beats nine dependent per-tap loads
+}
+
 template <typename T> static int dispatch_res_fwd(const TileArgs& a, hipStream_t st, bool* handled)
 {
     constexpr int EPC = 16 / sizeof(T);
     const bool narrow = a.Cin <= 4 * EPC;
-    const int cpr = narrow ? 4 : 8;
-    const int ncb = (a.Cin + cpr * EPC - 1) / (cpr * EPC);
-    const int pitch = cpr * 16 + 16;
     const int bn = a.Cout <= 32 ? 32 : (a.Cout <= 64 ? 64 : 128);
-    const long halo_b = (long)HPITCH * res_halo_rowb(cpr), epi_b = 256L * bn * sizeof(T);
-    long lds = (halo_b > epi_b ? halo_b : epi_b) + (long)ncb * 9 * bn * pitch + 8 * 2 * bn * 4 + 2L * ncb * cpr * EPC * 4;   // (at most 8 wave slots)
-    *handled = lds <= 154 * 1024 && (a.tiles_x * a.tiles_y * a.N) >= 32;   // even at one tile per block a single bulk weight load beats nine dependent per-tap loads
+    *handled = res_fwd_applies((int)sizeof(T), a.Cin, a.Cout, (long)a.tiles_x * a.tiles_y * a.N);
     if (!*handled) return SAUNET_OK;
 #define RES(BN_, WM_, WN_, CPR_) (a.epi.bn_x ? launch_res_fwd_i<T, BN_, WM_, WN_, CPR_, true>(a, st) : launch_res_fwd_i<T, BN_, WM_, WN_, CPR_, false>(a, st))
     // 8 waves per block (one resident block per CU: the weights + one halo fill the LDS): twice the waves to hide the halo latency
@@ -781,6 +799,15 @@ template <typename T> static int dispatch_res_fwd(const TileArgs& a, hipStream_t
     if (bn == 64) return narrow ? RES(64, 64, 64, 4) : RES(64, 64, 32, 8);
     return narrow ? RES(128, 128, 64, 4) : RES(128, 128, 64, 8);
 #undef RES
+}
+
+// y += conv(x, w) (saunet_bn_epilogue with bn_x == NULL and accumulate == 1: a residual branch's gradient is already in y) is served by the
+// resident-weight kernel's plain epilogue only
+bool tile_fwd_accumulate_supported(const saunet_conv_desc* d)
+{
+    return !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->H % TILE == 0 && d->W % TILE == 0 && d->Ho == d->H &&
+           d->Wo == d->W && (d->dtype == SAUNET_BF16 || d->dtype == SAUNET_F32) &&
+           res_fwd_applies(d->dtype == SAUNET_BF16 ? 2 : 4, d->Cin, d->Cout, (long)d->N * (d->H / TILE) * (d->W / TILE));
 }
 
 bool tile_fwd_supported(const saunet_conv_desc* d)
@@ -796,7 +823,7 @@ int tile_forward(const saunet_conv_desc* d, const void* x, const void* w, const 
 {
     TileArgs a;
     if (bnp) a.bnp = *bnp; else a.bnp.gamma = nullptr;
-    if (epi) { a.epi = *epi; if (a.epi.sums_replicas < 1) a.epi.sums_replicas = 1; } else a.epi.bn_x = nullptr;
+    if (epi) { a.epi = *epi; if (a.epi.sums_replicas < 1) a.epi.sums_replicas = 1; } else { a.epi.bn_x = nullptr; a.epi.accumulate = 0; }
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.pro_scale = ps; a.pro_shift = psh; a.stat_sum = ssum; a.stat_sumsq = ssq;
     a.stat_replicas = d->stat_replicas > 1 ? d->stat_replicas : 1; a.stat_rstride = d->stat_rstride;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Cout = d->Cout; a.ldy = d->ldy;

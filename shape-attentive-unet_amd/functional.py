@@ -363,9 +363,14 @@ def igemm_ok(t, cin, cout):
     return cin % epc == 0 and cout % epc == 0 and cin >= epc and cout >= 8 and ld_of(t) % epc == 0
 
 
-def conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed=False, out=None, bn_epi=None):
+DGRAD_ACCUMULATE = os.environ.get("SAUNET_DGRAD_ACCUMULATE", "1") != "0"      # A/B switch: 0 = separate add pass behind every accumulating data gradient
+
+
+def conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed=False, out=None, bn_epi=None, accumulate=False):
     """dx of y = conv(x, weight): a forward convolution over dy with re-packed weights.
-    bn_epi = (bn_x, BNParams, relu, sums): fuse the reduction pass of the BatchNorm backward that consumes dx."""
+    bn_epi = (bn_x, BNParams, relu, sums): fuse the reduction pass of the BatchNorm backward that consumes dx.
+    accumulate (without bn_epi): out += dx where the library has a kernel for it (saunet_conv2d_accumulate_supported), else dx is computed
+    into a fresh tensor and added by a separate pass -- `out` holds the sum either way."""
     dy = nhwc(dy)
     n, cin, h, w = x_shape
     if out is None:
@@ -380,6 +385,18 @@ def conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed=False, out=None,
             raise RuntimeError("dgrad: only stride-1 convolutions need an input gradient on this path")
         wp = PACKS.get(weight, L.PACK_DGRAD, dy.dtype)
         d = _desc(dy, cin, ld_of(out), h, w, kh, kw, 1, kh - 1 - pad)
+    if accumulate and bn_epi is None:
+        if transposed or not DGRAD_ACCUMULATE or not L.load().saunet_conv2d_accumulate_supported(C.byref(d)):
+            tmp = conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed)
+            copy_channels(tmp, out, accumulate=True)
+            return out
+        e = L.BnEpilogue()
+        e.bn_x, e.ld_bn_x, e.relu, e.accumulate = None, 0, 0, 1
+        e.scale = e.shift = e.mean = e.invstd = None
+        e.sums, e.sums_replicas, e.sums_rstride = None, 1, 0
+        L.call("saunet_conv2d_forward_ex", C.byref(d), dy.data_ptr(), wp.data_ptr(), None, None, None, out.data_ptr(), None, None,
+               C.byref(e), L.stream())
+        return out
     if bn_epi is not None:
         bx, p, relu, sums = bn_epi[:4]
         e = L.BnEpilogue()
@@ -813,8 +830,7 @@ class _BasicBlock(torch.autograd.Function):
         dw1 = conv_wgrad_raw(x, dz1, w1, 1, 1)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = conv_dgrad_raw(dz1, w1, x.shape, 1, 1)
-            copy_channels(dres, dx, accumulate=True)
+            dx = conv_dgrad_raw(dz1, w1, x.shape, 1, 1, out=dres, accumulate=True)      # on top of the skip branch's gradient
         return dx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None, None
 
 

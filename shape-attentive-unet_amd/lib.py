@@ -72,6 +72,7 @@ _SIGS = {
     "saunet_pack_weight_multi": [C.POINTER(PackList), i32, vp],
     "saunet_conv2d_forward": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "saunet_conv2d_forward_ex": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(BnEpilogue), vp],
+    "saunet_conv2d_accumulate_supported": [C.POINTER(ConvDesc)],
     "saunet_conv2d_forward_bnpro": [C.POINTER(ConvDesc), vp, vp, vp, C.POINTER(BnPrologue), vp, vp, vp, vp],
     "saunet_bn_xhat": [i32, vp, vp, i32, i32, f64, f32, vp, i32, vp],
     "saunet_conv2d_wgrad": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i64, vp],

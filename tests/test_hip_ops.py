@@ -457,3 +457,22 @@ def test_multi_tensor_packing_matches_torch_permutes(dtype):
     torch.cuda.synchronize()
     for (mode, w, ref, dims), out in zip(cases, outs):
         assert torch.equal(out, ref.contiguous().reshape(-1).to(dtype)), (mode, dims)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(4, 64, 128, 128, 64), (2, 32, 64, 128, 32), (1, 16, 256, 256, 16), (2, 64, 16, 16, 64), (2, 256, 32, 32, 128)])
+def test_conv_dgrad_accumulates_onto_the_residual_gradient(dtype, shape):
+    """out += dgrad(dy, w) (BasicBlock backward: the skip branch's gradient is already in `out`; /root/reference/models/resnet.py:30-59): the first
+    three geometries have the fused epilogue (saunet_conv2d_accumulate_supported), the others take the separate add -- same result contract."""
+    hf = HF()
+    n, cin, h, w, cout = shape
+    wt = rnd(cout, cin, 3, 3, scale=0.05, seed=2)
+    dy = rnd(n, cout, h, w, seed=3)
+    base = rnd(n, cin, h, w, seed=4)
+    out = to_dev(base, dtype)
+    got = hf.conv_dgrad_raw(to_dev(dy, dtype), wt.cuda(), (n, cin, h, w), 1, 1, out=out, accumulate=True)
+    assert got.data_ptr() == out.data_ptr()
+    xr = torch.zeros(n, cin, h, w, requires_grad=True)
+    F.conv2d(xr, q(wt, dtype), None, 1, 1).backward(q(dy, dtype))
+    ref = q(base, dtype) + xr.grad
+    close(out, ref, TOL[dtype] * (2 if dtype == torch.bfloat16 else 1), "out += dx")
