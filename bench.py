@@ -132,21 +132,16 @@ def kernel_roofline(S, dtype, batch, size, launch_mix=True):
 
 
 def weakest_family_roofline(S, dtype, batch, size):
-    """Second roofline entry: the WEAKEST large kernel family of the step next to the healthiest one -- the tiled 3x3 weight
-    gradient of the MFMA-bound decoder convolutions (conv_tile_wgrad_kernel<bf16, 3, 8, 64, 64, 32, 32, 1>: 17-24 % of the matrix-core peak;
-    bound by its transposing LDS fragment reads, one fresh fragment per MFMA).  Probe: dec3.c3x3rb (512 -> 128 at (size/4)^2), timed live with
-    HIP events; FLOPs 2 * P * 9 * Cin * Cout, arithmetic intensity far above the ridge, so it is priced against the MFMA peak.  Also the
-    LDS-DMA forward kernel of the same layer (conv3x3_mm_kernel) for comparison."""
+    """Second roofline entry: the WEAKEST large MFMA-priced kernel family of the step next to the healthiest one.  Three candidates
+    are timed live with HIP events at the step's geometry and the one with the lowest fraction of the dense matrix-core peak is reported (all
+    three are listed under `candidates`):
+      * dec3.c3x3rb weight gradient (512 -> 128 at (size/4)^2; conv3x3_wgrad_mm_kernel + its partial-gradient reduce) -- round 3's weakest,
+      * res1 forward (64 -> 64 at size^2; conv3x3_res_fwd_kernel: LDS-read bound, 288 FLOP/B sits AT the ridge, so the HBM fraction is given too),
+      * dec2.c3x3rb forward (256 -> 64 at (size/2)^2; conv3x3_mm_kernel with the 64-wide tile).
+    FLOPs = 2 * P * 9 * Cin * Cout.  `same_layer_forward` keeps the LDS-DMA forward of dec3 for comparison."""
     HF = S.functional
-    h = size // 4
-    cin, cout = 512, 128
-    x = torch.randn(batch, cin, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
-    dy = torch.randn(batch, cout, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
-    w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device="cuda") * 0.03)
-    out = HF.new_act(batch, cout, h, h, dtype, "cuda")
-    st = torch.zeros(HF.STAT_R, 2, cout, dtype=torch.float64, device="cuda")
-    fl = 2.0 * batch * h * h * 9 * cin * cout
     peak = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
+    esz = 2 if dtype == torch.bfloat16 else 4
 
     def timed(fn, reps=10):
         for _ in range(3):
@@ -158,14 +153,33 @@ def weakest_family_roofline(S, dtype, batch, size):
             fn()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
-    ms_w = timed(lambda: (HF.GRADS.reset(), HF.conv_wgrad_raw(x, dy, w, 1, 1)))
-    ms_f = timed(lambda: HF.conv_forward_raw(x, w, None, 1, 1, out=out, stats=st))
-    HF.GRADS.reset()
-    tf_w, tf_f = fl / (ms_w * 1e-3) / 1e12, fl / (ms_f * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": round(tf_w, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf_w / peak, 4), "ms": round(ms_w, 4),
-            "kernel": "conv_tile_wgrad 3x3 %d->%d @%dx%d B%d (dec3.c3x3rb weight gradient, incl. its partial-gradient reduce)" % (cin, cout, h, h, batch),
-            "flops": fl, "same_layer_forward": {"kernel": "conv3x3_mm_kernel (LDS-DMA staged)", "ms": round(ms_f, 4), "achieved": round(tf_f, 1),
-                                               "frac": round(tf_f / peak, 4)}}
+
+    def probe(cin, cout, h, wgrad):
+        x = torch.randn(batch, cin, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+        w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device="cuda") * 0.03)
+        fl = 2.0 * batch * h * h * 9 * cin * cout
+        if wgrad:
+            dy = torch.randn(batch, cout, h, h, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+            ms = timed(lambda: (HF.GRADS.reset(), HF.conv_wgrad_raw(x, dy, w, 1, 1)))
+            HF.GRADS.reset()
+        else:
+            out = HF.new_act(batch, cout, h, h, dtype, "cuda")
+            st = torch.zeros(HF.STAT_R, 2, cout, dtype=torch.float64, device="cuda")
+            ms = timed(lambda: HF.conv_forward_raw(x, w, None, 1, 1, out=out, stats=st))
+        tf = fl / (ms * 1e-3) / 1e12
+        byts = batch * h * h * (cin + cout) * esz
+        return {"ms": round(ms, 4), "achieved": round(tf, 1), "frac": round(tf / peak, 4), "flops": fl,
+                "hbm_frac": round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    cands = [
+        dict(probe(512, 128, size // 4, True), kernel="conv3x3_wgrad_mm 3x3 512->128 @%dx%d B%d (dec3.c3x3rb weight gradient, incl. its partial-gradient reduce)" % (size // 4, size // 4, batch)),
+        dict(probe(64, 64, size, False), kernel="conv3x3_res_fwd 3x3 64->64 @%dx%d B%d (res1 forward)" % (size, size, batch)),
+        dict(probe(256, 64, size // 2, False), kernel="conv3x3_mm<64> 3x3 256->64 @%dx%d B%d (dec2.c3x3rb forward)" % (size // 2, size // 2, batch)),
+    ]
+    fwd3 = probe(512, 128, size // 4, False)
+    worst = min(cands, key=lambda c: c["frac"])
+    return {"bound": "mfma", "achieved": worst["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": worst["frac"], "ms": worst["ms"], "kernel": worst["kernel"],
+            "flops": worst["flops"], "hbm_frac": worst["hbm_frac"], "candidates": cands,
+            "same_layer_forward": {"kernel": "conv3x3_mm_kernel 512->128 (LDS-DMA staged, dec3)", "ms": fwd3["ms"], "achieved": fwd3["achieved"], "frac": fwd3["frac"]}}
 
 
 def step_roofline(args, ms_per_step):

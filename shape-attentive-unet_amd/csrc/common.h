@@ -214,6 +214,22 @@ __device__ __forceinline__ void rep_sum2(const double* __restrict__ a, const dou
     sa = va; sb = vb;
 }
 
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ float dpp_add(float v)
+{
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __int_as_float(moved);
+}
+// sum over the 32 lanes of each wave half; valid in lanes 16..31 and 48..63
+__device__ __forceinline__ float half_wave_sum(float v)
+{
+    v = dpp_add<0xB1>(v);          // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);          // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);         // row_half_mirror
+    v = dpp_add<0x140>(v);         // row_mirror  -> every lane of a 16-lane row holds the row sum
+    v = dpp_add<0x142>(v);         // row_bcast:15: rows 1 and 3 += the sum of the row before (bound_ctrl: row 0 adds 0; row 2 is not used)
+    return v;
+}
+
 // keep + (send of the partner lane under the DPP permutation CTRL)
 template <int CTRL> __device__ __forceinline__ float dpp_exchange_add(float keep, float send)
 {
