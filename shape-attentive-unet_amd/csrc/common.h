@@ -107,6 +107,16 @@ __device__ __forceinline__ void mma_f32_chunk_split(const u32x4& a, const u32x4&
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a2), __builtin_bit_cast(bf16x8_t, b12), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1), __builtin_bit_cast(bf16x8_t, b12), c, 0, 0, 0);
 }
+// the same with both operands split beforehand (a fragment that feeds several products is split once)
+__device__ __forceinline__ void mma_f32_split_pre(const F32Split& A, const F32Split& B, f32x16& c)
+{
+    const u32x4 a3 = {A.h01, A.h23, A.l01, A.l23}, b3 = {B.l01, B.l23, B.h01, B.h23};
+    const u32x4 a2 = {A.m01, A.m23, A.m01, A.m23}, b12 = {B.h01, B.h23, B.m01, B.m23};
+    const u32x4 a1 = {A.h01, A.h23, A.h01, A.h23};
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a3), __builtin_bit_cast(bf16x8_t, b3), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a2), __builtin_bit_cast(bf16x8_t, b12), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1), __builtin_bit_cast(bf16x8_t, b12), c, 0, 0, 0);
+}
 __device__ __forceinline__ void mma_f32_chunk_exact(const u32x4& a, const u32x4& b, f32x16& c)
 {
 #pragma unroll

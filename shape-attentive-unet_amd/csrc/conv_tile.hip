@@ -1116,6 +1116,35 @@ __device__ __forceinline__ void tile_wgrad_body(const TileWgradArgs& a, const in
                             acc[m][nn][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[m]), __builtin_bit_cast(bf16x8_t, bf), acc[m][nn][j], 0, 0, 0);
                     }
                 }
+            } else if constexpr (std::is_same<T, f32s>::value) {
+                // float32 storage, 3 x bf16 split products (common.h): K = 8 pixels per step, a lane half holds 4 consecutive pixels of its channel;
+                // the dy fragment is split once per step, every x fragment once per (tap, channel tile)
+                const int lr = lane & 31, lh = lane >> 5;
+                static_assert(!TS || sizeof(T) == 2, "tap split: bf16 only");
+#pragma unroll
+                for (int k = 0; k < TILE; k += 8) {
+                    F32Split As[MI];
+#pragma unroll
+                    for (int m = 0; m < MI; ++m) {
+                        u32x4 v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = *(const unsigned*)(s_y + (ty * TILE + k + 4 * lh + j) * PY + (wm0 + m * 32 + lr) * 4);
+                        As[m] = f32_split3(v);
+                    }
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t) {
+                        const int kh = t / KS, kw = t - kh * KS;
+#pragma unroll
+                        for (int nn = 0; nn < NI; ++nn) {
+                            u32x4 v;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = *(const unsigned*)(s_x + ((ty + kh + kh0) * HC + kw + kw0 + k + 4 * lh + j) * PX + (wn0 + nn * 32 + lr) * 4);
+                            const F32Split Bs = f32_split3(v);
+#pragma unroll
+                            for (int m = 0; m < MI; ++m) mma_f32_split_pre(As[m], Bs, acc[m][nn][t]);
+                        }
+                    }
+                }
             } else {
                 const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -1889,6 +1918,13 @@ int tile_wgrad_grouped(const saunet_wgrad_group* s, void* ws, size_t ws_bytes, s
         if (small) return launch_tile_wgrad_grouped<u16, 1, 16, 64, 64, 64, 64, 4>(g, s, ws, ws_bytes, need, st);
         return launch_tile_wgrad_grouped<u16, 1, 8, 128, 128, 64, 64, 1>(g, s, ws, ws_bytes, need, st);
     }
+    if (f32_split_wanted((long)s->N * s->H * s->W)) {
+        if (s->KH == 3) {
+            if (small) return launch_tile_wgrad_grouped<f32s, 3, 16, 32, 32, 32, 32, 4>(g, s, ws, ws_bytes, need, st);
+            return launch_tile_wgrad_grouped<f32s, 3, 8, 64, 64, 32, 32, 1>(g, s, ws, ws_bytes, need, st);
+        }
+        return launch_tile_wgrad_grouped<f32s, 1, 8, 64, 64, 32, 32, 1>(g, s, ws, ws_bytes, need, st);
+    }
     if (s->KH == 3) {
         if (small) return launch_tile_wgrad_grouped<float, 3, 16, 32, 32, 32, 32, 4>(g, s, ws, ws_bytes, need, st);
         return launch_tile_wgrad_grouped<float, 3, 8, 64, 64, 32, 32, 1>(g, s, ws, ws_bytes, need, st);
@@ -1918,6 +1954,7 @@ int tile_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const f
         return launch_wgrad_mm(a, ws_bytes, need, st);
     }
     if (d->dtype == SAUNET_BF16) return dispatch_tile_wgrad<u16>(a, d->KH, aligned, ws_bytes, need, st);
+    if (d->dtype == SAUNET_F32 && aligned && f32_split_wanted((long)d->N * d->H * d->W)) return dispatch_tile_wgrad<f32s>(a, d->KH, aligned, ws_bytes, need, st);
     if (d->dtype == SAUNET_F32) return dispatch_tile_wgrad<float>(a, d->KH, aligned, ws_bytes, need, st);
     return set_error(SAUNET_BAD_DTYPE, "wgrad: dtype %d", d->dtype);
 }
