@@ -207,7 +207,7 @@ def test_duplicated_batch_invariance_at_bench_batches(dtype, B):
             assert all(torch.isfinite(g).all() for g in out[rep][2].values())
             del net, sm, feed, loss
             torch.cuda.empty_cache()
-        rtol = 2e-3 if dtype == torch.bfloat16 else 1e-5
+        rtol = 3e-4 if dtype == torch.bfloat16 else 1e-5            # measured (profiles/r04_duplicated_batch.txt): 5.4e-5 / 0
         assert abs(out[1][0] - out[2][0]) < rtol * out[1][0], (out[1][0], out[2][0])
         assert abs(out[1][1] - out[2][1]) < 1e-3
         gmax = max(float(g.abs().max()) for g in out[1][2].values())
@@ -216,7 +216,14 @@ def test_duplicated_batch_invariance_at_bench_batches(dtype, B):
         worst = max((float((out[2][2][k] - g).norm() / max(float(g.norm()), 1e-3 * gmax * g.numel() ** 0.5)), k) for k, g in out[1][2].items())
         # bf16: the two runs differ in the summation order of the float64 statistic atomics -> a few flipped roundings that the deep blocks
         # amplify (the same sensitivity the bf16-emulated oracle shows); float32: summation-order noise only
-        assert worst[0] < (0.35 if dtype == torch.bfloat16 else 5e-3), worst
+        try:      # the measured value next to the gate (gpurun merges gpurun_out/ back)
+            os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+            with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r04_duplicated_batch.txt"), "a") as f:
+                f.write("%s B=%d: loss %.6f vs %.6f, worst gradient tensor %s rel-L2 %.4f\n" % (str(dtype), B, out[1][0], out[2][0], worst[1], worst[0]))
+        except OSError:
+            pass
+        # measured over three runs (profiles/r04_duplicated_batch.txt): bf16 0.065 (denseblock2.denselayer1.conv2.weight, every run), float32 2e-4 .. 8e-4
+        assert worst[0] < (0.10 if dtype == torch.bfloat16 else 2e-3), worst
         if dtype == torch.bfloat16:
             torch.set_num_threads(min(os.cpu_count() or 8, 32))
             with torch.no_grad():
