@@ -1,4 +1,4 @@
-"""Run ONE conv geometry a few times (for rocprofv3 PMC passes): python scripts/one_kernel.py conv2|conv1|res1|dec2..dec5|center|mrfup5|mrfup3 [reps]"""
+"""Run ONE conv geometry a few times (for rocprofv3 PMC passes): python scripts/one_kernel.py conv2|conv1|res1|dec2..dec5|center|mrfup5|mrfup3|conv2dgrad|conv1dgrad [reps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
