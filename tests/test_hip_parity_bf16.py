@@ -110,8 +110,9 @@ def test_bf16_gradients_at_256_against_exact_and_bf16_emulated_oracle():
             lines.append("%-14s %4d | %8.4f %8.4f %8.4f | %8.4f %8.4f %8.4f" % (g, len(h), hm, hmin, hrel, em, emin, erel))
             if g in ("norm0", "expand"):
                 continue          # 1-3 parameters whose exact gradient is a near-cancellation (|g| ~ 1e-5 of the scale): direction is noise in any bf16 run
-            # margins = the measured worst gaps + 25 %: three runs gave 0.027-0.028 (median) and 0.047-0.049 (minimum), both in `center` (round 3: 0.05 / 0.12)
-            if hm < em - 0.035 or hmin < emin - 0.062:
+            # margins = the measured worst gaps + 40 %: five runs on three boxes gave 0.025-0.029 (median) and 0.046-0.049 (minimum), both in `center`
+            # (round 3: 0.05 / 0.12)
+            if hm < em - 0.04 or hmin < emin - 0.07:
                 bad.append("%s: HIP median/min cosine %.4f/%.4f below the bf16 emulation's %.4f/%.4f" % (g, hm, hmin, em, emin))
             if g in GROUPS_BENIGN and hmin < 0.99:
                 bad.append("%s: min cosine %.4f < 0.99 in a group that is benign under bf16 storage" % (g, hmin))
