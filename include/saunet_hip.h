@@ -48,6 +48,10 @@ typedef struct saunet_conv_desc {
      * in the cross-XCD atomic path (+40 us on a 4096-block launch); 16 replicas remove that.  0/1 = single copy. */
     int32_t stat_replicas, stat_rstride;
     int32_t epi_relu;              /* epilogue: y = max(conv + bias, 0) -- inference with BatchNorm folded into weights and bias */
+    /* Optional caller-owned scratch for the forward entry points (saunet_conv2d_forward / _ex / _bnpro): at least
+     * saunet_conv2d_forward_workspace(d) bytes, 16-byte aligned, private to this call until it has completed on `stream`.  NULL / too small:
+     * the launch uses a kernel selection that needs none (same result up to the float32 summation order). */
+    void* workspace; int64_t workspace_bytes;
 } saunet_conv_desc;
 
 const char* saunet_last_error(void);
@@ -67,6 +71,9 @@ int saunet_pack_weight_multi(const saunet_pack_list* pl, int dtype, void* stream
 /* y = conv(prologue(x), w) (+bias).  If stat_sum/stat_sumsq are non-NULL, per-output-channel
  * sums of the un-biased accumulator and its square are ATOMICALLY added (float64) -- the batch
  * statistics BatchNorm needs, taken in the producer's epilogue. */
+/* bytes of workspace the forward of `d` can use (0 = none).  Today only the 8 x 8 `center` geometry asks for one: its 3x3 convolution and
+ * data gradient (models/models.py:316) split K over workgroups and keep the float32 partials there (csrc/conv_mm.hip, cell mode). */
+int64_t saunet_conv2d_forward_workspace(const saunet_conv_desc* d);
 int saunet_conv2d_forward(const saunet_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                           const float* pro_scale, const float* pro_shift, void* y,
                           double* stat_sum, double* stat_sumsq, void* stream);

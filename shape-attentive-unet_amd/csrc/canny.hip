@@ -222,11 +222,10 @@ extern "C" int saunet_canny(int dtype, const float* image, int N, int H, int W, 
     if (dtype != SAUNET_F32 && dtype != SAUNET_BF16) return set_error(SAUNET_BAD_DTYPE, "canny: dtype %d", dtype);
     const size_t map_bytes = (size_t)H * W;
     if (map_bytes <= 152 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static DeviceOnce attr;
+        if (attr.first()) {
             (void)hipFuncSetAttribute((const void*)canny_hyst_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
             (void)hipFuncSetAttribute((const void*)canny_hyst_kernel<u16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-            attr_set = true;
         }
         // candidate list behind the byte map: up to a quarter of the pixels (weak candidates are typically < 5 %), within the LDS budget
         const size_t map_al = (map_bytes + 15) & ~(size_t)15;

@@ -192,6 +192,46 @@ struct FastDiv {
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// ---- A/B switches.  The PRODUCT build has none: the library's behaviour is a function of its arguments only (include/saunet_hip.h:
+// "no global mutable state").  A variant build (scripts/build_variant.sh ... -DSAUNET_AB_SWITCHES) reads the named environment variables
+// once per process so that two kernel selections can be compared on one box.
+#ifdef SAUNET_AB_SWITCHES
+#include <stdlib.h>
+inline bool ab_env_on(const char* name) { const char* v = getenv(name); return !(v && v[0] == '0'); }      // default on, "0" = off
+inline int ab_env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+inline bool ab_env_on(const char*) { return true; }
+inline int ab_env_int(const char*, int dflt) { return dflt; }
+#endif
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: first() is true once per (call site, device).  A lost race sets the
+// attribute twice, which is harmless.
+struct DeviceOnce {
+    unsigned long long done = 0;
+    bool first()
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (__atomic_load_n(&done, __ATOMIC_RELAXED) & bit) return false;
+        __atomic_fetch_or(&done, bit, __ATOMIC_RELAXED);
+        return true;
+    }
+};
+// the same for launch sites whose requirement grows with the problem: true when `lds` exceeds what this device was last given
+struct DeviceMaxLds {
+    int seen[64] = {0};
+    bool raise(int lds)
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        int& s = seen[dev & 63];
+        if (lds <= s) return false;
+        s = lds;
+        return true;
+    }
+};
+
 // sum over the replicated accumulators (saunet_bn_epilogue.sums_replicas): 8 loads in flight at a time -- these are pure latency chains
 // (one thread per channel), a one-load-per-iteration loop costs 16 memory round trips
 __device__ __forceinline__ double rep_sum(const double* __restrict__ s, int reps, int rstride, int i)

@@ -1,7 +1,6 @@
 // C-ABI front for the convolution family: weight packing, dispatch between the MFMA implicit-GEMM
 // kernels (conv_igemm.hip) and the small-channel pointwise kernels below, bias gradient.
 #include "common.h"
-#include <stdlib.h>
 #include "mma_tiles.h"
 
 namespace saunet {
@@ -25,6 +24,7 @@ bool tile_fwd_supported(const saunet_conv_desc* d);
 bool tile_fwd_accumulate_supported(const saunet_conv_desc* d);
 bool mm_fwd_supported(const saunet_conv_desc* d, const void* x, const void* w, const void* y, const float* ps, const saunet_bn_epilogue* epi);
 int mm_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* ssum, double* ssq, hipStream_t st);
+int64_t mm_forward_workspace(const saunet_conv_desc* d);
 bool tile_wgrad_supported(const saunet_conv_desc* d);
 bool tile_wgrad_unaligned_supported(const saunet_conv_desc* d);
 // MFMA tile wgrad with scalar staging for odd channel counts: correct, but measured SLOWER than pointwise_wgrad_kernel
@@ -593,6 +593,11 @@ int saunet_conv2d_forward(const saunet_conv_desc* d, const void* x, const void* 
     return saunet_conv2d_forward_ex(d, x, w, bias, ps, psh, y, ssum, ssq, nullptr, stream);
 }
 
+int64_t saunet_conv2d_forward_workspace(const saunet_conv_desc* d)
+{
+    return mm_forward_workspace(d);
+}
+
 int saunet_conv2d_accumulate_supported(const saunet_conv_desc* d)
 {
     return igemm_supported(d) && tile_fwd_accumulate_supported(d) ? 1 : 0;
@@ -704,7 +709,7 @@ int saunet_conv2d_forward_bnpro(const saunet_conv_desc* d, const void* x, const 
 // A/B switch: SAUNET_CONVT_WGRAD_DIRECT=0 sends ConvTranspose2d weight gradients back to the generic path
 static bool convt_direct(const saunet_conv_desc* d)
 {
-    static const bool on = !(getenv("SAUNET_CONVT_WGRAD_DIRECT") && getenv("SAUNET_CONVT_WGRAD_DIRECT")[0] == '0');
+    static const bool on = ab_env_on("SAUNET_CONVT_WGRAD_DIRECT");
     return on && tile_wgrad_convt_supported(d);
 }
 

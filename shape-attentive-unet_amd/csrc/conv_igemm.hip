@@ -13,7 +13,6 @@
 // Replaces F.conv2d / F.conv_transpose2d and their autograd backward in the reference
 // (/root/reference/models/models.py:118-123,203-237; attention_blocks.py:179-220; torchvision DenseNet).
 #include "common.h"
-#include <stdlib.h>
 
 namespace saunet {
 
@@ -366,11 +365,8 @@ static int launch_fwd_i(const IgemmArgs& a, int phases, hipStream_t st)
     const int pro_bytes = (a.pro_scale || a.bnp.gamma) ? 2 * a.kpt * CPR * EPC_ * 4 : 0;      // prologue scale/shift vectors behind the two stages
     const int LDS = (2 * STAGE + pro_bytes > EPI) ? 2 * STAGE + pro_bytes : EPI;
     auto kern = conv_igemm_fwd_kernel<T, BM, BN, WM, WN, CPR, BNEPI>;
-    static int attr_lds = 0;
-    if (LDS > attr_lds) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_lds = LDS;
-    }
+    static DeviceMaxLds attr;
+    if (attr.raise(LDS)) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     dim3 grid(cdiv(a.M, BM), cdiv(a.Cout, BN), phases);
     hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, st, a);
     SAUNET_CHECK_LAUNCH("conv_igemm_fwd");

@@ -16,7 +16,6 @@
 //
 // bf16 storage only; float32 storage keeps conv3x3_tile_fwd_kernel (exact f32 MFMA).
 #include "common.h"
-#include <stdlib.h>
 #include <type_traits>
 
 namespace saunet {
@@ -329,8 +328,8 @@ template <int BN, bool CELL = false> static int launch_mm(const MmArgs& a, hipSt
     constexpr int LDS = 2 * MmHalo<CELL>::BYTES + MM_RING * BN * 128 + 1024;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     auto kern = conv3x3_mm_kernel<BN, CELL>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    static DeviceOnce attr;
+    if (attr.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     hipLaunchKernelGGL(kern, dim3(a.ntiles * a.nnt * (CELL ? a.splits : 1)), dim3(512), LDS, st, a);
     SAUNET_CHECK_LAUNCH("conv3x3_mm");
     return SAUNET_OK;
@@ -339,7 +338,7 @@ template <int BN, bool CELL = false> static int launch_mm(const MmArgs& a, hipSt
 // which of the two output-channel tiles: 128 unless that leaves CUs idle (fewer than 256 workgroups) and 64 does better
 static int mm_pick_bn(const saunet_conv_desc* d)
 {
-    static const int force = getenv("SAUNET_MM_BN") ? atoi(getenv("SAUNET_MM_BN")) : 0;      // A/B switch
+    static const int force = ab_env_int("SAUNET_MM_BN", 0);      // A/B switch (variant builds only)
     if (force == 64 || force == 128) return force;
     if (d->Cout <= 64) return 64;
     const long tiles = (long)d->N * (d->H / 16) * (d->W / 16);
@@ -347,16 +346,40 @@ static int mm_pick_bn(const saunet_conv_desc* d)
     return b128 < 256 ? 64 : 128;
 }
 
+static bool mm_cell_geometry(const saunet_conv_desc* d)
+{
+    static const bool cell_on = ab_env_on("SAUNET_MM_CELL");        // A/B switch (variant builds only)
+    return cell_on && d->H == 8 && d->W == 8 && d->N % 4 == 0;          // 8 x 8 maps: 2 x 2 image cells
+}
+
 bool mm_fwd_supported(const saunet_conv_desc* d, const void* x, const void* w, const void* y, const float* ps, const saunet_bn_epilogue* epi)
 {
-    static const bool on = !(getenv("SAUNET_CONV_MM") && getenv("SAUNET_CONV_MM")[0] == '0');             // A/B switch
-    static const int min_cin = getenv("SAUNET_MM_MINCIN") ? atoi(getenv("SAUNET_MM_MINCIN")) : 128;
-    static const bool cell_on = !(getenv("SAUNET_MM_CELL") && getenv("SAUNET_MM_CELL")[0] == '0');        // A/B switch
-    const bool cell = cell_on && d->H == 8 && d->W == 8 && d->N % 4 == 0;          // 8 x 8 maps: 2 x 2 image cells
+    static const bool on = ab_env_on("SAUNET_CONV_MM");             // A/B switch (variant builds only)
+    static const int min_cin = ab_env_int("SAUNET_MM_MINCIN", 128);
     return on && d->dtype == SAUNET_BF16 && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
-           ((d->H % 16 == 0 && d->W % 16 == 0) || cell) && d->Ho == d->H && d->Wo == d->W && ps == nullptr && (epi == nullptr || epi->bn_x == nullptr) && d->Cin % 64 == 0 &&
+           ((d->H % 16 == 0 && d->W % 16 == 0) || mm_cell_geometry(d)) && d->Ho == d->H && d->Wo == d->W && ps == nullptr && (epi == nullptr || epi->bn_x == nullptr) && d->Cin % 64 == 0 &&
            d->Cin >= min_cin && d->Cin <= 2048 && d->Cout % 8 == 0 && d->Cout >= 64 && d->ldx % 8 == 0 && d->ldy % 8 == 0 &&
            !(((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) && (long)d->N * d->H * d->W * d->ldx < (1L << 30);
+}
+
+// cell mode (8 x 8 maps): few pixels, long K -- the channel blocks are split over workgroups until the chip is full.  -> number of splits
+static int mm_cell_splits(const saunet_conv_desc* d, int* items_out)
+{
+    static const int max_splits = ab_env_int("SAUNET_MM_SPLITS", 8);      // A/B switch (variant builds only)
+    const int ncb = d->Cin / 64, items = (d->N / 4) * ((d->Cout + 63) / 64);
+    int splits = 1;
+    while (splits * 2 <= max_splits && ncb % (splits * 2) == 0 && ncb / (splits * 2) >= 2 && items * splits * 2 <= 256) splits *= 2;
+    if (items_out) *items_out = items;
+    return splits;
+}
+
+// bytes of caller-owned workspace the forward of `d` can use (saunet_conv2d_forward_workspace): the split-K partials of cell mode
+int64_t mm_forward_workspace(const saunet_conv_desc* d)
+{
+    if (!mm_fwd_supported(d, nullptr, nullptr, nullptr, nullptr, nullptr) || !(d->H == 8 && d->W == 8)) return 0;
+    int items = 0;
+    const int splits = mm_cell_splits(d, &items);
+    return splits > 1 ? (int64_t)items * splits * 32 * 512 * (int64_t)sizeof(float) : 0;
 }
 
 int mm_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* ssum, double* ssq, hipStream_t st)
@@ -368,25 +391,13 @@ int mm_forward(const saunet_conv_desc* d, const void* x, const void* w, const fl
     a.splits = 1; a.ws = nullptr;
     if (d->H == 8 && d->W == 8) {          // cell mode: four images per 16 x 16 tile, 64-wide output tiles (the 20 x 20 halos leave no room for the 128-wide ring)
         a.tiles_y = a.tiles_x = 1; a.ntiles = d->N / 4; a.nnt = (d->Cout + 63) / 64;
-        // few pixels, long K: split the channel blocks over workgroups until the chip is full.  The partials live in a library-owned buffer
-        // (one stream at a time, like every workspace of this library); if it cannot be had (first use inside a stream capture) the layer runs unsplit.
-        static const int max_splits = getenv("SAUNET_MM_SPLITS") ? atoi(getenv("SAUNET_MM_SPLITS")) : 8;      // A/B switch
-        const int ncb = d->Cin / 64, items = a.ntiles * a.nnt;
-        int splits = 1;
-        while (splits * 2 <= max_splits && ncb % (splits * 2) == 0 && ncb / (splits * 2) >= 2 && items * splits * 2 <= 256) splits *= 2;
-        if (splits > 1) {
-            static float* ws = nullptr; static size_t ws_bytes = 0;
-            const size_t need = (size_t)items * splits * 32 * 512 * sizeof(float);
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(st, &cap);
-            if (cap == hipStreamCaptureStatusNone && need > ws_bytes) {
-                (void)hipDeviceSynchronize();
-                if (ws) (void)hipFree(ws);
-                ws = nullptr; ws_bytes = 0;
-                if (hipMalloc((void**)&ws, need) == hipSuccess) ws_bytes = need;
-                (void)hipGetLastError();
-            }
-            if (ws != nullptr && need <= ws_bytes) { a.splits = splits; a.ws = ws; }
+        // The partials live in the CALLER's workspace (saunet_conv_desc.workspace, sized by saunet_conv2d_forward_workspace); a call
+        // without one -- or with one that is too small or misaligned -- runs the layer unsplit (same result up to the summation order).
+        int items = 0;
+        const int splits = mm_cell_splits(d, &items);
+        const int64_t need = (int64_t)items * splits * 32 * 512 * (int64_t)sizeof(float);
+        if (splits > 1 && d->workspace != nullptr && d->workspace_bytes >= need && ((uintptr_t)d->workspace & 15) == 0) {
+            a.splits = splits; a.ws = (float*)d->workspace;
         }
         if (int rc = launch_mm<64, true>(a, st)) return rc;
         if (a.splits > 1) {

@@ -11,7 +11,6 @@
 //
 // MFMA: mfma_f32_32x32x16_bf16 (bf16 storage) / mfma_f32_32x32x2_f32 (float32 storage, exact f32).
 #include "common.h"
-#include <stdlib.h>
 
 namespace saunet {
 
@@ -328,8 +327,8 @@ template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI> static int la
     constexpr int EPI = EPI_TILE > EPI_BN ? EPI_TILE : EPI_BN;
     constexpr int LDS = MAIN > EPI ? MAIN : EPI;
     auto kern = conv3x3_tile_fwd_kernel<T, BN, WM, WN, CPR, BNEPI>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    static DeviceOnce attr;
+    if (attr.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     dim3 grid(a.tiles_x * a.tiles_y * a.N, cdiv(a.Cout, BN));
     hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, st, a);
     SAUNET_CHECK_LAUNCH("conv3x3_tile_fwd");
@@ -762,8 +761,8 @@ template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI> static int la
     int lds = (HALO_B > EPI_B ? HALO_B : EPI_B) + ncb * 9 * BN * (CPR * 16 + 16);
     a.lds_acc_off = lds; lds += (NT / 64) * 2 * BN * 4 + 2 * ncb * CPR * EPC * 4;      // accumulators (one slot per wave) + the prologue scale/shift vectors
     auto kern = conv3x3_res_fwd_kernel<T, BN, WM, WN, CPR, BNEPI>;
-    static int attr_lds = 0;
-    if (lds > attr_lds) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_lds = lds; }
+    static DeviceMaxLds attr;
+    if (attr.raise(lds)) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int items = a.tiles_x * a.tiles_y * a.N * cdiv(a.Cout, BN);
     const int per_cu = (160 * 1024) / lds > 0 ? (160 * 1024) / lds : 1;
     int blocks = 256 * per_cu; if (blocks > items) blocks = items;
@@ -1313,8 +1312,8 @@ template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KS
     constexpr int LDS = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
     static_assert(LDS <= 160 * 1024, "tile does not fit LDS");
     auto kern = conv_tile_wgrad_kernel<T, KS, TR, CO_T, CI_T, WM, WN, KSPLIT, ALIGNED>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    static DeviceOnce attr;
+    if (attr.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     a.tiles_y = a.H / TR; a.tiles_x = a.W / TILE; a.ntiles = a.N * a.tiles_y * a.tiles_x;
     constexpr int PARS = KS == 2 ? 4 : 1;                      // conv-transpose: the four output parities ride on blockIdx.y
     const int ncot = cdiv(a.Cout, CO_T); a.ncit = cdiv(a.Cin, CI_T); a.ncot = ncot;
@@ -1544,7 +1543,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tco_kernel(const float* __re
 
 bool wgrad_mm_supported(const TileWgradArgs& a, int ks, int dtype, bool aligned)
 {
-    static const bool on = !(getenv("SAUNET_WGRAD_MM") && getenv("SAUNET_WGRAD_MM")[0] == '0');                // A/B switch
+    static const bool on = ab_env_on("SAUNET_WGRAD_MM");                // A/B switch (variant builds only)
     return on && aligned && dtype == SAUNET_BF16 && ks == 3 && a.pro_scale == nullptr && a.pend == nullptr && a.Cout % 64 == 0 && a.Cin % 128 == 0 && a.H % 8 == 0 && a.W % 16 == 0 &&
            a.ldx % 8 == 0 && a.lddy % 8 == 0 && (long)a.N * a.H * a.W * (a.ldx > a.lddy ? a.ldx : a.lddy) < (1L << 30);
 }
@@ -1563,8 +1562,8 @@ int launch_wgrad_mm(TileWgradArgs& t, size_t ws_bytes, size_t* need, hipStream_t
     if (need) { *need = bytes; return SAUNET_OK; }
     if (a.ws == nullptr || ws_bytes < bytes) return set_error(SAUNET_BAD_SHAPE, "wgrad: workspace %zu < %zu bytes", ws_bytes, bytes);
     constexpr int LDS = 2 * WM_BUF;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_mm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    static DeviceOnce attr;
+    if (attr.first()) (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_mm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     hipLaunchKernelGGL(conv3x3_wgrad_mm_kernel, dim3(groups, chan_tiles), dim3(512), LDS, st, a);
     SAUNET_CHECK_LAUNCH("conv3x3_wgrad_mm");
     long rb = (a.wsize + 255) / 256; if (rb > 4096) rb = 4096;
@@ -1731,7 +1730,7 @@ __global__ __launch_bounds__(512, 2) void convt_wgrad_mm_kernel(ConvtWgradMmArgs
 
 bool convt_wgrad_mm_supported(const saunet_conv_desc* d, const saunet_wgrad_pending* pend)
 {
-    static const bool on = !(getenv("SAUNET_WGRAD_MM") && getenv("SAUNET_WGRAD_MM")[0] == '0');                // A/B switch
+    static const bool on = ab_env_on("SAUNET_WGRAD_MM");                // A/B switch (variant builds only)
     return on && pend == nullptr && d->Cin % 128 == 0 && d->Cout % 128 == 0 && d->H % 8 == 0 && d->W % 16 == 0 &&
            (long)d->N * d->Ho * d->Wo * d->ldy < (1L << 30) && (long)d->N * d->H * d->W * d->ldx < (1L << 30);
 }
@@ -1750,8 +1749,8 @@ int launch_convt_wgrad_mm(const saunet_conv_desc* d, const void* x, const void* 
     if (need) { *need = bytes; return SAUNET_OK; }
     if (ws == nullptr || ws_bytes < bytes) return set_error(SAUNET_BAD_SHAPE, "conv-transpose wgrad: workspace %zu < %zu bytes", ws_bytes, bytes);
     constexpr int LDS = 2 * CW_BUF;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)convt_wgrad_mm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    static DeviceOnce attr;
+    if (attr.first()) (void)hipFuncSetAttribute((const void*)convt_wgrad_mm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     hipLaunchKernelGGL(convt_wgrad_mm_kernel, dim3(groups, a.nct * 4), dim3(512), LDS, st, a);
     SAUNET_CHECK_LAUNCH("convt_wgrad_mm");
     long rb = (a.wsize + 255) / 256; if (rb > 4096) rb = 4096;
@@ -1817,8 +1816,8 @@ static int launch_tile_wgrad_grouped(GroupedWgradArgs& g, const saunet_wgrad_gro
     constexpr int LDS_RED = KSPLIT > 1 ? (4 / KSPLIT) * (KSPLIT - 1) * 16 * 64 * 4 : 0;   // per channel wave; (tap split: no cross-wave reduction)
     constexpr int LDS = LDS_MAIN > LDS_RED ? LDS_MAIN : LDS_RED;
     auto kern = conv_tile_wgrad_grouped_kernel<T, KS, TR, CO_T, CI_T, WM, WN, KSPLIT>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+    static DeviceOnce attr;
+    if (attr.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     g.tiles_y = g.H / TR; g.tiles_x = g.W / TILE; g.ntiles = g.N * g.tiles_y * g.tiles_x;
     long chan_tiles = 0, welems = 0;
     for (int i = 0; i < g.count; ++i) {

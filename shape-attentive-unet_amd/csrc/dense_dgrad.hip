@@ -20,7 +20,6 @@
 //   * per-channel sums over the 32 pixels of a tile are five DPP adds per value (VALU, not the LDS crossbar), then one
 //     LDS atomic per channel per wave tile and one float64 atomic per channel per block.
 #include "common.h"
-#include <stdlib.h>
 #include <type_traits>
 
 namespace saunet {
@@ -30,6 +29,17 @@ struct DenseDgradArgs {
     const float* scale; const float* shift; const float* mean; const float* invstd;
     double* sums; int reps, rstride;
     unsigned P; int Cin, relu, accumulate, group;
+    // APPLY variant (round 5): the operand is NOT a ready gradient but the masked conv2 data gradient G of the same layer; the BatchNorm backward
+    // of norm2,  dz1 = scale2 * (G - mean(G) - xhat(z1) * mean(G * xhat)),  is applied while the rows are loaded (the separate bn_bwd_apply pass
+    // read G and z1 and wrote dz1; this kernel then re-read dz1).  dz1 is also written out (by the blocks of channel group 0) for the deferred
+    // weight gradient of conv1.
+    const u16* z; int ldz; u16* dz; int lddz;
+    const double* sums2; int reps2, rstride2;      // [R][2][128]: sum G, sum G * xhat (dense_dgrad3 epilogue)
+    const float* p2;                                // [4][128] scale, shift, mean, invstd of norm2
+    double count;
+    float* dgamma2; float* dbeta2;                  // [128] out (written by block (0, 0))
+    // running coefficient sums of the block's "linear" BN1 backward: ab[r][0][c] += scale[c] * sum G, ab[r][1][c] += scale[c] * sum G * xhat
+    double* ab; int ab_reps, ab_rstride, ab_half;
 };
 
 constexpr int DG_GROUP = 256;          // channels per block (weights of one group live in LDS: 256 rows x 272 B)
@@ -53,7 +63,7 @@ constexpr int DG_WAVES = 4;
 //     template parameter), each step a fixed set of registers, the hand-over copies sit where everything they wait for is old;
 //   * the two BN-backward sums took 320 DPP adds (8 cycles each per wave) + 128 lane-atomics on LDS (12 cycles per lane) per step:
 //     replaced by the transposing row reduction above (60 DPP adds) into REGISTER accumulators that live for the wave's lifetime.
-template <int NS> __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgradArgs a)
+template <int NS, bool APPLY = false> __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgrad_kernel(DenseDgradArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char d_smem[];
     TSTAMP_INIT();
@@ -76,11 +86,18 @@ template <int NS> __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgra
         for (int i = 0; i < 4; ++i) o.x[i] = *(const u32x4*)(xr + min(step * 64 + 16 * i + lh8, GC - 8));
     };
     u32x4 gf[8];
+    u32x4 zr[APPLY ? 8 : 1];
     auto request_g = [&](size_t pp) {
         const u16* grow = a.g + pp * a.ldg + lh * 8;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) gf[ks] = *(const u32x4*)(grow + ks * 16);
+        if constexpr (APPLY) {
+            const u16* zrow = a.z + pp * a.ldz + lh * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) zr[ks] = *(const u32x4*)(zrow + ks * 16);
+        }
     };
+    float* s_cf = s_par + 4 * GCP;                     // APPLY: [3][128] a, b, c of  dz1 = a*G + b*z1 + c
     XP xa, xb;                        // x (needed first, for the mask) is requested one step ahead; y at the start of its own step
     // the two BN-backward sums stay in registers for the wave's whole lifetime: red[step][2t + r] = the lane's transposed partial sum
     // (row_transpose_sum) of the 8 channels of MFMA tile t, run pair r
@@ -116,14 +133,50 @@ template <int NS> __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgra
         s_par[i] = ok ? a.scale[g0 + i] : 0.f; s_par[GCP + i] = ok ? a.shift[g0 + i] : 0.f;
         s_par[2 * GCP + i] = is; s_par[3 * GCP + i] = ok ? -a.mean[g0 + i] * is : 0.f;
     }
+    if constexpr (APPLY) {
+        // the coefficients of norm2's backward from the replicated sums of the conv2 data gradient's epilogue (what bn_bwd_apply_kernel did once
+        // per block): dz1 = s*(G - m1 - (z1 - mu)*is*m2) = s*G - s*is*m2 * z1 - s*(m1 - mu*is*m2)
+        for (int k = threadIdx.x; k < 128; k += NT) {
+            double S1, S2;
+            rep_sum2(a.sums2, a.sums2 + 128, a.reps2, a.rstride2, k, S1, S2);
+            const float sc = a.p2[k], mu = a.p2[256 + k], is = a.p2[384 + k];
+            const float m1 = (float)(S1 / a.count), m2 = (float)(S2 / a.count);
+            s_cf[k] = sc; s_cf[128 + k] = -sc * is * m2; s_cf[256 + k] = -sc * (m1 - mu * is * m2);
+            if (blockIdx.x == 0 && blockIdx.y == 0 && a.dgamma2) { a.dbeta2[k] = (float)S1; a.dgamma2[k] = (float)S2; }
+        }
+    }
     __syncthreads();
     TSTAMP(41);
+    const bool dz_writer = APPLY && blockIdx.y == 0;
+    bool first_tile = true;
     for (unsigned tp = blockIdx.x * DG_WAVES + wave; tp < ntp; tp += stride) {
         const unsigned p = tp * 32u + lr;
         const bool live = p < a.P;
         const size_t pp = live ? p : a.P - 1;
         const size_t ppn = tp + stride < ntp ? min((tp + stride) * 32u + lr, a.P - 1) : pp;      // the wave's next tile (this one again when there is none: cache hits)
         TSTAMP(42);
+        if constexpr (APPLY) {
+            // (no cross-tile prefetch of the raw rows here: G and z1 together are 64 registers, the NS = 4 body has 19 to spare)
+            if (!first_tile) request_g(pp);
+            first_tile = false;
+            int cfl = 8 * lh;
+            asm volatile("" : "+v"(cfl));            // opaque: keeps the 48 coefficient vectors of a tile from being hoisted out of the loop
+            u16* dzrow = a.dz + pp * a.lddz + 8 * lh;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                float G[8], Z[8], d[8];
+                Vec16<u16>::unpack(gf[ks], G); Vec16<u16>::unpack(zr[ks], Z);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 ca = *(const f32x4*)(s_cf + ks * 16 + cfl + 4 * h), cb = *(const f32x4*)(s_cf + 128 + ks * 16 + cfl + 4 * h);
+                    const f32x4 cc = *(const f32x4*)(s_cf + 256 + ks * 16 + cfl + 4 * h);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) d[4 * h + q] = fmaf(ca[q], G[4 * h + q], fmaf(cb[q], Z[4 * h + q], cc[q]));
+                }
+                gf[ks] = Vec16<u16>::pack(d);
+                if (dz_writer && live) *(u32x4*)(dzrow + ks * 16) = gf[ks];
+            }
+        }
         u16* yrow = a.y + pp * a.ldy + g0 + 8 * lh;
         const u16* yrow0 = a.y + pp * a.ldy + g0;
         // the weight fragments are re-read from LDS for every tile ON PURPOSE: with the steps written out their addresses are tile-invariant
@@ -203,7 +256,7 @@ template <int NS> __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgra
                 const f32x16 acc0 = mma(T0);
                 f32x16 acc1 = acc0;
                 if (two) acc1 = mma(T1);
-                request_g(ppn);                  // gf is free: the next tile's fragments travel behind this step's two epilogues
+                if constexpr (!APPLY) request_g(ppn);                  // gf is free: the next tile's fragments travel behind this step's two epilogues
                 epilogue(T0, acc0);
                 if (two) epilogue(T1, acc1);
                 if constexpr ((NS & 1) == 1) cur = nxt;     // odd number of steps: the next tile's step 0 reads the set this step read
@@ -249,6 +302,12 @@ template <int NS> __global__ __launch_bounds__(DG_WAVES * 64, 2) void dense_dgra
             }
         atomicAdd(&a.sums[ro + g0 + c], (double)t1);
         atomicAdd(&a.sums[ro + a.Cin + g0 + c], (double)t2);
+        if (a.ab) {       // the layer's share of the block's linear BN1-backward coefficients (replaces the per-layer coefficient launch)
+            const float sc = a.scale[g0 + c];
+            const size_t ra = (size_t)(blockIdx.x % a.ab_reps) * a.ab_rstride;
+            atomicAdd(&a.ab[ra + g0 + c], (double)(sc * t1));
+            atomicAdd(&a.ab[ra + a.ab_half + g0 + c], (double)(sc * t2));
+        }
     }
     TSTAMP(48);
 }
@@ -513,13 +572,12 @@ int dense_dgrad3_forward(const saunet_conv_desc* d, const void* x, const void* w
     a.N = d->N; a.H = d->H; a.W = d->W; a.P = (unsigned)((long)d->N * d->H * d->W); a.relu = epi->relu;
     a.dW = FastDiv::make((unsigned)d->W); a.dHW = FastDiv::make((unsigned)(d->H * d->W));
     const size_t lds = (size_t)128 * D3_WPITCH * 2 + sizeof(float) * 4 * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr;
+    if (attr.first()) {
         (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
-        attr_set = true;
     }
-    static const bool halo_env = !(getenv("SAUNET_DGRAD3_HALO") && getenv("SAUNET_DGRAD3_HALO")[0] == '0');     // A/B switch
+    static const bool halo_env = ab_env_on("SAUNET_DGRAD3_HALO");     // A/B switch (variant builds only)
     const long ntile = (long)d->N * (d->H >> 4) * (d->W >> 4);
     if (halo_env && d->H % 16 == 0 && d->W % 16 == 0 && ntile >= 256) {
         // one 8-wave workgroup per CU, 16 x 16 tiles: only for maps with at least one tile per CU
@@ -570,13 +628,12 @@ int dense_dgrad_forward(const saunet_conv_desc* d, const void* x, const void* w,
     // pixel tile per wave
     long bx = 512 / groups; const long maxbx = ((long)a.P + 32 * DG_WAVES - 1) / (32 * DG_WAVES);
     if (bx > maxbx) bx = maxbx; if (bx < 1) bx = 1;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr;
+    if (attr.first()) {
         (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_set = true;
     }
     const dim3 grid((unsigned)bx, groups), block(DG_WAVES * 64);
     if (ns == 1) hipLaunchKernelGGL(dense_dgrad_kernel<1>, grid, block, lds, st, a);

@@ -295,6 +295,20 @@ def _desc(x, cout, ldy, ho, wo, kh, kw, stride, pad, transposed=False, pro_relu=
     return d
 
 
+def _attach_workspace(d, device):
+    """Caller-owned scratch of the forward entry points (saunet_conv2d_forward_workspace): allocated from torch's stream-ordered caching
+    allocator -- inside a hipGraph capture from the graph's private pool -- and handed over in the descriptor.  Only the 8 x 8 `center`
+    geometry asks for one today, so the query is skipped for everything else.  Returns the tensor (keep it referenced until the launch)."""
+    if d.H != 8 or d.W != 8 or d.KH != 3:
+        return None
+    need = L.load().saunet_conv2d_forward_workspace(C.byref(d))
+    if need <= 0:
+        return None
+    ws = torch.empty(int(need), dtype=torch.uint8, device=device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), int(need)
+    return ws
+
+
 def conv_out_hw(h, w, kh, kw, stride, pad, transposed):
     if transposed:
         return 2 * h, 2 * w
@@ -322,6 +336,7 @@ def conv_forward_raw(x, weight, bias, stride, pad, transposed=False, pro=None, o
     if stats is not None:
         d.stat_replicas, d.stat_rstride = stats.shape[0], stats.stride(0)
     d.epi_relu = 1 if act_relu else 0
+    _ws = _attach_workspace(d, x.device)
     L.call("saunet_conv2d_forward", C.byref(d), x.data_ptr(), wp.data_ptr(), L.ptr(bias),
            L.ptr(pro[0]) if pro else None, L.ptr(pro[1]) if pro else None, out.data_ptr(),
            stats[0, 0].data_ptr() if stats is not None else None, stats[0, 1].data_ptr() if stats is not None else None, L.stream())
@@ -385,6 +400,7 @@ def conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed=False, out=None,
             raise RuntimeError("dgrad: only stride-1 convolutions need an input gradient on this path")
         wp = PACKS.get(weight, L.PACK_DGRAD, dy.dtype)
         d = _desc(dy, cin, ld_of(out), h, w, kh, kw, 1, kh - 1 - pad)
+    _ws = _attach_workspace(d, dy.device)
     if accumulate and bn_epi is None:
         if transposed or not DGRAD_ACCUMULATE or not L.load().saunet_conv2d_accumulate_supported(C.byref(d)):
             tmp = conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed)

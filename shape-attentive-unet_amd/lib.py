@@ -18,7 +18,7 @@ PACK_FWD, PACK_DGRAD, PACK_CONVT_FWD, PACK_CONVT_DGRAD = 0, 1, 2, 3
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dtype", "N", "H", "W", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "KH", "KW", "stride", "pad",
-        "transposed", "pro_relu", "stat_replicas", "stat_rstride", "epi_relu")]
+        "transposed", "pro_relu", "stat_replicas", "stat_rstride", "epi_relu")] + [("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
 class BnEpilogue(C.Structure):
@@ -73,6 +73,7 @@ _SIGS = {
     "saunet_conv2d_forward": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "saunet_conv2d_forward_ex": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(BnEpilogue), vp],
     "saunet_conv2d_accumulate_supported": [C.POINTER(ConvDesc)],
+    "saunet_conv2d_forward_workspace": [C.POINTER(ConvDesc)],
     "saunet_conv2d_forward_bnpro": [C.POINTER(ConvDesc), vp, vp, vp, C.POINTER(BnPrologue), vp, vp, vp, vp],
     "saunet_bn_xhat": [i32, vp, vp, i32, i32, f64, f32, vp, i32, vp],
     "saunet_conv2d_wgrad": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i64, vp],

@@ -64,3 +64,40 @@ def test_param_grouping_matches_train_py():
     assert n_decay + n_nodecay == 32896505
     assert g[1]["weight_decay"] == 0.0
     assert all(p.dim() in (2, 4) for p in g[0]["params"]) and all(p.dim() == 1 for p in g[1]["params"])
+
+
+def test_product_sources_have_no_global_switches():
+    """include/saunet_hip.h: 'nothing here allocates, synchronises'; no process-global mutable behaviour.  The kernel sources must not call
+    getenv / hipMalloc / hipFree / hipDeviceSynchronize (A/B switches live behind -DSAUNET_AB_SWITCHES in common.h, variant builds only)."""
+    csrc = os.path.join(ROOT, "shape-attentive-unet_amd", "csrc")
+    bad = []
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith(".hip"):
+            continue
+        for i, line in enumerate(open(os.path.join(csrc, f)), 1):
+            code = line.split("//")[0]
+            if re.search(r"\b(getenv|hipMalloc|hipFree|hipDeviceSynchronize|hipStreamSynchronize|hipStreamIsCapturing)\b", code):
+                bad.append("%s:%d: %s" % (f, i, line.strip()))
+    assert not bad, bad
+    common = open(os.path.join(csrc, "common.h")).read()
+    head, _, rest = common.partition("#ifdef SAUNET_AB_SWITCHES")
+    assert "getenv" not in head and "getenv" not in rest.partition("#else")[2], "getenv outside the SAUNET_AB_SWITCHES branch of common.h"
+    from saunet_amd import _build
+    assert not any("SAUNET_AB_SWITCHES" in f for f in _build.FLAGS)
+
+
+def test_forward_workspace_query(lib):
+    """saunet_conv2d_forward_workspace: only the 8 x 8 `center` geometry (bf16, Cin % 64 == 0) asks for split-K scratch; bytes = items x splits x 64 KB."""
+    import ctypes as C
+    handle = lib.load()
+
+    def desc(n, h, cin, cout, dtype=1):
+        d = lib.ConvDesc()
+        d.dtype, d.N, d.H, d.W, d.Cin, d.ldx = dtype, n, h, h, cin, cin
+        d.Ho, d.Wo, d.Cout, d.ldy, d.KH, d.KW, d.stride, d.pad = h, h, cout, cout, 3, 3, 1, 1
+        return d
+    assert handle.saunet_conv2d_forward_workspace(C.byref(desc(32, 8, 1024, 512))) == 8 * 8 * 4 * 32 * 512 * 4      # 64 items x 4 splits
+    assert handle.saunet_conv2d_forward_workspace(C.byref(desc(32, 8, 512, 1024))) == 8 * 16 * 2 * 32 * 512 * 4     # its data gradient
+    assert handle.saunet_conv2d_forward_workspace(C.byref(desc(32, 16, 1536, 512))) == 0
+    assert handle.saunet_conv2d_forward_workspace(C.byref(desc(32, 8, 1024, 512, dtype=0))) == 0
+    assert handle.saunet_conv2d_forward_workspace(C.byref(desc(2, 8, 1024, 512))) == 0                                # N % 4 != 0: not cell mode
