@@ -160,6 +160,46 @@ typedef struct saunet_wgrad_group {
 } saunet_wgrad_group;
 int64_t saunet_conv2d_wgrad_grouped_workspace(const saunet_wgrad_group* g);
 int saunet_conv2d_wgrad_grouped(const saunet_wgrad_group* g, void* workspace, int64_t workspace_bytes, void* stream);
+/* ---- DenseNet layer backward, fused (round 5; bf16 storage, training-mode BatchNorm) ---------------------------------------------------
+ * One torchvision _DenseLayer (norm1-relu-conv1(1x1 -> 128)-norm2-relu-conv2(3x3 -> 32), used at /root/reference/models/models.py:306-313)
+ * inside a block whose concat is ONE buffer; replaces autograd's convolution_backward (input part) + native_batch_norm_backward of both
+ * BatchNorms behind loss.backward() (train.py:104) with TWO launches per layer (four until round 4):
+ *   saunet_dense_layer_backward_conv2:  g = dbuf[:, Cin:Cin+32] - (A + B * xhat)   (the deferred correction of the block's "linear" BN1 backward,
+ *       A, B = ab / count, applied as the operand is loaded and written to dz2 for the weight gradient)
+ *       G = conv2-dgrad(g) * [relu mask of norm2(z1)]  -> g_out,   sums2 += (sum G, sum G * xhat(z1))
+ *     (maps with >= 256 16 x 16 tiles use the LDS-DMA staged kernel and a separate correction pass: two launches inside the call)
+ *   saunet_dense_layer_backward_conv1:  dz1 = scale2 * (G - mean(G) - xhat(z1) * mean(G * xhat))  from sums2, applied as G is loaded, written to dz1;
+ *       D = conv1-dgrad(dz1) * [relu mask of norm1(buf)],  dbuf[:, :Cin] += scale1 * D,  sums1 += (sum D, sum D * xhat),
+ *       ab[.., :Cin] += scale1 * (sum D, sum D * xhat)   (what saunet_bn_backward_coeff did in its own launch),  dgamma2 / dbeta2 = sums2.
+ * dz2 == NULL: the chunk needs no correction (the block's last layer: nothing was accumulated into ab for it); conv2 then reads dbuf directly.
+ * All accumulators are float64, replicated [R][2][C] like the statistics, zero-initialised by the caller. */
+typedef struct saunet_dense_layer_bwd {
+    int32_t N, H, W, Cin, Ctot, reserved;
+    const void* buf; void* dbuf;                /* [P][Ctot] concat activations / gradient (channel stride Ctot) */
+    const float* xhat; int32_t ld_xhat, reserved2;   /* [5][ld_xhat]: xs, xt, mean, invstd, var of the concat channels (saunet_bn_xhat / _bnpro) */
+    double* ab; int32_t ab_replicas, ab_rstride;     /* [R][2][Ctot] */
+    double count;
+    const void* z1; void* g; void* dz1; void* dz2;   /* [P][128] x3, [P][32]; g is scratch between the two calls */
+    const void* w2_dgrad; const void* w1_dgrad;     /* SAUNET_PACK_DGRAD packings of conv2 / conv1 */
+    const float* p1; const float* p2;               /* [4][Cin], [4][128]: scale, shift, mean, invstd (saunet_conv2d_forward_bnpro params) */
+    double* sums2; int32_t sums2_replicas, sums2_rstride;   /* [R][2][128] */
+    double* sums1; int32_t sums1_replicas, sums1_rstride;   /* [R][2][Cin] */
+    float* dgamma2; float* dbeta2;                  /* [128] out */
+} saunet_dense_layer_bwd;
+int saunet_dense_layer_backward_conv2(const saunet_dense_layer_bwd* l, void* stream);
+int saunet_dense_layer_backward_conv1(const saunet_dense_layer_bwd* l, void* stream);
+/* y = d - (A + B * (x*xs + xt)) with A, B = ab / count (replicated float64 sums, rows ab and ab + ab_half): the deferred correction of the linear
+ * BN1 backward for C channels (C <= 256); y may alias d. */
+int saunet_bn_backward_correct_ab(int dtype, const void* d, int ldd, const void* x, int ldx, void* y, int ldy, const double* ab, int ab_replicas,
+                                  int ab_rstride, int ab_half, double count, const float* xs, const float* xt, int64_t pixels, int C, void* stream);
+/* dgamma / dbeta of every norm1 of a dense block from the per-layer sums (one launch per block instead of one per layer) */
+#define SAUNET_DENSE_LAYERS_MAX 64
+typedef struct saunet_dense_bn1_list {
+    int32_t count, replicas;
+    const double* sums[SAUNET_DENSE_LAYERS_MAX]; int32_t rstride[SAUNET_DENSE_LAYERS_MAX]; int32_t cin[SAUNET_DENSE_LAYERS_MAX];
+    float* dgamma[SAUNET_DENSE_LAYERS_MAX]; float* dbeta[SAUNET_DENSE_LAYERS_MAX];
+} saunet_dense_bn1_list;
+int saunet_dense_bn1_grads(const saunet_dense_bn1_list* l, void* stream);
 /* bytes of caller-owned scratch saunet_conv2d_wgrad needs for this shape (0 = none; <0 = saunet_status).
  * The tiled kernels write per-block partial gradients there with plain stores and reduce them afterwards
  * (cross-XCD float atomics on the same addresses are ~10x more expensive than the stores + one reduce pass). */

@@ -329,6 +329,13 @@ struct DenseDgrad3Args {
     double* sums; int reps, rstride;
     int N, H, W; unsigned P; int relu;
     FastDiv dW, dHW;
+    // CORR variant (round 5, per-wave kernel only): g is the block's gradient buffer chunk BEFORE the deferred correction of the linear BN1
+    // backward; g' = g - (A[c] + B[c] * xhat(x)[c]) is applied to every fragment as it is loaded (zero padding stays zero) and the corrected
+    // centre pixel goes to gc for the deferred weight gradient.  A, B = the running coefficient sums `ab` / count (dense_dgrad_kernel epilogue).
+    const u16* xc; int ldxc;                       // the chunk's activations (block buffer slice)
+    const double* ab; int ab_reps, ab_rstride, ab_half; double count;
+    const float* xs; const float* xt;              // xhat rows of the chunk's channels
+    u16* gc; int ldgc;
 };
 constexpr int D3_WPITCH = 296;
 // HALO variant (maps whose H and W are multiples of 16): the workgroup (8 waves) owns a 16 x 16 pixel tile, wave w its rows 2w, 2w + 1;
@@ -342,9 +349,10 @@ constexpr int D3_WPITCH = 296;
 constexpr int D3_HALO_PIECES = 21, D3_HALO_BYTES = D3_HALO_PIECES * 1024;
 static __device__ u32x4 g_dg_zeros[4];
 
-template <bool HALO>
+template <bool HALO, bool CORR = false>
 __global__ __launch_bounds__((HALO ? 8 : DG_WAVES) * 64, HALO ? 1 : 2) void dense_dgrad3_kernel(DenseDgrad3Args a)
 {
+    static_assert(!(HALO && CORR), "the correction is folded into the per-wave variant only");
     extern __shared__ __attribute__((aligned(1024))) unsigned char d_smem[];
     TSTAMP_INIT();
     TSTAMP(50);
@@ -391,7 +399,24 @@ __global__ __launch_bounds__((HALO ? 8 : DG_WAVES) * 64, HALO ? 1 : 2) void dens
         const float is = a.invstd[i];
         s_par[i] = a.scale[i]; s_par[128 + i] = a.shift[i]; s_par[256 + i] = is; s_par[384 + i] = -a.mean[i] * is;
     }
+    float* s_cc = s_par + 512;                     // CORR: [2][32]  g' = g - (cA + cB * x)
+    if constexpr (CORR) {
+        if (threadIdx.x < 32) {
+            const int c = threadIdx.x;
+            double A, B;
+            rep_sum2(a.ab, a.ab + a.ab_half, a.ab_reps, a.ab_rstride, c, A, B);
+            const float Af = (float)(A / a.count), Bf = (float)(B / a.count);
+            s_cc[c] = fmaf(Bf, a.xt[c], Af); s_cc[32 + c] = Bf * a.xs[c];
+        }
+    }
     __syncthreads();
+    float cA[CORR ? 16 : 1], cB[CORR ? 16 : 1];     // this lane's channels 16*h + 8*lh + j
+    if constexpr (CORR) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { cA[8 * h + j] = s_cc[16 * h + 8 * lh + j]; cB[8 * h + j] = s_cc[32 + 16 * h + 8 * lh + j]; }
+    }
     const unsigned ntp = (a.P + 31) / 32;
     // the two BN-backward sums in registers for the wave's lifetime (see dense_dgrad_kernel): red[step][2t + r]
     float red[2][4];
@@ -452,8 +477,26 @@ __global__ __launch_bounds__((HALO ? 8 : DG_WAVES) * 64, HALO ? 1 : 2) void dens
             for (int tap = 0; tap < 9; ++tap) {
                 const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
                 const bool ok = live && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-                const u16* row = a.g + ((size_t)n * a.H * a.W + (size_t)(ok ? yy : py) * a.W + (ok ? xx : px)) * a.ldg + lh * 8;
-                const u32x4 v0 = *(const u32x4*)row, v1 = *(const u32x4*)(row + 16);
+                const size_t pix = (size_t)n * a.H * a.W + (size_t)(ok ? yy : py) * a.W + (ok ? xx : px);
+                const u16* row = a.g + pix * a.ldg + lh * 8;
+                u32x4 v0 = *(const u32x4*)row, v1 = *(const u32x4*)(row + 16);
+                if constexpr (CORR) {
+                    const u16* xrow = a.xc + pix * a.ldxc + lh * 8;
+                    const u32x4 x0 = *(const u32x4*)xrow, x1 = *(const u32x4*)(xrow + 16);
+                    float gv[8], xv[8];
+                    Vec16<u16>::unpack(v0, gv); Vec16<u16>::unpack(x0, xv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) gv[j] -= fmaf(cB[j], xv[j], cA[j]);
+                    v0 = Vec16<u16>::pack(gv);
+                    Vec16<u16>::unpack(v1, gv); Vec16<u16>::unpack(x1, xv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) gv[j] -= fmaf(cB[8 + j], xv[j], cA[8 + j]);
+                    v1 = Vec16<u16>::pack(gv);
+                    if (tap == 4 && live) {          // the corrected gradient of this lane's own pixel: what the conv2 weight gradient reads later
+                        u16* gcrow = a.gc + (size_t)pc * a.ldgc + lh * 8;
+                        *(u32x4*)gcrow = v0; *(u32x4*)(gcrow + 16) = v1;
+                    }
+                }
                 gf[2 * tap] = ok ? v0 : u32x4{0u, 0u, 0u, 0u};
                 gf[2 * tap + 1] = ok ? v1 : u32x4{0u, 0u, 0u, 0u};
             }
@@ -554,6 +597,13 @@ __global__ __launch_bounds__((HALO ? 8 : DG_WAVES) * 64, HALO ? 1 : 2) void dens
     }
 }
 
+// maps on which the conv2 data gradient runs the LDS-DMA staged (HALO) kernel: multiples of 16 with at least one 16 x 16 tile per CU
+static bool dense_dgrad3_halo(int N, int H, int W)
+{
+    static const bool halo_env = ab_env_on("SAUNET_DGRAD3_HALO");     // A/B switch (variant builds only)
+    return halo_env && H % 16 == 0 && W % 16 == 0 && (long)N * (H >> 4) * (W >> 4) >= 256;
+}
+
 bool dense_dgrad3_supported(const saunet_conv_desc* d, const float* bias, const float* ps, const saunet_bn_epilogue* epi)
 {
     return epi != nullptr && epi->bn_x != nullptr && !epi->accumulate && d->dtype == SAUNET_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 1 &&
@@ -561,35 +611,41 @@ bool dense_dgrad3_supported(const saunet_conv_desc* d, const float* bias, const 
            bias == nullptr && ps == nullptr && (long)d->N * d->H * d->W < (1L << 31);
 }
 
-int dense_dgrad3_forward(const saunet_conv_desc* d, const void* x, const void* w, void* y, const saunet_bn_epilogue* epi, hipStream_t st)
+static int launch_dense_dgrad3(DenseDgrad3Args& a, bool corr, hipStream_t st)
 {
-    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)epi->bn_x) & 15)
-        return set_error(SAUNET_BAD_ALIGN, "dense 3x3 dgrad: operands must be 16-byte aligned");
-    DenseDgrad3Args a;
-    a.g = (const u16*)x; a.ldg = d->ldx; a.w = (const u16*)w; a.z = (const u16*)epi->bn_x; a.ldz = epi->ld_bn_x; a.y = (u16*)y; a.ldy = d->ldy;
-    a.scale = epi->scale; a.shift = epi->shift; a.mean = epi->mean; a.invstd = epi->invstd;
-    a.sums = epi->sums; a.reps = epi->sums_replicas > 1 ? epi->sums_replicas : 1; a.rstride = epi->sums_rstride;
-    a.N = d->N; a.H = d->H; a.W = d->W; a.P = (unsigned)((long)d->N * d->H * d->W); a.relu = epi->relu;
-    a.dW = FastDiv::make((unsigned)d->W); a.dHW = FastDiv::make((unsigned)(d->H * d->W));
-    const size_t lds = (size_t)128 * D3_WPITCH * 2 + sizeof(float) * 4 * 128;
+    const size_t lds = (size_t)128 * D3_WPITCH * 2 + sizeof(float) * (4 * 128 + 64);
     static DeviceOnce attr;
     if (attr.first()) {
         (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
     }
-    static const bool halo_env = ab_env_on("SAUNET_DGRAD3_HALO");     // A/B switch (variant builds only)
-    const long ntile = (long)d->N * (d->H >> 4) * (d->W >> 4);
-    if (halo_env && d->H % 16 == 0 && d->W % 16 == 0 && ntile >= 256) {
+    if (!corr && dense_dgrad3_halo(a.N, a.H, a.W)) {
         // one 8-wave workgroup per CU, 16 x 16 tiles: only for maps with at least one tile per CU
+        const long ntile = (long)a.N * (a.H >> 4) * (a.W >> 4);
         const long bx = ntile < 256 ? ntile : 256;
         hipLaunchKernelGGL(dense_dgrad3_kernel<true>, dim3((unsigned)bx), dim3(512), lds + 2 * D3_HALO_BYTES, st, a);
     } else {
         long bx = 512; const long maxbx = ((long)a.P + 32 * DG_WAVES - 1) / (32 * DG_WAVES);
         if (bx > maxbx) bx = maxbx; if (bx < 1) bx = 1;
-        hipLaunchKernelGGL(dense_dgrad3_kernel<false>, dim3((unsigned)bx), dim3(DG_WAVES * 64), lds, st, a);
+        if (corr) hipLaunchKernelGGL((dense_dgrad3_kernel<false, true>), dim3((unsigned)bx), dim3(DG_WAVES * 64), lds, st, a);
+        else hipLaunchKernelGGL(dense_dgrad3_kernel<false>, dim3((unsigned)bx), dim3(DG_WAVES * 64), lds, st, a);
     }
     SAUNET_CHECK_LAUNCH("dense_dgrad3");
     return SAUNET_OK;
+}
+
+int dense_dgrad3_forward(const saunet_conv_desc* d, const void* x, const void* w, void* y, const saunet_bn_epilogue* epi, hipStream_t st)
+{
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)epi->bn_x) & 15)
+        return set_error(SAUNET_BAD_ALIGN, "dense 3x3 dgrad: operands must be 16-byte aligned");
+    DenseDgrad3Args a{};
+    a.g = (const u16*)x; a.ldg = d->ldx; a.w = (const u16*)w; a.z = (const u16*)epi->bn_x; a.ldz = epi->ld_bn_x; a.y = (u16*)y; a.ldy = d->ldy;
+    a.scale = epi->scale; a.shift = epi->shift; a.mean = epi->mean; a.invstd = epi->invstd;
+    a.sums = epi->sums; a.reps = epi->sums_replicas > 1 ? epi->sums_replicas : 1; a.rstride = epi->sums_rstride;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.P = (unsigned)((long)d->N * d->H * d->W); a.relu = epi->relu;
+    a.dW = FastDiv::make((unsigned)d->W); a.dHW = FastDiv::make((unsigned)(d->H * d->W));
+    return launch_dense_dgrad3(a, false, st);
 }
 
 bool dense_dgrad_supported(const saunet_conv_desc* d, const float* bias, const float* ps, const saunet_bn_epilogue* epi)
@@ -599,15 +655,8 @@ bool dense_dgrad_supported(const saunet_conv_desc* d, const float* bias, const f
            bias == nullptr && ps == nullptr && d->Cout <= 2048 && (long)d->N * d->H * d->W < (1L << 31);
 }
 
-int dense_dgrad_forward(const saunet_conv_desc* d, const void* x, const void* w, void* y, const saunet_bn_epilogue* epi, hipStream_t st)
+static int launch_dense_dgrad(DenseDgradArgs& a, bool apply, hipStream_t st)
 {
-    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)epi->bn_x) & 15)
-        return set_error(SAUNET_BAD_ALIGN, "dense dgrad: operands must be 16-byte aligned");
-    DenseDgradArgs a;
-    a.g = (const u16*)x; a.ldg = d->ldx; a.w = (const u16*)w; a.x = (const u16*)epi->bn_x; a.ldx = epi->ld_bn_x; a.y = (u16*)y; a.ldy = d->ldy;
-    a.scale = epi->scale; a.shift = epi->shift; a.mean = epi->mean; a.invstd = epi->invstd;
-    a.sums = epi->sums; a.reps = epi->sums_replicas > 1 ? epi->sums_replicas : 1; a.rstride = epi->sums_rstride;
-    a.P = (unsigned)((long)d->N * d->H * d->W); a.Cin = d->Cout; a.relu = epi->relu; a.accumulate = epi->accumulate;
     // channels per block: 256 (weights copied to LDS once per block) when every wave gets many pixel tiles, fewer on the
     // low-resolution blocks where the copy would dominate and more blocks are needed to fill the chip
     const long ntp = ((long)a.P + 31) / 32;
@@ -620,7 +669,7 @@ int dense_dgrad_forward(const saunet_conv_desc* d, const void* x, const void* w,
     const int groups = (a.Cin + a.group - 1) / a.group;
     const int gcp = ((a.Cin < a.group ? a.Cin : a.group) + 31) & ~31;
     const int ns = (gcp + 63) / 64;                      // 64-channel steps of a full group (a shorter last group masks its surplus steps)
-    size_t lds = (size_t)gcp * DG_WPITCH * 2 + sizeof(float) * 4 * gcp;
+    size_t lds = (size_t)gcp * DG_WPITCH * 2 + sizeof(float) * 4 * gcp + (apply ? sizeof(float) * 3 * 128 : 0);
     const size_t red_bytes = (size_t)DG_WAVES * ns * 4 * 64 * sizeof(float);       // the end-of-kernel fold re-uses the weight area
     if (lds < red_bytes) lds = red_bytes;
     // two resident blocks per CU (registers): the grid must not EXCEED that capacity -- a handful of surplus blocks start only when the first
@@ -634,16 +683,109 @@ int dense_dgrad_forward(const saunet_conv_desc* d, const void* x, const void* w,
         (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)dense_dgrad_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     }
     const dim3 grid((unsigned)bx, groups), block(DG_WAVES * 64);
-    if (ns == 1) hipLaunchKernelGGL(dense_dgrad_kernel<1>, grid, block, lds, st, a);
-    else if (ns == 2) hipLaunchKernelGGL(dense_dgrad_kernel<2>, grid, block, lds, st, a);
-    else if (ns == 3) hipLaunchKernelGGL(dense_dgrad_kernel<3>, grid, block, lds, st, a);
-    else hipLaunchKernelGGL(dense_dgrad_kernel<4>, grid, block, lds, st, a);
+    if (apply) {
+        if (ns == 1) hipLaunchKernelGGL((dense_dgrad_kernel<1, true>), grid, block, lds, st, a);
+        else if (ns == 2) hipLaunchKernelGGL((dense_dgrad_kernel<2, true>), grid, block, lds, st, a);
+        else if (ns == 3) hipLaunchKernelGGL((dense_dgrad_kernel<3, true>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((dense_dgrad_kernel<4, true>), grid, block, lds, st, a);
+    } else {
+        if (ns == 1) hipLaunchKernelGGL(dense_dgrad_kernel<1>, grid, block, lds, st, a);
+        else if (ns == 2) hipLaunchKernelGGL(dense_dgrad_kernel<2>, grid, block, lds, st, a);
+        else if (ns == 3) hipLaunchKernelGGL(dense_dgrad_kernel<3>, grid, block, lds, st, a);
+        else hipLaunchKernelGGL(dense_dgrad_kernel<4>, grid, block, lds, st, a);
+    }
     SAUNET_CHECK_LAUNCH("dense_dgrad");
     return SAUNET_OK;
 }
 
+int dense_dgrad_forward(const saunet_conv_desc* d, const void* x, const void* w, void* y, const saunet_bn_epilogue* epi, hipStream_t st)
+{
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)epi->bn_x) & 15)
+        return set_error(SAUNET_BAD_ALIGN, "dense dgrad: operands must be 16-byte aligned");
+    DenseDgradArgs a{};
+    a.g = (const u16*)x; a.ldg = d->ldx; a.w = (const u16*)w; a.x = (const u16*)epi->bn_x; a.ldx = epi->ld_bn_x; a.y = (u16*)y; a.ldy = d->ldy;
+    a.scale = epi->scale; a.shift = epi->shift; a.mean = epi->mean; a.invstd = epi->invstd;
+    a.sums = epi->sums; a.reps = epi->sums_replicas > 1 ? epi->sums_replicas : 1; a.rstride = epi->sums_rstride;
+    a.P = (unsigned)((long)d->N * d->H * d->W); a.Cin = d->Cout; a.relu = epi->relu; a.accumulate = epi->accumulate;
+    return launch_dense_dgrad(a, false, st);
+}
+
+int bn_backward_correct_ab(int dtype, const void* d, int ldd, const void* x, int ldx, void* y, int ldy, const double* ab, int ab_replicas,
+                           int ab_rstride, int ab_half, double count, const float* xs, const float* xt, int64_t pixels, int C, hipStream_t st);
+
 }  // namespace saunet
+
+using namespace saunet;
+
+static int dense_layer_check(const saunet_dense_layer_bwd* l, const char* who)
+{
+    if (!l || l->N < 1 || l->H < 1 || l->W < 1 || l->Cin < 8 || l->Cin % 8 || l->Ctot % 8 || l->Cin + 32 > l->Ctot || l->Cin > 2048 ||
+        (long)l->N * l->H * l->W >= (1L << 31) || l->count < 1.0)
+        return set_error(SAUNET_BAD_SHAPE, "%s: bad geometry", who);
+    if (!l->buf || !l->dbuf || !l->xhat || !l->ab || !l->z1 || !l->g || !l->p2 || !l->sums2 || l->ab_replicas < 1 || l->sums2_replicas < 1 || l->ld_xhat < l->Ctot)
+        return set_error(SAUNET_BAD_SHAPE, "%s: incomplete descriptor", who);
+    if (((uintptr_t)l->buf | (uintptr_t)l->dbuf | (uintptr_t)l->z1 | (uintptr_t)l->g | (uintptr_t)l->dz1 | (uintptr_t)l->dz2 |
+         (uintptr_t)l->w1_dgrad | (uintptr_t)l->w2_dgrad) & 15)
+        return set_error(SAUNET_BAD_ALIGN, "%s: operands must be 16-byte aligned", who);
+    return SAUNET_OK;
+}
+
+extern "C" {
+
+int saunet_dense_layer_backward_conv2(const saunet_dense_layer_bwd* l, void* stream)
+{
+    if (int rc = dense_layer_check(l, "dense_layer_backward_conv2")) return rc;
+    if (!l->w2_dgrad) return set_error(SAUNET_BAD_SHAPE, "dense_layer_backward_conv2: no packed weights");
+    hipStream_t st = (hipStream_t)stream;
+    const long P = (long)l->N * l->H * l->W;
+    const u16* chunk = (const u16*)l->dbuf + l->Cin;
+    DenseDgrad3Args a{};
+    a.w = (const u16*)l->w2_dgrad; a.z = (const u16*)l->z1; a.ldz = 128; a.y = (u16*)l->g; a.ldy = 128;
+    a.scale = l->p2; a.shift = l->p2 + 128; a.mean = l->p2 + 256; a.invstd = l->p2 + 384;
+    a.sums = l->sums2; a.reps = l->sums2_replicas; a.rstride = l->sums2_rstride;
+    a.N = l->N; a.H = l->H; a.W = l->W; a.P = (unsigned)P; a.relu = 1;
+    a.dW = FastDiv::make((unsigned)l->W); a.dHW = FastDiv::make((unsigned)(l->H * l->W));
+    if (l->dz2 == nullptr) {                       // nothing to correct: read the chunk in place
+        a.g = chunk; a.ldg = l->Ctot;
+        return launch_dense_dgrad3(a, false, st);
+    }
+    const double* ab = l->ab + l->Cin;
+    if (dense_dgrad3_halo(l->N, l->H, l->W)) {     // large maps: a streaming correction pass into dz2, then the LDS-DMA staged kernel over dz2
+        if (int rc = bn_backward_correct_ab(SAUNET_BF16, chunk, l->Ctot, (const u16*)l->buf + l->Cin, l->Ctot, l->dz2, 32, ab, l->ab_replicas, l->ab_rstride,
+                                            l->Ctot, l->count, l->xhat + l->Cin, l->xhat + l->ld_xhat + l->Cin, P, 32, st)) return rc;
+        a.g = (const u16*)l->dz2; a.ldg = 32;
+        return launch_dense_dgrad3(a, false, st);
+    }
+    a.g = chunk; a.ldg = l->Ctot;
+    a.xc = (const u16*)l->buf + l->Cin; a.ldxc = l->Ctot;
+    a.ab = ab; a.ab_reps = l->ab_replicas; a.ab_rstride = l->ab_rstride; a.ab_half = l->Ctot; a.count = l->count;
+    a.xs = l->xhat + l->Cin; a.xt = l->xhat + l->ld_xhat + l->Cin;
+    a.gc = (u16*)l->dz2; a.ldgc = 32;
+    return launch_dense_dgrad3(a, true, st);
+}
+
+int saunet_dense_layer_backward_conv1(const saunet_dense_layer_bwd* l, void* stream)
+{
+    if (int rc = dense_layer_check(l, "dense_layer_backward_conv1")) return rc;
+    if (!l->w1_dgrad || !l->p1 || !l->sums1 || !l->dz1 || l->sums1_replicas < 1) return set_error(SAUNET_BAD_SHAPE, "dense_layer_backward_conv1: incomplete descriptor");
+    DenseDgradArgs a{};
+    a.g = (const u16*)l->g; a.ldg = 128; a.w = (const u16*)l->w1_dgrad; a.x = (const u16*)l->buf; a.ldx = l->Ctot; a.y = (u16*)l->dbuf; a.ldy = l->Ctot;
+    a.scale = l->p1; a.shift = l->p1 + l->Cin; a.mean = l->p1 + 2 * l->Cin; a.invstd = l->p1 + 3 * l->Cin;
+    a.sums = l->sums1; a.reps = l->sums1_replicas; a.rstride = l->sums1_rstride;
+    a.P = (unsigned)((long)l->N * l->H * l->W); a.Cin = l->Cin; a.relu = 1; a.accumulate = 1;
+    a.z = (const u16*)l->z1; a.ldz = 128; a.dz = (u16*)l->dz1; a.lddz = 128;
+    a.sums2 = l->sums2; a.reps2 = l->sums2_replicas; a.rstride2 = l->sums2_rstride; a.p2 = l->p2; a.count = l->count;
+    a.dgamma2 = l->dgamma2; a.dbeta2 = l->dbeta2;
+    a.ab = l->ab; a.ab_reps = l->ab_replicas; a.ab_rstride = l->ab_rstride; a.ab_half = l->Ctot;
+    return launch_dense_dgrad(a, true, (hipStream_t)stream);
+}
+
+}  // extern "C"
 
 SAUNET_TIMING_READER(dense_dgrad)

@@ -443,6 +443,52 @@ template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_coeff
     }
 }
 
+// the chunk correction with the coefficients taken from the block's running float64 sums (dense_dgrad_kernel's epilogue accumulates them):
+// y = d - (A + B * (x*xs + xt)),  A = sum_r ab[r][c] / count,  B = sum_r ab[r][half + c] / count.  y may alias d.
+struct CorrectAbArgs {
+    const void* d; int ldd; const void* x; int ldx; void* y; int ldy;
+    const double* ab; int reps, rstride, half; double count; const float* xs; const float* xt; long P; int C; long rpb;
+};
+template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_correct_ab_kernel(CorrectAbArgs a)
+{
+    __shared__ float s_ab[2][256];         // A + B*xt ,  B*xs
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+        double A, B;
+        rep_sum2(a.ab, a.ab + a.half, a.reps, a.rstride, c, A, B);
+        const float Af = (float)(A / a.count), Bf = (float)(B / a.count);
+        s_ab[0][c] = fmaf(Bf, a.xt[c], Af); s_ab[1][c] = Bf * a.xs[c];
+    }
+    __syncthreads();
+    const long p0 = blockIdx.x * a.rpb, p1 = min(p0 + a.rpb, a.P);
+    const int CH = a.C / V;
+    const T* dd = (const T*)a.d; const T* x = (const T*)a.x; T* y = (T*)a.y;
+    const int cw = min(256, CH), rl = 256 / cw;
+    const int ch = threadIdx.x % cw, r0 = threadIdx.x / cw;
+    if (r0 >= rl) return;
+    float av[V], bv[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { av[j] = s_ab[0][ch * V + j]; bv[j] = s_ab[1][ch * V + j]; }
+    for (long p = p0 + r0; p < p1; p += rl) {
+        float dv[V], xv[V];
+        ChunkIO<T, V>::load(dd + p * a.ldd + ch * V, dv);
+        ChunkIO<T, V>::load(x + p * a.ldx + ch * V, xv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) dv[j] -= fmaf(bv[j], xv[j], av[j]);
+        ChunkIO<T, V>::store(y + p * a.ldy + ch * V, dv);
+    }
+}
+
+// dgamma / dbeta of all norm1 layers of a dense block: blockIdx.y = layer
+__global__ __launch_bounds__(256) void dense_bn1_grads_kernel(saunet_dense_bn1_list l)
+{
+    const int layer = blockIdx.y, C = l.cin[layer];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1, s2;
+    rep_sum2(l.sums[layer], l.sums[layer] + C, l.replicas, l.rstride[layer], c, s1, s2);
+    l.dbeta[layer][c] = (float)s1; l.dgamma[layer][c] = (float)s2;
+}
+
 static inline long rows_per_block(long P, int C, int V, int* blocks)
 {
     // enough blocks to fill the chip, each with a few thousand elements per thread at most
@@ -476,6 +522,22 @@ using namespace saunet;
     } while (0)
 
 namespace saunet {
+int bn_backward_correct_ab(int dtype, const void* d, int ldd, const void* x, int ldx, void* y, int ldy, const double* ab, int ab_replicas,
+                           int ab_rstride, int ab_half, double count, const float* xs, const float* xt, int64_t pixels, int C, hipStream_t st)
+{
+    if (C < 1 || C > 256 || pixels < 1 || !d || !x || !y || !ab || !xs || !xt || ab_replicas < 1 || count < 1.0)
+        return set_error(SAUNET_BAD_SHAPE, "bn_backward_correct_ab: C=%d pixels=%ld", C, (long)pixels);
+    const bool vec = vec_ok(dtype, C, {ldd, ldx, ldy}, {d, x, y});
+    int blocks; const int V = vec ? (dtype == SAUNET_BF16 ? 8 : 4) : 1;
+    CorrectAbArgs a{d, ldd, x, ldx, y, ldy, ab, ab_replicas, ab_rstride, ab_half, count, xs, xt, (long)pixels, C, 0};
+    a.rpb = rows_per_block(pixels, C, V, &blocks);
+#define CALL(TT, VV) hipLaunchKernelGGL((bn_bwd_correct_ab_kernel<TT, VV>), dim3(blocks), dim3(256), 0, st, a)
+    DISPATCH_TV(dtype, vec, CALL);
+#undef CALL
+    SAUNET_CHECK_LAUNCH("bn_backward_correct_ab");
+    return SAUNET_OK;
+}
+
 int bn_prologue_finalize(const saunet_bn_prologue* p, int Cin, hipStream_t st)
 {
     hipLaunchKernelGGL(bn_prologue_finalize_kernel, dim3(1), dim3(256), sizeof(float) * 2 * Cin, st, *p, Cin, nullptr);
@@ -625,6 +687,25 @@ int saunet_bn_backward_coeff_correct(int dtype, int C, const double* sums, int s
     DISPATCH_TV(dtype, vec, CALL);
 #undef CALL
     SAUNET_CHECK_LAUNCH("bn_backward_coeff_correct");
+    return SAUNET_OK;
+}
+
+int saunet_bn_backward_correct_ab(int dtype, const void* d, int ldd, const void* x, int ldx, void* y, int ldy, const double* ab, int ab_replicas,
+                                  int ab_rstride, int ab_half, double count, const float* xs, const float* xt, int64_t pixels, int C, void* stream)
+{
+    return bn_backward_correct_ab(dtype, d, ldd, x, ldx, y, ldy, ab, ab_replicas, ab_rstride, ab_half, count, xs, xt, pixels, C, (hipStream_t)stream);
+}
+
+int saunet_dense_bn1_grads(const saunet_dense_bn1_list* l, void* stream)
+{
+    if (!l || l->count < 1 || l->count > SAUNET_DENSE_LAYERS_MAX || l->replicas < 1) return set_error(SAUNET_BAD_SHAPE, "dense_bn1_grads: %d layers", l ? l->count : 0);
+    int cmax = 0;
+    for (int i = 0; i < l->count; ++i) {
+        if (!l->sums[i] || !l->dgamma[i] || !l->dbeta[i] || l->cin[i] < 1) return set_error(SAUNET_BAD_SHAPE, "dense_bn1_grads: layer %d is empty", i);
+        if (l->cin[i] > cmax) cmax = l->cin[i];
+    }
+    hipLaunchKernelGGL(dense_bn1_grads_kernel, dim3((cmax + 255) / 256, l->count), dim3(256), 0, (hipStream_t)stream, *l);
+    SAUNET_CHECK_LAUNCH("dense_bn1_grads");
     return SAUNET_OK;
 }
 

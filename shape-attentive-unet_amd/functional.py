@@ -463,6 +463,7 @@ def flush_wgrad_reductions(pending):
 
 DENSE_WGRAD_GROUPED = True   # all weight gradients of a dense block as two grouped launches (False: per-layer launches)
 DENSE_COEFF_CORRECT = True   # coefficient + chunk correction of the linear BatchNorm backward in one launch (False: two)
+DENSE_BWD_FUSED = True       # bf16 training: two launches per dense layer in backward (saunet_dense_layer_backward_conv2 / _conv1; False: the round-4 four)
 
 
 def conv_wgrad_grouped(problems, ksize, pad, pro_relu):
@@ -1574,6 +1575,9 @@ class _DenseBlock(torch.autograd.Function):
                        AB[1, lo:hi].data_ptr(), xh[0, lo:hi].data_ptr(), xh[1, lo:hi].data_ptr(), P, hi - lo, L.stream())
 
         grads = [None] * (6 * nl)
+        if (DENSE_BWD_FUSED and training and buf.is_cuda and buf.dtype == torch.bfloat16 and growth == 32 and params[2].shape[0] == 128 and c0 % 8 == 0
+                and ld_of(buf) == ctot and ld_of(dbuf) == ctot and nl <= L.DENSE_LAYERS_MAX):
+            return _DenseBlock._backward_fused(ctx, buf, dbuf, xh, params, saved, grads)
         pend = [] if (buf.is_cuda and DENSE_WGRAD_BATCH_REDUCE) else None   # the 2 x L partial-gradient reductions: one launch
         # default: both weight gradients of every layer are deferred to the end of the block and issued as two GROUPED launches (every layer's
         # dz1 / corrected gradient chunk stays alive until then: 24 x 8 MB at block 3 -- nothing against 288 GB)
@@ -1627,6 +1631,72 @@ class _DenseBlock(torch.autograd.Function):
         if pend:
             flush_wgrad_reductions(pend)
         correct(0, c0)
+        dx0 = dbuf[:, :c0] if ctx.needs_input_grad[0] else None
+        return (dx0, None, None) + tuple(grads) + (None,) * (4 * nl)
+
+
+    @staticmethod
+    def _backward_fused(ctx, buf, dbuf, xh, params, saved, grads):
+        """Round 5: two launches per layer (saunet_dense_layer_backward_conv2 / _conv1) instead of four.  The BatchNorm-backward apply of
+        norm2 happens in the conv1 data gradient's operand load, the deferred chunk correction of the linear BN1 backward in the conv2
+        data gradient's (a separate streaming pass only on the maps that run the LDS-DMA staged conv2 kernel), and the per-layer
+        coefficient launch is gone: the conv1 kernel's epilogue adds scale * (sum g, sum g*xhat) to the block's running float64 sums `ab`."""
+        nl, c0, growth, count, training = ctx.meta
+        n, ctot, h, w = buf.shape
+        dev = buf.device
+        P = n * h * w
+        st = L.stream()
+        ab = new_stats(ctot, dev)
+        g = new_act(n, 128, h, w, buf.dtype, dev)                   # scratch between the two launches of a layer
+        wg1, wg2 = [], []
+        bl = L.DenseBn1List()
+        bl.count, bl.replicas = nl, STAT_R
+        keep = []
+        d = L.DenseLayerBwd()
+        d.N, d.H, d.W, d.Ctot = n, h, w, ctot
+        d.buf, d.dbuf, d.xhat, d.ld_xhat = buf.data_ptr(), dbuf.data_ptr(), xh.data_ptr(), xh.stride(0)
+        d.ab, d.ab_replicas, d.ab_rstride, d.count = ab.data_ptr(), ab.shape[0], ab.stride(0), float(count)
+        d.g = g.data_ptr()
+        for l in reversed(range(nl)):
+            n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
+            z1, p1b, p2b = saved[3 * l:3 * l + 3]
+            cin = c0 + growth * l
+            dz1 = new_act(n, 128, h, w, buf.dtype, dev)
+            dz2 = new_act(n, growth, h, w, buf.dtype, dev) if l + 1 < nl else None      # the last chunk has no consumer inside the block: nothing to correct
+            s2, s1 = new_stats(128, dev), new_stats(cin, dev)
+            dgb2 = torch.empty(2, 128, dtype=torch.float32, device=dev)
+            dgb1 = torch.empty(2, cin, dtype=torch.float32, device=dev)
+            w2p, w1p = PACKS.get(c2w, L.PACK_DGRAD, buf.dtype), PACKS.get(c1w, L.PACK_DGRAD, buf.dtype)
+            d.Cin = cin
+            d.z1, d.dz1, d.dz2 = z1.data_ptr(), dz1.data_ptr(), (dz2.data_ptr() if dz2 is not None else None)
+            d.w2_dgrad, d.w1_dgrad, d.p1, d.p2 = w2p.data_ptr(), w1p.data_ptr(), p1b.data_ptr(), p2b.data_ptr()
+            d.sums2, d.sums2_replicas, d.sums2_rstride = s2.data_ptr(), s2.shape[0], s2.stride(0)
+            d.sums1, d.sums1_replicas, d.sums1_rstride = s1.data_ptr(), s1.shape[0], s1.stride(0)
+            d.dgamma2, d.dbeta2 = dgb2[0].data_ptr(), dgb2[1].data_ptr()
+            L.call("saunet_dense_layer_backward_conv2", C.byref(d), st)
+            L.call("saunet_dense_layer_backward_conv1", C.byref(d), st)
+            wg2.append((l, z1, dz2 if dz2 is not None else dbuf[:, cin:cin + growth], c2w, (p2b[0], p2b[1])))
+            wg1.append((l, buf[:, :cin], dz1, c1w, (p1b[0], p1b[1])))
+            bl.sums[l], bl.rstride[l], bl.cin[l] = s1.data_ptr(), s1.stride(0), cin
+            bl.dgamma[l], bl.dbeta[l] = dgb1[0].data_ptr(), dgb1[1].data_ptr()
+            keep += [s1, s2, w2p, w1p]
+            grads[6 * l], grads[6 * l + 1], grads[6 * l + 3], grads[6 * l + 4] = dgb1[0], dgb1[1], dgb2[0], dgb2[1]
+        L.call("saunet_dense_bn1_grads", C.byref(bl), st)
+        pend = [] if DENSE_WGRAD_BATCH_REDUCE else None
+        for plist, slot, ks, pd in ((wg2, 5, 3, 1), (wg1, 2, 1, 0)):
+            dws = conv_wgrad_grouped([(x_, dy_, w_, pro_) for (_l, x_, dy_, w_, pro_) in plist], ks, pd, True) if DENSE_WGRAD_GROUPED else None
+            if dws is None:        # geometry off the tiled kernels (maps that are not multiples of the 16-pixel tile): per-layer launches
+                dws = [conv_wgrad_raw(x_, dy_, w_, 1, pd, pro=(pro_[0], pro_[1], True), pending=pend) for (_l, x_, dy_, w_, pro_) in plist]
+            for (l_, *_rest), dw_ in zip(plist, dws):
+                grads[6 * l_ + slot] = dw_
+        if pend:
+            flush_wgrad_reductions(pend)
+        dt = L.dtype_code(buf)
+        for lo in range(0, c0, 256):      # the block's input channels: corrected in place, they are the gradient handed upstream
+            hi = min(lo + 256, c0)
+            dsl, xsl = dbuf[:, lo:hi], buf[:, lo:hi]
+            L.call("saunet_bn_backward_correct_ab", dt, dsl.data_ptr(), ctot, xsl.data_ptr(), ctot, dsl.data_ptr(), ctot, ab[0, 0, lo:hi].data_ptr(),
+                   ab.shape[0], ab.stride(0), ctot, float(count), xh[0, lo:hi].data_ptr(), xh[1, lo:hi].data_ptr(), P, hi - lo, st)
         dx0 = dbuf[:, :c0] if ctx.needs_input_grad[0] else None
         return (dx0, None, None) + tuple(grads) + (None,) * (4 * nl)
 

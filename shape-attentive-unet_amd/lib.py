@@ -61,6 +61,27 @@ class WgradGroup(C.Structure):
     _fields_ = [(n, C.c_int32) for n in "dtype N H W KH pad pro_relu count".split()] + [("item", WgradGroupItem * WGRAD_GROUP_MAX)]
 
 
+class DenseLayerBwd(C.Structure):
+    """saunet_dense_layer_bwd"""
+    _fields_ = [(n, C.c_int32) for n in "N H W Cin Ctot reserved".split()] + [
+        ("buf", C.c_void_p), ("dbuf", C.c_void_p), ("xhat", C.c_void_p), ("ld_xhat", C.c_int32), ("reserved2", C.c_int32),
+        ("ab", C.c_void_p), ("ab_replicas", C.c_int32), ("ab_rstride", C.c_int32), ("count", C.c_double),
+        ("z1", C.c_void_p), ("g", C.c_void_p), ("dz1", C.c_void_p), ("dz2", C.c_void_p), ("w2_dgrad", C.c_void_p), ("w1_dgrad", C.c_void_p),
+        ("p1", C.c_void_p), ("p2", C.c_void_p),
+        ("sums2", C.c_void_p), ("sums2_replicas", C.c_int32), ("sums2_rstride", C.c_int32),
+        ("sums1", C.c_void_p), ("sums1_replicas", C.c_int32), ("sums1_rstride", C.c_int32),
+        ("dgamma2", C.c_void_p), ("dbeta2", C.c_void_p)]
+
+
+DENSE_LAYERS_MAX = 64
+
+
+class DenseBn1List(C.Structure):
+    """saunet_dense_bn1_list"""
+    _fields_ = [("count", C.c_int32), ("replicas", C.c_int32), ("sums", C.c_void_p * DENSE_LAYERS_MAX), ("rstride", C.c_int32 * DENSE_LAYERS_MAX),
+                ("cin", C.c_int32 * DENSE_LAYERS_MAX), ("dgamma", C.c_void_p * DENSE_LAYERS_MAX), ("dbeta", C.c_void_p * DENSE_LAYERS_MAX)]
+
+
 class TensorList(C.Structure):
     _fields_ = [("count", C.c_int32), ("ptrs", (C.c_void_p * 96) * 4), ("numel", C.c_int64 * 96)]
 
@@ -95,6 +116,10 @@ _SIGS = {
     "saunet_bn_backward_coeff": [i32, vp, i32, i32, f64, vp, vp, vp, vp, vp, i32, vp],
     "saunet_bn_backward_correct": [i32, vp, i32, vp, i32, vp, vp, vp, vp, i64, i32, vp],
     "saunet_bn_backward_coeff_correct": [i32, i32, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp, vp, i64, vp],
+    "saunet_dense_layer_backward_conv2": [C.POINTER(DenseLayerBwd), vp],
+    "saunet_dense_layer_backward_conv1": [C.POINTER(DenseLayerBwd), vp],
+    "saunet_bn_backward_correct_ab": [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, f64, vp, vp, i64, i32, vp],
+    "saunet_dense_bn1_grads": [C.POINTER(DenseBn1List), vp],
     "saunet_bilinear_forward": [i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp],
     "saunet_bilinear_backward": [i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp],
     "saunet_im2col": [i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp],

@@ -187,3 +187,48 @@ def test_whole_block_grouped_weight_gradients_match_the_per_layer_launches(dtype
     tol = 2e-5 if dtype == torch.float32 else 2e-3
     for k in grads[True]:
         assert rel(grads[True][k], grads[False][k]) < tol, (k, rel(grads[True][k], grads[False][k]))
+
+
+@pytest.mark.parametrize("layers,cin,shape", [(4, 64, (4, 32, 32)),        # per-wave conv2 kernel with the correction in its operand load; NS = 1 ... 3 conv1 variants
+                                              (3, 256, (8, 16, 16)),       # block-4-like: Cin 256 ... 320 in 64-channel groups
+                                              (3, 64, (4, 128, 128)),      # 256 tiles: LDS-DMA staged conv2 kernel + separate correction pass
+                                              (2, 96, (1, 16, 48)),        # non-square map
+                                              (3, 40, (3, 8, 8))])         # map below the 16-pixel tile: per-layer weight gradients
+def test_fused_layer_backward_matches_the_four_launch_backward(layers, cin, shape):
+    """Round 5: saunet_dense_layer_backward_conv2 / _conv1 (BN2-backward apply and the chunk correction folded into the data gradients' operand
+    loads, coefficient sums in the conv1 kernel's epilogue) against the round-4 sequence dgrad3 -> bn_bwd_apply -> dgrad1 -> coeff_correct on
+    the same bf16 block.  Both round dz1 and the corrected chunk to bf16 at the same points, so they agree to accumulation-order noise; and the
+    fused path is held to float64 like every other path (torchvision _DenseLayer backward, /root/reference/models/models.py:306-313)."""
+    import saunet_amd as S
+    HF = S.functional
+    torch.manual_seed(17 + layers)
+    n, h, w = shape
+    dtype = torch.bfloat16
+    block = S.modules._DenseBlock(layers, cin).cuda().train()
+    with torch.no_grad():
+        for m in block.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(4.0, 6.0)       # away from the ReLU kink: no mask flips between the runs
+    x0 = torch.randn(n, cin, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    cot, grads = None, {}
+    assert HF.DENSE_BWD_FUSED is True
+    try:
+        for fused in (True, False):
+            HF.DENSE_BWD_FUSED = fused
+            block.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            y = block(x)
+            if cot is None:
+                cot = torch.randn(y.shape, device="cuda").to(dtype)
+            (y.float() * cot.float()).sum().backward()
+            grads[fused] = {"x": x.grad.float().clone(), **{k: v.grad.float().clone() for k, v in block.named_parameters()}}
+    finally:
+        HF.DENSE_BWD_FUSED = True
+    ry, xr, prm = ref_block(block, x0)
+    (ry * cot.double()).sum().backward()
+    ref = {"x": xr.grad, **{k: prm[k].grad for k in prm}}
+    for k in grads[True]:
+        assert rel_l2(grads[True][k], grads[False][k]) < 1e-2, (k, rel_l2(grads[True][k], grads[False][k]))
+        # neither path may be further from float64 than bf16 storage explains (the unfused path is the yardstick)
+        e_f, e_u = rel_l2(grads[True][k], ref[k]), rel_l2(grads[False][k], ref[k])
+        assert e_f < max(1.5 * e_u, 2e-2), (k, e_f, e_u)
