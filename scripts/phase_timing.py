@@ -10,10 +10,11 @@ dt = torch.bfloat16
 n = 32
 def act(c, h): return torch.randn(n, c, h, h, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
 unit = "conv_tile"
-if case == "conv2fwd":
-    x = act(128, 128); w = torch.nn.Parameter(torch.randn(32, 128, 3, 3, device="cuda") * 0.03)
+if case in ("conv2fwd", "conv2fwd3", "conv2fwd4"):
+    hh = {"conv2fwd": 128, "conv2fwd3": 32, "conv2fwd4": 16}[case]
+    x = act(128, hh); w = torch.nn.Parameter(torch.randn(32, 128, 3, 3, device="cuda") * 0.03)
     sc = torch.rand(128, device="cuda") + 0.5; sh = torch.randn(128, device="cuda") * 0.1
-    out = HF.new_act(n, 32, 128, 128, dt, "cuda"); st = torch.zeros(HF.STAT_R, 2, 32, dtype=torch.float64, device="cuda")
+    out = HF.new_act(n, 32, hh, hh, dt, "cuda"); st = torch.zeros(HF.STAT_R, 2, 32, dtype=torch.float64, device="cuda")
     run = lambda: HF.conv_forward_raw(x, w, None, 1, 1, pro=(sc, sh, True), out=out, stats=st)
 elif case in ("conv2wgrad", "conv1wgrad", "dec3wgrad"):
     cin, h, cout, k = {"conv2wgrad": (128, 128, 32, 3), "conv1wgrad": (192, 128, 128, 1), "dec3wgrad": (512, 64, 128, 3)}[case]

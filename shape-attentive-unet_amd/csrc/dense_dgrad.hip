@@ -661,6 +661,9 @@ static int launch_dense_dgrad(DenseDgradArgs& a, bool apply, hipStream_t st)
     // low-resolution blocks where the copy would dominate and more blocks are needed to fill the chip
     const long ntp = ((long)a.P + 31) / 32;
     a.group = ntp >= 4096 ? DG_GROUP : (ntp >= 1024 ? 128 : 64);
+    static const int force_group = ab_env_int("SAUNET_DG_GROUP", 0), force_small = ab_env_int("SAUNET_DG_GROUP_SMALL", 0);     // A/B (variant builds only)
+    if (force_group > 0) a.group = force_group;
+    if (force_small > 0 && ntp < 4096) a.group = force_small;
     {   // equal groups: every group runs the same number of 64-channel steps (the step sequence is compiled per step count), so
         // Cin = 320 with at most 256 channels per group is 2 x 160, not 256 + 64
         const int ng = (a.Cin + a.group - 1) / a.group;
@@ -676,6 +679,8 @@ static int launch_dense_dgrad(DenseDgradArgs& a, bool apply, hipStream_t st)
     // ones retire and double the kernel time (515 blocks for Cin = 640 at 32 x 32 ran 60 us, 512 blocks for Cin = 992 61 us); at least one
     // pixel tile per wave
     long bx = 512 / groups; const long maxbx = ((long)a.P + 32 * DG_WAVES - 1) / (32 * DG_WAVES);
+    static const int small_blocks = ab_env_int("SAUNET_DG_BLOCKS_SMALL", 0);       // A/B (variant builds only): total blocks on the small maps
+    if (small_blocks > 0 && ntp < 4096) bx = small_blocks / groups;
     if (bx > maxbx) bx = maxbx; if (bx < 1) bx = 1;
     static DeviceOnce attr;
     if (attr.first()) {

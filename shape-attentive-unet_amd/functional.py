@@ -463,7 +463,7 @@ def flush_wgrad_reductions(pending):
 
 DENSE_WGRAD_GROUPED = True   # all weight gradients of a dense block as two grouped launches (False: per-layer launches)
 DENSE_COEFF_CORRECT = True   # coefficient + chunk correction of the linear BatchNorm backward in one launch (False: two)
-DENSE_BWD_FUSED = True       # bf16 training: two launches per dense layer in backward (saunet_dense_layer_backward_conv2 / _conv1; False: the round-4 four)
+DENSE_BWD_FUSED = os.environ.get("SAUNET_DENSE_BWD_FUSED", "1") != "0"       # bf16 training: two launches per dense layer in backward (saunet_dense_layer_backward_conv2 / _conv1; False: the round-4 four)
 
 
 def conv_wgrad_grouped(problems, ksize, pad, pro_relu):

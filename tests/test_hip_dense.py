@@ -228,7 +228,9 @@ def test_fused_layer_backward_matches_the_four_launch_backward(layers, cin, shap
     (ry * cot.double()).sum().backward()
     ref = {"x": xr.grad, **{k: prm[k].grad for k in prm}}
     for k in grads[True]:
-        assert rel_l2(grads[True][k], grads[False][k]) < 1e-2, (k, rel_l2(grads[True][k], grads[False][k]))
-        # neither path may be further from float64 than bf16 storage explains (the unfused path is the yardstick)
-        e_f, e_u = rel_l2(grads[True][k], ref[k]), rel_l2(grads[False][k], ref[k])
+        # neither path may be further from float64 than bf16 storage explains (the unfused path is the yardstick), and the two agree to
+        # accumulation-order noise -- except where the gradient itself is rounding noise: with no unit masked, norm1's bias gradient is the pixel
+        # sum of a BatchNorm-backward output, analytically ~0, and both paths sit 10-20 % (of that tiny norm) from float64
+        e_f, e_u, e_fu = rel_l2(grads[True][k], ref[k]), rel_l2(grads[False][k], ref[k]), rel_l2(grads[True][k], grads[False][k])
+        assert e_fu < max(1e-2, 1.5 * e_u), (k, e_fu, e_u)
         assert e_f < max(1.5 * e_u, 2e-2), (k, e_f, e_u)
