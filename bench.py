@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--dry-run", action="store_true", help="host-side rehearsal of the N>1 path WITHOUT a GPU (gloo): real SAUNet parameter set, "
                     "synthetic gradients, bucketed all-reduce overlapped with the backward hooks, timing protocol and JSON line; no kernel runs")
+    ap.add_argument("--share-gpu", action="store_true", help="REHEARSAL of the N>1 path on a 1-GPU box: the N ranks run the real HIP step on the SAME GPU and "
+                    "exchange gradients / SyncBN statistics over gloo (SAUNET_SHARE_GPU=1, SAUNET_DIST_BACKEND=gloo): real kernels, real bucket / hook / "
+                    "overlap logic and the bench's own timing protocol; the line is marked `rehearsal` and carries no multi-GPU `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "radam"])
@@ -500,6 +503,8 @@ def self_launch(args):
     import subprocess
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ)
+    if args.share_gpu:
+        env.update(SAUNET_SHARE_GPU="1", SAUNET_DIST_BACKEND="gloo")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
@@ -532,6 +537,8 @@ def main():
         return
     if args.dry_run:
         return dry_run(args, S, dp)
+    if args.share_gpu:
+        os.environ.update(SAUNET_SHARE_GPU="1", SAUNET_DIST_BACKEND="gloo")
     rank, local, world = dp.init_from_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but %d rank(s) were launched" % (args.gpus, world))
@@ -631,11 +638,20 @@ def main():
         if buckets is not None and buckets.exposed_events is not None:
             exposed = buckets.exposed_events[0].elapsed_time(buckets.exposed_events[1])
         payload = sum(p.numel() for p in buckets.params) * 4 if buckets is not None else 0
+        table = buckets.bucket_table() if buckets is not None else []
+        span = (max(r["done_ms"] for r in table) - min(r["launch_ms"] for r in table)) if table and all("done_ms" in r for r in table) else None
+        # every replica must hold the same parameters after the same number of averaged updates (weights are broadcast once, then only
+        # all-reduced gradients move them): float64 checksum of every parameter, min == max over ranks
+        chk = torch.stack([p.detach().double().sum() for p in net.parameters()])
+        lo, hi = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN); torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         comm = {"backend": torch.distributed.get_backend(), "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.get_backend() == "nccl" else 0,
                 "buckets": len(buckets.buckets) if buckets is not None else 0, "bucket_mb": args.bucket_mb, "allreduce_payload_bytes": payload,
                 "exposed_allreduce_ms_last_step": None if exposed is None else round(exposed, 3),
-                "bucket_table_last_step": buckets.bucket_table() if buckets is not None else [],
-                "syncbn_allreduces_per_step": 12}
+                "allreduce_span_ms_last_step": None if span is None else round(span, 3),
+                "bucket_table_last_step": table,
+                "syncbn_allreduces_per_step": S.functional.SYNCBN_ALLREDUCES["last_step"],
+                "replicas_identical": bool(torch.equal(lo, hi)), "physical_gpus": torch.cuda.device_count()}
     final_loss = float(loss.detach().float())
 
     if rank == 0:
@@ -654,7 +670,12 @@ def main():
         }
         if comm is not None:
             out["comm"] = comm
-        if not args.no_roofline:
+        if args.share_gpu and world > 1:
+            # N ranks time-share ONE GPU: the aggregate is not an N-GPU measurement and must never be read as one
+            out["rehearsal"] = "%d ranks share 1 GPU over gloo: real HIP step + bucketed all-reduce / SyncBN exchange under the bench's timing protocol; not a scaling measurement" % world
+            out["rehearsal_slices_per_s"] = out["value"]
+            out["value"] = None
+        if not args.no_roofline and not (args.share_gpu and world > 1):
             try:
                 out["roofline"] = kernel_roofline(S, dtype, args.batch, args.size, launch_mix=not args.no_launch_mix)
                 out["roofline"]["traffic"] = pmc_traffic(out["roofline"]["kernel"])

@@ -108,8 +108,12 @@ def capturing():
     return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
+SYNCBN_ALLREDUCES = {"count": 0, "last_step": 0}      # SyncBN statistic exchanges issued since the last begin_step() / during the last full step
+
+
 def begin_step():
     """Called at the start of every SAUNet forward: new scratch arenas, all weight packings refreshed in bulk."""
+    SYNCBN_ALLREDUCES["last_step"], SYNCBN_ALLREDUCES["count"] = SYNCBN_ALLREDUCES["count"], 0
     STATS.reset(); GRADS.reset()
     PACKS.prepack()
 
@@ -670,6 +674,7 @@ def bn_backward(dy, x, p, relu, count, training, residual=None, dx=None, accumul
         # are averaged with all other parameter gradients afterwards, so they must come from the local sums
         local = sums.clone()
         torch.distributed.all_reduce(sums, group=sync_group)
+        SYNCBN_ALLREDUCES["count"] += 1
     if dx is None:
         dx = new_act(n, c, h, w, x.dtype, dev)
     dres = new_act(n, c, h, w, x.dtype, dev) if want_dres else None
@@ -746,6 +751,7 @@ class _ConvBNAct(torch.autograd.Function):
                 raise RuntimeError("synchronised batch norm behind a biased convolution is not on the SAUNet path")
             flat = collapse_stats(stats)
             torch.distributed.all_reduce(flat, group=group)
+            SYNCBN_ALLREDUCES["count"] += 1
             count *= torch.distributed.get_world_size(group)
             p = BNParams(cout, x.device)
             tm, tv, it = sync_bufs if sync_bufs is not None else (None, None, None)

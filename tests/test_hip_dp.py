@@ -98,3 +98,36 @@ def test_rccl_ranks_match_dp_emulation(tmp_path, world):
     res = launch(tmp_path, world, 2, "nccl")
     assert res["backend"] == "nccl"
     check(res, world, 2, 1.2e-2)
+
+
+def test_bench_rehearsal_two_ranks_share_the_gpu():
+    """`bench.py --gpus 2 --share-gpu`: the bench's own N > 1 protocol -- self-launch of one rank per requested GPU, parameter
+    broadcast, hook-launched bucket all-reduces overlapped with the backward kernels, the first-step bucket rebuild (encoder.classifier has no
+    gradient), the 12 SyncBN statistic all-reduces of res1-3, barrier + max-over-ranks timing -- with the REAL HIP step on both ranks, on the one
+    GPU of this box over gloo.  The line is marked as a rehearsal and carries no multi-GPU value.  /root/reference/train.py:272-277 (one replica
+    per device), lib/nn/modules/batchnorm.py:98-139 (SyncBN exchange)."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SAUNET_SHARE_GPU", "SAUNET_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "3", "--warmup", "2", "--batch", "4",
+                        "--size", "128", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["value"] is None and "rehearsal" in rec and rec["rehearsal_slices_per_s"] > 0
+    assert rec["config"]["global_batch"] == 8 and rec["config"]["parallelism"] == "dp2"
+    comm = rec["comm"]
+    assert comm["backend"] == "gloo" and comm["rccl_ranks"] == 0 and comm["physical_gpus"] >= 1
+    assert comm["replicas_identical"] is True
+    # 31.9 M float32 gradients (127.5 MB) in buckets of at most 32 MB, cut at parameter boundaries in reverse registration order: 6 buckets
+    # of 13.8 - 33.4 MB (a parameter that would overflow the cap opens the next bucket; center / dec5 hold 4.7 - 7.1 M-element tensors)
+    assert comm["buckets"] == 6 and len(comm["bucket_table_last_step"]) == 6
+    assert sum(row["MB"] for row in comm["bucket_table_last_step"]) == pytest.approx(comm["allreduce_payload_bytes"] / 1e6, rel=1e-3)
+    assert comm["syncbn_allreduces_per_step"] == 12                                     # 6 SyncBN layers x (forward statistics + backward sums)
+    # overlap: the compute stream waited for less than the exchange took from the first launch to the last completion
+    assert comm["exposed_allreduce_ms_last_step"] is not None and comm["allreduce_span_ms_last_step"] is not None
+    assert comm["exposed_allreduce_ms_last_step"] < comm["allreduce_span_ms_last_step"], comm
+    launches = [row["launch_ms"] for row in comm["bucket_table_last_step"]]
+    assert launches == sorted(launches) and launches[-1] > launches[0]                  # buckets leave one by one as backward produces them
