@@ -134,6 +134,263 @@ def kernel_roofline(S, dtype, batch, size, launch_mix=True):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Live per-kernel census of one real training step: which kernels dominate is READ from the committed rocprofv3
+# summary of this round, and each of them is timed here over its real launch mix -- not one favourable geometry of one kernel.
+STATS_FILE = os.path.join("profiles", "r05_f_step_kernel_stats.txt")
+
+
+def _norm_symbol(name):
+    """rocprofv3 row / launch-log name -> 'xyz_kernel<unsigned short, 64, ...>' (namespace, return type and argument list dropped)"""
+    n = name.strip().replace("void saunet::", "").replace("saunet::", "")
+    depth, cut = 0, len(n)
+    for i, ch in enumerate(n):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    n = n[:cut].strip()
+    if "_kernel" not in n and "<" not in n:
+        n += "_kernel"
+    return n
+
+
+def _family(sym):
+    return sym.split("<")[0]
+
+
+def read_kernel_ranking(path=None):
+    """(symbols, families) of the committed per-step kernel table: [(symbol, us_per_step, calls_per_step)], largest first.  None if absent."""
+    path = path or os.path.join(ROOT, STATS_FILE)
+    try:
+        rows = []
+        section = "symbols"
+        for line in open(path):
+            if line.startswith("# [families]"):
+                section = "families"
+            elif line.startswith("# [symbols]"):
+                section = "symbols"
+            if line.startswith("#") or line.startswith("calls") or not line.strip() or section != "symbols":
+                continue
+            f = line.split(None, 5)
+            if len(f) < 6 or not f[0].isdigit():
+                continue
+            rows.append((_norm_symbol(f[5]), float(f[4]), float(f[0])))
+        steps = None
+        for line in open(path):
+            if "/step = total /" in line:
+                steps = float(line.split("/step = total /")[1].split()[0])
+        rows = [(sym, us, calls / (steps or 1.0)) for sym, us, calls in rows if "rocclr" not in sym and "at::native" not in sym]
+        rows.sort(key=lambda r: -r[1])
+        fam = {}
+        for sym, us, calls in rows:
+            e = fam.setdefault(_family(sym), [0.0, 0.0, 0])
+            e[0] += us; e[1] += calls; e[2] += 1
+        fams = sorted(((k, v[0], v[1], v[2]) for k, v in fam.items()), key=lambda r: -r[1])
+        return rows, fams
+    except Exception:
+        return None
+
+
+_SECONDARY = ("wgrad_reduce", "bn_bwd_correct_ab", "conv3x3_mm_finish", "bn_prologue_finalize")
+
+
+def _main_symbol(log):
+    """a library call may launch a helper next to its main kernel ('conv_tile_wgrad_grouped_kernel<..>+wgrad_reduce_multi'): the call's
+    HIP-event time is attributed to the main kernel and the helpers are listed under `includes`"""
+    parts = [_norm_symbol(x) for x in log.split("+") if x]
+    main = [x for x in parts if not _family(x).replace("_kernel", "").startswith(_SECONDARY)]
+    return (main[0] if main else parts[0]), [x for x in parts if x != (main[0] if main else parts[0])]
+
+
+def _call_work(name, args, esz):
+    """(algorithmic bytes, FLOPs) of one library call, SURVEY 8(d) accounting: every operand read once, every result written once (+ the
+    read of the accumulate target), weights once; None for entries that are not priced."""
+    def obj(a):
+        return getattr(a, "_obj", a)
+    if name in ("saunet_conv2d_forward", "saunet_conv2d_forward_ex", "saunet_conv2d_forward_bnpro"):
+        d = obj(args[0])
+        taps = 16 if d.transposed else d.KH * d.KW
+        pin, pout = d.N * d.H * d.W, d.N * d.Ho * d.Wo
+        by = (pin * d.Cin + pout * d.Cout + taps * d.Cin * d.Cout) * esz
+        if name == "saunet_conv2d_forward_ex" and args[9] is not None:
+            e = obj(args[9])
+            if e.bn_x:
+                by += pout * d.Cout * esz                       # the tensor the fused BatchNorm backward normalised
+            if e.accumulate:
+                by += pout * d.Cout * esz                       # y is read before it is written
+        mac_px = pin if d.transposed else pout                  # conv-transpose: 16 taps per INPUT pixel
+        return by, 2.0 * mac_px * taps * d.Cin * d.Cout
+    if name == "saunet_dense_layer_backward_conv2":
+        l = obj(args[0]); P = l.N * l.H * l.W
+        chunk = 3 * 32 if l.dz2 else 32                          # gradient chunk (+ its activations and the corrected copy)
+        return (P * (chunk + 128 + 128) + 9 * 32 * 128) * esz, 2.0 * P * 288 * 128
+    if name == "saunet_dense_layer_backward_conv1":
+        l = obj(args[0]); P = l.N * l.H * l.W
+        return (P * (3 * 128 + 3 * l.Cin) + 128 * l.Cin) * esz, 2.0 * P * 128 * l.Cin
+    if name == "saunet_bn_backward_apply":
+        P, Cc = args[24], args[25]
+        return P * Cc * esz * (3 + (1 if args[17] else 0) + (1 if args[5] else 0) + (1 if args[20] else 0)), 0.0
+    if name == "saunet_bn_backward_reduce":
+        return args[15] * args[16] * esz * (2 + (1 if args[5] else 0)), 0.0
+    if name == "saunet_affine_act":
+        return args[10] * args[11] * esz * (2 + (1 if args[5] else 0)), 0.0
+    if name == "saunet_affine_act_pool":
+        return args[8] * args[9] * esz * 2, 0.0
+    if name in ("saunet_conv2d_wgrad", "saunet_conv2d_wgrad_deferred"):
+        d = obj(args[0])
+        taps = 16 if d.transposed else d.KH * d.KW
+        pin, pout = d.N * d.H * d.W, d.N * d.Ho * d.Wo
+        return (pin * d.Cin + pout * d.Cout) * esz + taps * d.Cin * d.Cout * 4, 2.0 * (pin if d.transposed else pout) * taps * d.Cin * d.Cout
+    if name == "saunet_conv2d_wgrad_grouped":
+        g = obj(args[0]); P = g.N * g.H * g.W
+        by = fl = 0.0
+        for i in range(g.count):
+            it = g.item[i]
+            by += P * (it.Cin + it.Cout) * esz + g.KH * g.KH * it.Cin * it.Cout * 4
+            fl += 2.0 * P * g.KH * g.KH * it.Cin * it.Cout
+        return by, fl
+    if name == "saunet_bn_backward_correct_ab":
+        return args[14] * args[15] * esz * 3, 0.0
+    if name == "saunet_bn_backward_coeff_correct":
+        return args[21] * (args[18] - args[17]) * esz * 3, 0.0
+    return None
+
+
+def live_kernel_census(S, step_fn, dtype):
+    """ONE eager training step with HIP events (recorded on the launch stream = torch's current stream) around every call into
+    libsaunet_hip.so.  The GPU is held back by a spin kernel while the host queues the step, so the launches execute back to back as they do
+    inside the captured graph and an event pair brackets a kernel's execution + its launch boundary, not host gaps.  The kernel(s) behind
+    a call come from the library's own launch log (saunet_launch_log), so the attribution follows the real dispatch.
+    -> {symbol: {"ms", "launches", "algorithmic_bytes", "flops", "priced_ms", "includes"}} for this step."""
+    L = S.lib
+    handle = L.load()
+    orig = L.call
+    esz = 2 if dtype == torch.bfloat16 else 4
+    recs = []
+
+    def traced(name, *args):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        handle.saunet_launch_log()                         # drop anything logged outside a traced call
+        e0.record()
+        orig(name, *args)
+        e1.record()
+        log = handle.saunet_launch_log()
+        recs.append((name, (log or b"").decode(), e0, e1, _call_work(name, args, esz)))
+
+    step_fn(); torch.cuda.synchronize()                    # allocator pools / packings warm
+    # calibrate the spin kernel, then hold the GPU for ~1.5x the host time of an eager step
+    t0 = time.perf_counter(); step_fn(); host_ms = (time.perf_counter() - t0) * 1e3
+    torch.cuda.synchronize()
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record(); torch.cuda._sleep(1000000); c1.record(); torch.cuda.synchronize()
+    per_ms = 1000000 / max(c0.elapsed_time(c1), 1e-3)
+    L.call = traced
+    nulls = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(8)]
+    try:
+        torch.cuda._sleep(int(per_ms * min(1.5 * host_ms + 10.0, 400.0)))
+        step_fn()
+        for a_, b_ in nulls:                               # empty event pairs in the same queue: what the bracketing itself costs
+            a_.record(); b_.record()
+    finally:
+        L.call = orig
+    torch.cuda.synchronize()
+    live_kernel_census.event_pair_overhead_us = round(sorted(a_.elapsed_time(b_) for a_, b_ in nulls)[len(nulls) // 2] * 1e3, 2)
+    out = {}
+    for name, log, e0, e1, work in recs:
+        if not log:
+            continue
+        sym, inc = _main_symbol(log)
+        ms = e0.elapsed_time(e1)
+        r = out.setdefault(sym, {"ms": 0.0, "launches": 0, "algorithmic_bytes": 0.0, "flops": 0.0, "priced_ms": 0.0, "includes": set()})
+        r["ms"] += ms; r["launches"] += 1; r["includes"].update(inc)
+        if work is not None:
+            r["algorithmic_bytes"] += work[0]; r["flops"] += work[1]; r["priced_ms"] += ms
+    return out
+
+
+def _roofline_entry(label, ms, launches, nbytes, flops, dtype, extra=None):
+    peak_tf = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
+    e = {"kernel": label, "ms": round(ms, 4), "launches": int(launches), "algorithmic_bytes": int(nbytes), "traffic": None}
+    if ms <= 0 or nbytes <= 0:
+        e.update(bound=None, achieved=None, peak=None, unit=None, frac=None)
+        return e
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    tfl = flops / (ms * 1e-3) / 1e12
+    ai = flops / nbytes
+    if ai * HBM_PEAK_GBS / 1e3 < peak_tf:
+        e.update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), tflops=round(tfl, 1))
+    else:
+        e.update(bound="mfma", achieved=round(tfl, 1), peak=peak_tf, unit="TFLOP/s", frac=round(tfl / peak_tf, 4), gbs=round(gbs, 1))
+    e["flop_per_byte"] = round(ai, 1)
+    if extra:
+        e.update(extra)
+    return e
+
+
+def census_roofline(S, step_fn, dtype, args):
+    """`roofline` of the bench line.  The kernel ranking is read from the committed rocprofv3 summary of this round (profiles/r05_*): its
+    top three SYMBOLS are reported one by one, its largest FAMILY (all template instances of one kernel) gives the headline `frac` -- each
+    timed live over its real launch mix of one step (live_kernel_census), algorithmic bytes per SURVEY 8(d), HBM traffic from the committed
+    whole-step PMC passes (profiles/step_pmc.json `per_kernel`, FETCH_SIZE x 2 + WRITE_SIZE per the guide's gfx950 correction)."""
+    rank = read_kernel_ranking()
+    census = live_kernel_census(S, step_fn, dtype)
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "step_pmc.json")) as f:
+            rec = json.load(f)
+        if rec.get("config") == [args.size, args.batch, args.dtype]:
+            pmc = {_norm_symbol(k): v for k, v in rec.get("per_kernel", {}).items()}
+    except Exception:
+        pass
+    if rank is None:
+        # no committed table (a fresh checkout mid-round): rank by the live census itself and say so
+        syms = sorted(((k, v["ms"] * 1e3, v["launches"]) for k, v in census.items()), key=lambda r: -r[1])
+        fam = {}
+        for sym, us, calls in syms:
+            e = fam.setdefault(_family(sym), [0.0, 0.0, 0]); e[0] += us; e[1] += calls; e[2] += 1
+        fams = sorted(((k, v[0], v[1], v[2]) for k, v in fam.items()), key=lambda r: -r[1])
+        source = "live census (no committed %s)" % STATS_FILE
+    else:
+        syms, fams = rank
+        source = STATS_FILE
+
+    def entry_for(symbols, label, rocprof_us):
+        ms = sum(census[s_]["ms"] for s_ in symbols if s_ in census)
+        pms = sum(census[s_]["priced_ms"] for s_ in symbols if s_ in census)
+        n = sum(census[s_]["launches"] for s_ in symbols if s_ in census)
+        by = sum(census[s_]["algorithmic_bytes"] for s_ in symbols if s_ in census)
+        fl = sum(census[s_]["flops"] for s_ in symbols if s_ in census)
+        inc = sorted(set().union(*[census[s_]["includes"] for s_ in symbols if s_ in census])) if any(s_ in census for s_ in symbols) else []
+        # bytes are known for the priced calls only: the rate is taken over THEIR time (ms stays the whole symbol's time)
+        e = _roofline_entry(label, pms if pms > 0 else ms, n, by, fl, dtype)
+        e["ms"] = round(ms, 4)
+        e["priced_fraction_of_ms"] = round(pms / ms, 3) if ms > 0 else None
+        e["rocprof_ms_per_step"] = round(rocprof_us / 1e3, 4) if rocprof_us is not None else None
+        tr = [pmc[s_]["traffic_bytes_per_step"] for s_ in symbols if s_ in pmc]
+        e["traffic"] = int(sum(tr)) if tr else None
+        if inc:
+            e["includes"] = inc
+        return e
+    kernels = [entry_for([sym], sym, us) for sym, us, _ in syms[:3]]
+    top_family = fams[0][0]
+    members = [sym for sym, _, _ in syms if _family(sym) == top_family]
+    if rank is None:
+        members = [k for k in census if _family(k) == top_family]
+    out = entry_for(members, "%s (%d template instances, whole launch mix of the step)" % (top_family, len(members)), fams[0][1])
+    out["ranking_source"] = source
+    out["timing"] = ("HIP events on the launch stream around every library call of ONE eager step queued behind a spin kernel (launches run back to back); "
+                     "an event pair brackets the kernel AND its launch boundary (1.5-3 us per launch on this chip), so `ms` sits above the "
+                     "rocprofv3 kernel-only duration by about that much per launch")
+    out["empty_event_pair_us"] = getattr(live_kernel_census, "event_pair_overhead_us", None)
+    out["kernels"] = kernels
+    out["families"] = [{"family": k, "rocprof_ms_per_step": round(us / 1e3, 4), "launches": round(c, 1)} for k, us, c, _ in fams[:6]]
+    return out
+
+
 def weakest_family_roofline(S, dtype, batch, size):
     """Second roofline entry: the WEAKEST large MFMA-priced kernel family of the step next to the healthiest one.  Three candidates
     are timed live with HIP events at the step's geometry and the one with the lowest fraction of the dense matrix-core peak is reported (all
@@ -677,13 +934,18 @@ def main():
             out["value"] = None
         if not args.no_roofline and not (args.share_gpu and world > 1):
             try:
-                out["roofline"] = kernel_roofline(S, dtype, args.batch, args.size, launch_mix=not args.no_launch_mix)
-                out["roofline"]["traffic"] = pmc_traffic(out["roofline"]["kernel"])
+                # the dominant kernels of THIS round's committed profile, timed live over one real step's launch mix
+                out["roofline"] = census_roofline(S, eager_step, dtype, args)
+                # round 1-4's headline kernel stays on the line as a fourth entry (one geometry + its 58-launch mix)
+                dd = kernel_roofline(S, dtype, args.batch, args.size, launch_mix=not args.no_launch_mix)
+                dd["traffic"] = pmc_traffic(dd["kernel"])
+                out["roofline"]["dense_dgrad_probe"] = dd
                 out["roofline"]["step"] = step_roofline(args, ms)     # per-GPU step: weak scaling, every rank does this work
                 if rank == 0:
                     out["roofline"]["weakest_large_family"] = weakest_family_roofline(S, dtype, args.batch, args.size)
             except Exception as e:
-                out["roofline"] = {"error": str(e)[:200]}
+                import traceback
+                out["roofline"] = {"error": str(e)[:200], "where": traceback.format_exc()[-400:]}
         if world == 1 and not args.no_extras:
             # release the headline configuration first: the extras build their own nets / graphs
             del graph, net, sm, opt, feed, img, seg, edge

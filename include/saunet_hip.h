@@ -56,6 +56,10 @@ typedef struct saunet_conv_desc {
 
 const char* saunet_last_error(void);
 int saunet_version(void);
+/* names of the kernels the calling thread's API calls have launched since the previous call of this function, joined by '+' (a name is the
+ * kernel's symbol without "_kernel", e.g. "conv_igemm_fwd", "bn_bwd_correct_ab+dense_dgrad3"); thread-local, valid until the next call.
+ * Measurement aid (bench.py attributes HIP-event times to kernel families with it); no effect on any launch. */
+const char* saunet_launch_log(void);
 /* number of compute units seen on `device` (sanity / grid sizing); <0 on error */
 int saunet_init(int device);
 

@@ -34,8 +34,9 @@ rec = {"kernel": line["kernel"],
        "SQ": {k: round(v[0]) for k, v in sq.items()}}
 json.dump(rec, open(os.path.join(ROOT, "profiles", "roofline_pmc.json"), "w"), indent=1)
 
-def summary(db, steps):
-    return subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "prof_summary.py"), db, str(steps)], capture_output=True, text=True).stdout
+def summary(db, steps, families=False):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "prof_summary.py"), db, str(steps)] + (["--families"] if families else []),
+                          capture_output=True, text=True).stdout
 
 rf = summary(O + "/rf_stats/p_results.db", 1).split("\n")
 rf = "\n".join(l[:230] for l in rf[1:10])
@@ -45,5 +46,5 @@ open(os.path.join(ROOT, "profiles", "%s_roofline_kernel_rocprof.txt" % tag), "w"
     "\n# bench.py line of the same run:\n" + json.dumps({"roofline": line}) + "\n")
 open(os.path.join(ROOT, "profiles", "%s_f_step_kernel_stats.txt" % tag), "w").write(
     "# rocprofv3 --kernel-trace --stats -- python bench.py --no-graph --steps 10 --warmup 3 --no-cpu-baseline --no-roofline\n"
-    "# (eager mode so that every launch is attributed; 15 steps incl. warm-up; per-step = total / 15)\n" + summary(O + "/step/p_results.db", 15))
+    "# (eager mode so that every launch is attributed; 15 steps incl. warm-up; per-step = total / 15)\n" + summary(O + "/step/p_results.db", 15, families=True))
 print(json.dumps(rec)[:600])

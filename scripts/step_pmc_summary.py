@@ -37,7 +37,10 @@ for d, k, n, fb, wb, util, valu in rows[:40]:
 print("# all kernels: %.2f ms/step, %.1f GB/step HBM traffic, average %.0f GB/s" % (tot / steps / 1e6, sum(r[3] + r[4] for r in rows) / steps / 1e9, sum(r[3] + r[4] for r in rows) / tot))
 if len(sys.argv) > 3:      # machine-readable record for bench.py's roofline.step (profiles/step_pmc.json)
     import json
-    json.dump({"config": [256, 32, "bf16"], "traffic_bytes_per_step": sum(r[3] + r[4] for r in rows) / steps,
+    per_kernel = {k.replace("void saunet::", "").replace("saunet::", ""): {"launches_per_step": round(n / steps, 2), "traffic_bytes_per_step": (fb + wb) / steps,
+                                                                              "fetch_bytes_per_step": fb / steps, "write_bytes_per_step": wb / steps, "ms_per_step": d / steps / 1e6}
+                  for d, k, n, fb, wb, util, valu in rows}
+    json.dump({"config": [256, 32, "bf16"], "traffic_bytes_per_step": sum(r[3] + r[4] for r in rows) / steps, "per_kernel": per_kernel,
                "kernel_ms_per_step": tot / steps / 1e6, "steps": steps,
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --no-graph` (scripts/collect_step_pmc.sh); bytes = FETCH_SIZE*2 + WRITE_SIZE"},
               open(sys.argv[3], "w"), indent=1)

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <string.h>
 #include "../../include/saunet_hip.h"
 
 namespace saunet {
@@ -18,9 +19,13 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 int set_error(int code, const char* fmt, ...);
+// thread-local log of the kernels the current thread's API calls launched (name = kernel symbol without "_kernel"); saunet_launch_log()
+// returns and clears it -- how bench.py attributes the HIP-event time of a call to a kernel family without guessing the dispatch
+void note_launch(const char* name);
 
 #define SAUNET_CHECK_LAUNCH(name)                                                     \
     do {                                                                              \
+        saunet::note_launch(name);                                                    \
         hipError_t e__ = hipGetLastError();                                           \
         if (e__ != hipSuccess)                                                        \
             return saunet::set_error(SAUNET_LAUNCH_FAILED, "%s: %s", name, hipGetErrorString(e__)); \
@@ -191,6 +196,26 @@ struct FastDiv {
 };
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// kernel symbol the way rocprofv3 prints it -- "name_kernel<unsigned short, 64, 64, 32, 32, 8, false>" -- for the launch log
+// (saunet_launch_log): built once per templated launch site (function-local static)
+template <typename T> inline const char* type_name();
+template <> inline const char* type_name<float>() { return "float"; }
+template <> inline const char* type_name<u16>() { return "unsigned short"; }
+template <> inline const char* type_name<f32s>() { return "saunet::f32s"; }
+inline void kn_put(char* o, size_t cap, int v) { snprintf(o + strlen(o), cap - strlen(o), "%d", v); }
+inline void kn_put(char* o, size_t cap, bool v) { snprintf(o + strlen(o), cap - strlen(o), "%s", v ? "true" : "false"); }
+inline void kn_put(char* o, size_t cap, const char* v) { snprintf(o + strlen(o), cap - strlen(o), "%s", v); }
+struct KName {
+    char s[192];
+    template <typename... A> KName(const char* base, A... a)
+    {
+        snprintf(s, sizeof(s), "%s<", base);
+        int i = 0;
+        ((i++ ? (void)kn_put(s, sizeof(s), ", ") : (void)0, kn_put(s, sizeof(s), a)), ...);
+        kn_put(s, sizeof(s), ">");
+    }
+};
 
 // ---- A/B switches.  The PRODUCT build has none: the library's behaviour is a function of its arguments only (include/saunet_hip.h:
 // "no global mutable state").  A variant build (scripts/build_variant.sh ... -DSAUNET_AB_SWITCHES) reads the named environment variables

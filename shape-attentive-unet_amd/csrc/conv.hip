@@ -1,11 +1,20 @@
 // C-ABI front for the convolution family: weight packing, dispatch between the MFMA implicit-GEMM
 // kernels (conv_igemm.hip) and the small-channel pointwise kernels below, bias gradient.
 #include "common.h"
+#include <string.h>
 #include "mma_tiles.h"
 
 namespace saunet {
 
 static thread_local char g_err[512] = "";
+static thread_local char g_launches[2][256] = {"", ""};
+static thread_local int g_launch_cur = 0;
+void note_launch(const char* name)
+{
+    char* b = g_launches[g_launch_cur];
+    const size_t used = strlen(b), n = strlen(name);
+    if (used + n + 2 < sizeof(g_launches[0])) { if (used) b[used] = '+'; memcpy(b + used + (used ? 1 : 0), name, n + 1); }
+}
 int set_error(int code, const char* fmt, ...)
 {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
@@ -544,6 +553,13 @@ using namespace saunet;
 extern "C" {
 
 const char* saunet_last_error(void) { return g_err; }
+const char* saunet_launch_log(void)
+{
+    const char* r = g_launches[g_launch_cur];
+    g_launch_cur ^= 1;
+    g_launches[g_launch_cur][0] = 0;
+    return r;
+}
 int saunet_version(void) { return 1; }
 
 int saunet_init(int device)

@@ -369,7 +369,8 @@ static int launch_fwd_i(const IgemmArgs& a, int phases, hipStream_t st)
     if (attr.raise(LDS)) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     dim3 grid(cdiv(a.M, BM), cdiv(a.Cout, BN), phases);
     hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, st, a);
-    SAUNET_CHECK_LAUNCH("conv_igemm_fwd");
+    static const KName kn("conv_igemm_fwd_kernel", type_name<T>(), BM, BN, WM, WN, CPR, BNEPI);
+    SAUNET_CHECK_LAUNCH(kn.s);
     return SAUNET_OK;
 }
 

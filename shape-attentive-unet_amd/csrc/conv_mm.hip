@@ -331,7 +331,8 @@ template <int BN, bool CELL = false> static int launch_mm(const MmArgs& a, hipSt
     static DeviceOnce attr;
     if (attr.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     hipLaunchKernelGGL(kern, dim3(a.ntiles * a.nnt * (CELL ? a.splits : 1)), dim3(512), LDS, st, a);
-    SAUNET_CHECK_LAUNCH("conv3x3_mm");
+    static const KName kn("conv3x3_mm_kernel", BN, CELL);
+    SAUNET_CHECK_LAUNCH(kn.s);
     return SAUNET_OK;
 }
 

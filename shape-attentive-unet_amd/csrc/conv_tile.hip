@@ -331,7 +331,8 @@ template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI> static int la
     if (attr.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     dim3 grid(a.tiles_x * a.tiles_y * a.N, cdiv(a.Cout, BN));
     hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, st, a);
-    SAUNET_CHECK_LAUNCH("conv3x3_tile_fwd");
+    static const KName kn("conv3x3_tile_fwd_kernel", type_name<T>(), BN, WM, WN, CPR, BNEPI);
+    SAUNET_CHECK_LAUNCH(kn.s);
     return SAUNET_OK;
 }
 
@@ -767,7 +768,8 @@ template <typename T, int BN, int WM, int WN, int CPR, bool BNEPI> static int la
     const int per_cu = (160 * 1024) / lds > 0 ? (160 * 1024) / lds : 1;
     int blocks = 256 * per_cu; if (blocks > items) blocks = items;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, st, a);
-    SAUNET_CHECK_LAUNCH("conv3x3_res_fwd");
+    static const KName kn("conv3x3_res_fwd_kernel", type_name<T>(), BN, WM, WN, CPR, BNEPI);
+    SAUNET_CHECK_LAUNCH(kn.s);
     return SAUNET_OK;
 }
 
@@ -1324,9 +1326,10 @@ template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KS
     if (a.ws == nullptr || ws_bytes < bytes) return set_error(SAUNET_BAD_SHAPE, "wgrad: workspace %zu < %zu bytes", ws_bytes, bytes);
     dim3 grid(groups, ncot * a.ncit * PARS);
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, a);
+    static const KName kn("conv_tile_wgrad_kernel", type_name<T>(), KS, TR, CO_T, CI_T, WM, WN, KSPLIT, ALIGNED);
+    SAUNET_CHECK_LAUNCH(kn.s);
     if (a.pend) {
         a.pend->ws = a.ws; a.pend->dw = a.dw; a.pend->wsize = a.wsize; a.pend->groups = groups; a.pend->reserved = 0;
-        SAUNET_CHECK_LAUNCH("conv_tile_wgrad");
         return SAUNET_OK;
     }
     long rb = (a.wsize + 255) / 256; if (rb > 2048) rb = 2048;
@@ -1334,7 +1337,7 @@ template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KS
     while (rb * gsl < 512 && gsl * 8 < groups) gsl *= 2;
     const int gper = (groups + gsl - 1) / gsl; gsl = (groups + gper - 1) / gper;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rb, gsl), dim3(256), 0, st, a.ws, a.wsize, groups, gper, a.dw);
-    SAUNET_CHECK_LAUNCH("conv_tile_wgrad");
+    SAUNET_CHECK_LAUNCH("wgrad_reduce");
     return SAUNET_OK;
 }
 
@@ -1853,7 +1856,8 @@ static int launch_tile_wgrad_grouped(GroupedWgradArgs& g, const saunet_wgrad_gro
         else g.item[i].ws = g.item[i].dw;            // one group: the block owns the whole problem and stores the gradient itself
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blk), dim3(256), LDS, st, g);
-    SAUNET_CHECK_LAUNCH("conv_tile_wgrad_grouped");
+    static const KName kn("conv_tile_wgrad_grouped_kernel", type_name<T>(), KS, TR, CO_T, CI_T, WM, WN, KSPLIT);
+    SAUNET_CHECK_LAUNCH(kn.s);
     if (groups > 1) {
         for (int i0 = 0; i0 < g.count; i0 += SAUNET_WGRAD_REDUCE_MAX) {
             saunet_wgrad_reduce_list l; l.reserved = 0;

@@ -631,7 +631,7 @@ static int launch_dense_dgrad3(DenseDgrad3Args& a, bool corr, hipStream_t st)
         if (corr) hipLaunchKernelGGL((dense_dgrad3_kernel<false, true>), dim3((unsigned)bx), dim3(DG_WAVES * 64), lds, st, a);
         else hipLaunchKernelGGL(dense_dgrad3_kernel<false>, dim3((unsigned)bx), dim3(DG_WAVES * 64), lds, st, a);
     }
-    SAUNET_CHECK_LAUNCH("dense_dgrad3");
+    SAUNET_CHECK_LAUNCH(corr ? "dense_dgrad3_kernel<false, true>" : (dense_dgrad3_halo(a.N, a.H, a.W) ? "dense_dgrad3_kernel<true, false>" : "dense_dgrad3_kernel<false, false>"));
     return SAUNET_OK;
 }
 
@@ -705,7 +705,8 @@ static int launch_dense_dgrad(DenseDgradArgs& a, bool apply, hipStream_t st)
         else if (ns == 3) hipLaunchKernelGGL(dense_dgrad_kernel<3>, grid, block, lds, st, a);
         else hipLaunchKernelGGL(dense_dgrad_kernel<4>, grid, block, lds, st, a);
     }
-    SAUNET_CHECK_LAUNCH("dense_dgrad");
+    const KName kn("dense_dgrad_kernel", ns > 4 ? 4 : ns, apply);
+    SAUNET_CHECK_LAUNCH(kn.s);
     return SAUNET_OK;
 }
 

@@ -520,6 +520,12 @@ using namespace saunet;
         else if ((dtype) == SAUNET_BF16) { if (vec) { CALL(u16, 8); } else { CALL(u16, 1); } } \
         else return set_error(SAUNET_BAD_DTYPE, "dtype %d", (dtype));                     \
     } while (0)
+// launch-log name of a <T, V> kernel: "base_kernel<unsigned short, 8>"
+#define CHECK_LAUNCH_TV(base, dtype, vec)                                                 \
+    do {                                                                                  \
+        const KName kn__(base "_kernel", (dtype) == SAUNET_BF16 ? "unsigned short" : "float", (vec) ? ((dtype) == SAUNET_BF16 ? 8 : 4) : 1); \
+        SAUNET_CHECK_LAUNCH(kn__.s);                                                      \
+    } while (0)
 
 namespace saunet {
 int bn_backward_correct_ab(int dtype, const void* d, int ldd, const void* x, int ldx, void* y, int ldy, const double* ab, int ab_replicas,
@@ -534,7 +540,7 @@ int bn_backward_correct_ab(int dtype, const void* d, int ldd, const void* x, int
 #define CALL(TT, VV) hipLaunchKernelGGL((bn_bwd_correct_ab_kernel<TT, VV>), dim3(blocks), dim3(256), 0, st, a)
     DISPATCH_TV(dtype, vec, CALL);
 #undef CALL
-    SAUNET_CHECK_LAUNCH("bn_backward_correct_ab");
+    CHECK_LAUNCH_TV("bn_bwd_correct_ab", dtype, vec);
     return SAUNET_OK;
 }
 
@@ -567,7 +573,7 @@ int saunet_bn_stats(int dtype, const void* x, int64_t pixels, int C, int ld, dou
 #define CALL(TT, VV) hipLaunchKernelGGL((bn_stats_kernel<TT, VV>), dim3(blocks), dim3(256), 2 * C * sizeof(double), st, (const TT*)x, (long)pixels, C, ld, rpb, sum, sumsq, replicas, rstride)
     DISPATCH_TV(dtype, vec, CALL);
 #undef CALL
-    SAUNET_CHECK_LAUNCH("bn_stats");
+    CHECK_LAUNCH_TV("bn_stats", dtype, vec);
     return SAUNET_OK;
 }
 
@@ -617,7 +623,7 @@ int saunet_affine_act(int dtype, const void* x, int ldx, const float* scale, con
 #define CALL(TT, VV) hipLaunchKernelGGL((affine_act_kernel<TT, VV>), dim3(blocks), dim3(256), 0, st, (const TT*)x, ldx, scale, shift, (const TT*)residual, ldr, relu, (TT*)y, ldy, (long)pixels, C, rpb)
     DISPATCH_TV(dtype, vec, CALL);
 #undef CALL
-    SAUNET_CHECK_LAUNCH("affine_act");
+    CHECK_LAUNCH_TV("affine_act", dtype, vec);
     return SAUNET_OK;
 }
 
@@ -654,7 +660,7 @@ int saunet_bn_backward_reduce(int dtype, const void* dy, int lddy, const void* x
 #define CALL(TT, VV) hipLaunchKernelGGL((bn_bwd_reduce_kernel<TT, VV>), dim3(blocks), dim3(256), 2 * C * sizeof(double), st, a)
     DISPATCH_TV(dtype, vec, CALL);
 #undef CALL
-    SAUNET_CHECK_LAUNCH("bn_backward_reduce");
+    CHECK_LAUNCH_TV("bn_bwd_reduce", dtype, vec);
     return SAUNET_OK;
 }
 
@@ -663,7 +669,7 @@ int saunet_bn_backward_coeff(int C, const double* sums, int sums_replicas, int s
 {
     hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, sums, sums_replicas < 1 ? 1 : sums_replicas, sums_rstride,
                        count, scale, A, B, dgamma, dbeta, training);
-    SAUNET_CHECK_LAUNCH("bn_backward_coeff");
+    SAUNET_CHECK_LAUNCH("bn_bwd_coeff");
     return SAUNET_OK;
 }
 
@@ -686,7 +692,7 @@ int saunet_bn_backward_coeff_correct(int dtype, int C, const double* sums, int s
 #define CALL(TT, VV) hipLaunchKernelGGL((bn_bwd_coeff_correct_kernel<TT, VV>), dim3(total), dim3(256), 0, st, a)
     DISPATCH_TV(dtype, vec, CALL);
 #undef CALL
-    SAUNET_CHECK_LAUNCH("bn_backward_coeff_correct");
+    CHECK_LAUNCH_TV("bn_bwd_coeff_correct", dtype, vec);
     return SAUNET_OK;
 }
 
@@ -719,7 +725,7 @@ int saunet_bn_backward_correct(int dtype, void* dx, int lddx, const void* x, int
 #define CALL(TT, VV) hipLaunchKernelGGL((bn_bwd_correct_kernel<TT, VV>), dim3(blocks), dim3(256), 0, st, (TT*)dx, lddx, (const TT*)x, ldx, A, B, xhat_scale, xhat_shift, (long)pixels, C, rpb)
     DISPATCH_TV(dtype, vec, CALL);
 #undef CALL
-    SAUNET_CHECK_LAUNCH("bn_backward_correct");
+    CHECK_LAUNCH_TV("bn_bwd_correct", dtype, vec);
     return SAUNET_OK;
 }
 
@@ -743,7 +749,7 @@ int saunet_bn_backward_apply(int dtype, const void* dy, int lddy, const void* x,
 #define CALL(TT, VV) hipLaunchKernelGGL((bn_bwd_apply_kernel<TT, VV>), dim3(blocks), dim3(256), sizeof(float) * 2 * C, st, a)
     DISPATCH_TV(dtype, vec, CALL);
 #undef CALL
-    SAUNET_CHECK_LAUNCH("bn_backward_apply");
+    CHECK_LAUNCH_TV("bn_bwd_apply", dtype, vec);
     return SAUNET_OK;
 }
 

@@ -104,7 +104,7 @@ int saunet_sgd_step(const saunet_tensor_list* tl, const float* hyper, void* stre
     for (int t = 0; t < tl->count; ++t) if (tl->numel[t] > biggest) biggest = tl->numel[t];
     long bx = (biggest / 4 + 511) / 512; if (bx > 2048) bx = 2048; if (bx < 1) bx = 1;      // ~2 vectors per thread for the largest tensor
     hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)bx, tl->count), dim3(256), 0, (hipStream_t)stream, *tl, hyper);
-    SAUNET_CHECK_LAUNCH("sgd_step");
+    SAUNET_CHECK_LAUNCH("sgd");
     return SAUNET_OK;
 }
 
@@ -112,7 +112,7 @@ int saunet_radam_step(const saunet_tensor_list* tl, const float* hyper, void* st
 {
     if (tl->count <= 0 || tl->count > 96) return set_error(SAUNET_BAD_SHAPE, "radam: %d tensors", tl->count);
     hipLaunchKernelGGL(radam_kernel, dim3(128, tl->count), dim3(256), 0, (hipStream_t)stream, *tl, hyper);
-    SAUNET_CHECK_LAUNCH("radam_step");
+    SAUNET_CHECK_LAUNCH("radam");
     return SAUNET_OK;
 }
 
@@ -120,7 +120,7 @@ int saunet_adam_step(const saunet_tensor_list* tl, const float* hyper, void* str
 {
     if (tl->count <= 0 || tl->count > 96) return set_error(SAUNET_BAD_SHAPE, "adam: %d tensors", tl->count);
     hipLaunchKernelGGL(adam_kernel, dim3(128, tl->count), dim3(256), 0, (hipStream_t)stream, *tl, hyper);
-    SAUNET_CHECK_LAUNCH("adam_step");
+    SAUNET_CHECK_LAUNCH("adam");
     return SAUNET_OK;
 }
 

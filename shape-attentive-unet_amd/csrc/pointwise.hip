@@ -643,7 +643,7 @@ int saunet_bilinear_forward(int dtype, const void* x, int N, int H, int W, int C
     if (dtype == SAUNET_F32) { if (vec) hipLaunchKernelGGL((bilinear_fwd_kernel<float, 4>), g, dim3(256), 0, st, a); else hipLaunchKernelGGL((bilinear_fwd_kernel<float, 1>), g, dim3(256), 0, st, a); }
     else if (dtype == SAUNET_BF16) { if (vec) hipLaunchKernelGGL((bilinear_fwd_kernel<u16, 8>), g, dim3(256), 0, st, a); else hipLaunchKernelGGL((bilinear_fwd_kernel<u16, 1>), g, dim3(256), 0, st, a); }
     else return set_error(SAUNET_BAD_DTYPE, "dtype %d", dtype);
-    SAUNET_CHECK_LAUNCH("bilinear_forward");
+    SAUNET_CHECK_LAUNCH("bilinear_fwd");
     return SAUNET_OK;
 }
 
@@ -667,7 +667,7 @@ int saunet_bilinear_backward(int dtype, const void* dy, int N, int Ho, int Wo, i
     else if (dtype == SAUNET_F32) { if (vec) hipLaunchKernelGGL((bilinear_bwd_kernel<float, 4>), dim3(grid_for(total)), dim3(256), 0, st, a); else hipLaunchKernelGGL((bilinear_bwd_kernel<float, 1>), dim3(grid_for(total)), dim3(256), 0, st, a); }
     else if (dtype == SAUNET_BF16) { if (vec) hipLaunchKernelGGL((bilinear_bwd_kernel<u16, 8>), dim3(grid_for(total)), dim3(256), 0, st, a); else hipLaunchKernelGGL((bilinear_bwd_kernel<u16, 1>), dim3(grid_for(total)), dim3(256), 0, st, a); }
     else return set_error(SAUNET_BAD_DTYPE, "dtype %d", dtype);
-    SAUNET_CHECK_LAUNCH("bilinear_backward");
+    SAUNET_CHECK_LAUNCH("bilinear_bwd");
     return SAUNET_OK;
 }
 

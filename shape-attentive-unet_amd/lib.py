@@ -165,7 +165,7 @@ _SIGS = {
     "saunet_adam_step": [C.POINTER(TensorList), vp, vp],
     "saunet_bucket_copy": [C.POINTER(TensorList), i32, f32, vp],
 }
-EXPORTS = sorted(list(_SIGS) + ["saunet_last_error", "saunet_version"])
+EXPORTS = sorted(list(_SIGS) + ["saunet_last_error", "saunet_version", "saunet_launch_log"])
 
 _lib = None
 
@@ -181,6 +181,7 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.saunet_last_error.restype = C.c_char_p
     lib.saunet_version.restype = C.c_int
+    lib.saunet_launch_log.restype = C.c_char_p
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = sig
