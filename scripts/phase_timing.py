@@ -46,6 +46,17 @@ elif case in ("conv1fwd", "conv1fwd3", "conv1fwd4"):
     sc = torch.rand(ci_, device="cuda") + 0.5; sh = torch.randn(ci_, device="cuda") * 0.1
     out = HF.new_act(n, 128, h_, h_, dt, "cuda"); st = torch.zeros(HF.STAT_R, 2, 128, dtype=torch.float64, device="cuda")
     run = lambda: HF.conv_forward_raw(x, w, None, 1, 0, pro=(sc, sh, True), out=out, stats=st)
+elif case in ("conv1small3", "conv1small4"):
+    unit = "dense_fwd"
+    ci_, h_ = {"conv1small3": (640, 32), "conv1small4": (768, 16)}[case]
+    buf = act(1024, h_); x = buf[:, :ci_]; w = torch.nn.Parameter(torch.randn(128, ci_, 1, 1, device="cuda") * 0.03)
+    gam = torch.rand(ci_, device="cuda") + 0.5; bet = torch.randn(ci_, device="cuda") * 0.1
+    HF.STATS.reset()
+    stats = HF.bn_stats(x); xh = torch.zeros(5, 1024, device="cuda")
+    HF.L.call("saunet_bn_xhat", ci_ - 32, stats[0, 0].data_ptr(), stats[0, 1].data_ptr(), stats.shape[0], stats.stride(0), float(n * h_ * h_), 1e-5, xh.data_ptr(), xh.stride(0), HF.L.stream())
+    prm = HF.BNParams(ci_, "cuda"); rm = torch.zeros(ci_, device="cuda"); rv = torch.ones(ci_, device="cuda")
+    out = HF.new_act(n, 128, h_, h_, dt, "cuda"); st = torch.zeros(HF.STAT_R, 2, 128, dtype=torch.float64, device="cuda")
+    run = lambda: HF.conv_forward_bnpro(x, w, 1, 0, stats, n * h_ * h_, ci_ - 32, xh, gam, bet, rm, rv, 0.1, 1e-5, prm.buf, out=out, stats=st)
 elif case in ("conv1dgrad", "conv1dgrad3", "conv1dgrad4"):
     unit = "dense_dgrad"
     cin, ctot, h = {"conv1dgrad": (192, 256, 128), "conv1dgrad3": (640, 1024, 32), "conv1dgrad4": (768, 1024, 16)}[case]

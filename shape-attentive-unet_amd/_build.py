@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libsaunet_hip.so")
-SOURCES = ["conv.hip", "conv_igemm.hip", "conv_tile.hip", "conv_mm.hip", "dense_dgrad.hip", "norm.hip", "pointwise.hip", "pool.hip", "gate.hip", "expand.hip", "loss.hip", "canny.hip", "augment.hip", "optim.hip"]
+SOURCES = ["conv.hip", "conv_igemm.hip", "conv_tile.hip", "conv_mm.hip", "dense_dgrad.hip", "dense_fwd.hip", "norm.hip", "pointwise.hip", "pool.hip", "gate.hip", "expand.hip", "loss.hip", "canny.hip", "augment.hip", "optim.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mma_tiles.h"), os.path.join(ROOT, "include", "saunet_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 

@@ -234,3 +234,54 @@ def test_fused_layer_backward_matches_the_four_launch_backward(layers, cin, shap
         e_f, e_u, e_fu = rel_l2(grads[True][k], ref[k]), rel_l2(grads[False][k], ref[k]), rel_l2(grads[True][k], grads[False][k])
         assert e_fu < max(1e-2, 1.5 * e_u), (k, e_fu, e_u)
         assert e_f < max(1.5 * e_u, 2e-2), (k, e_f, e_u)
+
+
+@pytest.mark.parametrize("n,h,w,cin,c_lo", [(8, 16, 16, 512, 480),      # block-4 geometry in small: 64-pixel tiles
+                                            (2, 16, 16, 288, 256),      # Cin % 64 == 32: the last stage reads past Cin and must contribute exact zeros
+                                            (32, 32, 32, 352, 320),     # 32768 pixels: 128-pixel tiles
+                                            (3, 8, 8, 992, 0),          # 192 pixels: a partial last tile; every channel finalised in the kernel
+                                            (1, 8, 8, 128, 96)])        # one 64-pixel tile, two K stages
+def test_small_map_conv1_forward_with_bn_prologue_matches_float64(n, h, w, cin, c_lo):
+    """dense_conv1_fwd_kernel (csrc/dense_fwd.hip, round 5): y = conv1x1(relu(BN(x))) with the BatchNorm coefficients derived in the kernel from the
+    producer's raw sums (channels >= c_lo) or taken from the published xhat rows (channels < c_lo), LDS-DMA staged operands and the prologue
+    applied in place in the LDS -- against float64 on the bf16-rounded operands, together with the output statistics, the parameter block and
+    the xhat rows it publishes (torchvision _DenseLayer.norm1 -> relu1 -> conv1, /root/reference/models/models.py:306-313)."""
+    import saunet_amd as S
+    HF = S.functional
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(cin + h)
+    ctot = cin + 64
+    buf = torch.randn(n, ctot, h, w, generator=g).cuda().to(dt).contiguous(memory_format=torch.channels_last)
+    x = buf[:, :cin]
+    weight = torch.nn.Parameter((torch.randn(128, cin, 1, 1, generator=g) * 0.05).cuda())
+    gamma = torch.empty(cin).uniform_(0.5, 1.5, generator=g).cuda(); beta = torch.empty(cin).uniform_(-0.3, 0.3, generator=g).cuda()
+    count = n * h * w
+    HF.STATS.reset(); HF.GRADS.reset()
+    stats = HF.bn_stats(x)                                            # [R, 2, cin] raw sums of the input channels
+    xh = torch.zeros(5, ctot, dtype=torch.float32, device="cuda")
+    eps = 1e-5
+    if c_lo > 0:
+        HF.L.call("saunet_bn_xhat", c_lo, stats[0, 0].data_ptr(), stats[0, 1].data_ptr(), stats.shape[0], stats.stride(0), float(count), eps,
+                  xh.data_ptr(), xh.stride(0), HF.L.stream())
+    params = HF.BNParams(cin, "cuda")
+    rmean, rvar = torch.zeros(cin, device="cuda"), torch.ones(cin, device="cuda")
+    st_out = HF.new_stats(128, "cuda")
+    HF.L.load().saunet_launch_log()                                   # clear the launch log: the next call's kernels only
+    y = HF.conv_forward_bnpro(x, weight, 1, 0, stats, count, c_lo, xh, gamma, beta, rmean, rvar, 0.1, eps, params.buf, stats=st_out)
+    launched = HF.L.load().saunet_launch_log().decode()
+    assert "dense_conv1_fwd_kernel<" in launched, launched       # the kernel under test is the one the library picked (after the lazy weight packing)
+    sums = HF.collapse_stats(st_out).double().cpu()
+    torch.cuda.synchronize()
+    xd = x.double()
+    mean = xd.mean((0, 2, 3)); var = xd.var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + eps)
+    scale = gamma.double() * invstd; shift = beta.double() - mean * scale
+    # the kernel rounds the activated operand to bf16 before the matrix cores
+    a = torch.relu(xd * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).to(dt).double()
+    ref = F.conv2d(a, weight.detach().to(dt).double())
+    assert rel(y, ref) < 1e-2, rel(y, ref)                                                       # bf16 store of an fp32 accumulator
+    assert (sums[:128] - ref.sum((0, 2, 3)).cpu()).abs().max() <= 2e-3 * ref.abs().sum((0, 2, 3)).max().cpu()
+    assert (sums[128:] - (ref * ref).sum((0, 2, 3)).cpu()).abs().max() <= 2e-3 * (ref * ref).sum((0, 2, 3)).max().cpu()
+    assert rel(params.scale, scale) < 1e-5 and rel(params.shift, shift) < 1e-4 and rel(params.mean, mean) < 1e-5 and rel(params.invstd, invstd) < 1e-5
+    assert rel(xh[0, c_lo:cin], invstd[c_lo:]) < 1e-5 and rel(xh[2, c_lo:cin], mean[c_lo:]) < 1e-4
+    assert rel(rmean, 0.1 * mean) < 1e-4
