@@ -87,7 +87,8 @@ int saunet_conv2d_forward(const saunet_conv_desc* d, const void* x, const void* 
  * while the tile is still on chip.  bn_x is the tensor that BN normalised, same pixels/channels as y. */
 typedef struct saunet_bn_epilogue {
     const void* bn_x; int32_t ld_bn_x; int32_t relu;
-    int32_t accumulate;   /* 1: y += scale[c]*g instead of y = g ("linear" BN backward, see saunet_bn_backward_coeff); 1x1 path only */
+    int32_t accumulate;   /* 1: y += scale[c]*g instead of y = g ("linear" BN backward, see saunet_bn_backward_coeff); 2: y = scale[c]*g (the same
+                           * term written by the FIRST consumer of a buffer, without reading y); 1x1 path only */
     int32_t reserved;
     const float* scale; const float* shift; const float* mean; const float* invstd;
     double* sums;
@@ -192,6 +193,11 @@ typedef struct saunet_dense_layer_bwd {
 } saunet_dense_layer_bwd;
 int saunet_dense_layer_backward_conv2(const saunet_dense_layer_bwd* l, void* stream);
 int saunet_dense_layer_backward_conv1(const saunet_dense_layer_bwd* l, void* stream);
+/* ab[0][c] += scale[c] * S1[c],  ab[0][ab_half + c] += scale[c] * S2[c]  (S = the replicated BatchNorm-backward sums of a consumer that stored
+ * y = scale * g: the transition behind a dense block), dgamma = S2, dbeta = S1: the coefficient half of the linear BN backward in the running
+ * float64 form the fused dense-layer backward reads. */
+int saunet_bn_backward_coeff_ab(int C, const double* sums, int sums_replicas, int sums_rstride, const float* scale, double* ab, int ab_half,
+                                float* dgamma, float* dbeta, void* stream);
 /* y = d - (A + B * (x*xs + xt)) with A, B = ab / count (replicated float64 sums, rows ab and ab + ab_half): the deferred correction of the linear
  * BN1 backward for C channels (C <= 256); y may alias d. */
 int saunet_bn_backward_correct_ab(int dtype, const void* d, int ldd, const void* x, int ldx, void* y, int ldy, const double* ab, int ab_replicas,

@@ -1,5 +1,5 @@
 import os, sys, collections, traceback
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import saunet_amd as S
 from saunet_amd import optim, data, lib as L

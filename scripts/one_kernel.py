@@ -7,6 +7,24 @@ HF = S.functional
 which = sys.argv[1]; reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dt = torch.bfloat16
 n = 32
+if which in ("conv1dgrad3", "conv1dgrad4", "conv2dgrad3", "conv2dgrad4"):     # the same on the low-resolution blocks (32 x 32 / 16 x 16 maps)
+    h = 32 if which.endswith("3") else 16
+    cin, ctot = (640, 1024) if h == 32 else (768, 1024)
+    buf = torch.randn(n, ctot, h, h, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+    dbuf = torch.randn(n, ctot, h, h, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+    z1 = torch.randn(n, 128, h, h, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+    c = 128 if which.startswith("conv2") else cin
+    p = HF.BNParams(c, "cuda"); p.buf[0].uniform_(0.5, 1.5); p.buf[1].normal_(0, 0.3); p.buf[2].normal_(0, 0.3); p.buf[3].uniform_(0.5, 1.5)
+    if which.startswith("conv2"):
+        w = torch.nn.Parameter(torch.randn(32, 128, 3, 3, device="cuda") * 0.05)
+        for _ in range(reps):
+            HF.conv_dgrad_raw(dbuf[:, cin:cin + 32], w, z1.shape, 1, 1, bn_epi=(z1, p, True, HF.new_stats(128, "cuda")))
+    else:
+        w = torch.nn.Parameter(torch.randn(128, cin, 1, 1, device="cuda") * 0.05)
+        for _ in range(reps):
+            HF.conv_dgrad_raw(z1, w, (n, cin, h, h), 1, 0, out=dbuf[:, :cin], bn_epi=(buf[:, :cin], p, True, HF.new_stats(cin, "cuda"), True))
+    torch.cuda.synchronize()
+    sys.exit(0)
 if which in ("conv2dgrad", "conv1dgrad"):        # DenseNet data gradients with their BatchNorm-backward reduction epilogues, block-1 geometry
     dbuf = torch.randn(n, 256, 128, 128, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
     z1 = torch.randn(n, 128, 128, 128, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)

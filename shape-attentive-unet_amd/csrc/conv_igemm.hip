@@ -324,11 +324,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void conv_igemm_fwd_
                 e1[j] += g[j];
                 e2[j] = fmaf(g[j], (xv[j] - emu[j]) * eis[j], e2[j]);
             }
-            if (a.epi.accumulate) {   // y += scale[c] * g  (linear BN backward: corrections are applied per chunk later)
+            if (a.epi.accumulate == 1) {   // y += scale[c] * g  (linear BN backward: corrections are applied per chunk later)
                 float o[EPC];
                 Vec16<T>::unpack(*(const u32x4*)(yg + opixv[i] * a.ldy + colv), o);
 #pragma unroll
                 for (int j = 0; j < EPC; ++j) g[j] = fmaf(esc[j], g[j], o[j]);
+            } else if (a.epi.accumulate == 2) {   // y = scale[c] * g  (the first consumer's term of the linear form: nothing to read)
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) g[j] *= esc[j];
             }
             v = Vec16<T>::pack(g);
         }

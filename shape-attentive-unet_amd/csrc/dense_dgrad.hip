@@ -193,7 +193,7 @@ template <int NS, bool APPLY = false> __global__ __launch_bounds__(DG_WAVES * 64
             u32x4 yv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) yv[i] = u32x4{0u, 0u, 0u, 0u};
-            if (a.accumulate) {        // wave-uniform
+            if (a.accumulate == 1) {        // wave-uniform (2 = scaled store: y = scale * G, nothing to read)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) yv[i] = *(const u32x4*)(yrow0 + min(step * 64 + 16 * i + plane, GC - 8));
             }
@@ -240,7 +240,7 @@ template <int NS, bool APPLY = false> __global__ __launch_bounds__(DG_WAVES * 64
                             const bool keep = ok && (!a.relu || fmaf(xf[e], sc[q], sh[q]) > 0.f);
                             const float Gv = keep ? G[e] : 0.f;
                             e1[e] = Gv; e2[e] = Gv * fmaf(xf[e], a1[q], a0[q]);
-                            o[e] = a.accumulate ? fmaf(sc[q], Gv, yf[e]) : Gv;
+                            o[e] = a.accumulate ? fmaf(sc[q], Gv, yf[e]) : Gv;        // (scaled store: yf = 0)
                         }
                     }
                     red[step][2 * t + r] += row_transpose_sum(e1, e2, sd0, sd1, sd2, sd3);

@@ -478,6 +478,19 @@ template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_corre
     }
 }
 
+__global__ void bn_bwd_coeff_ab_kernel(int C, const double* __restrict__ sums, int reps, int rstride, const float* __restrict__ scale, double* __restrict__ ab,
+                                       int half, float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1, s2;
+    rep_sum2(sums, sums + C, reps, rstride, c, s1, s2);
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    const double sc = (double)scale[c];
+    ab[c] += sc * s1; ab[half + c] += sc * s2;
+}
+
 // dgamma / dbeta of all norm1 layers of a dense block: blockIdx.y = layer
 __global__ __launch_bounds__(256) void dense_bn1_grads_kernel(saunet_dense_bn1_list l)
 {
@@ -700,6 +713,16 @@ int saunet_bn_backward_correct_ab(int dtype, const void* d, int ldd, const void*
                                   int ab_rstride, int ab_half, double count, const float* xs, const float* xt, int64_t pixels, int C, void* stream)
 {
     return bn_backward_correct_ab(dtype, d, ldd, x, ldx, y, ldy, ab, ab_replicas, ab_rstride, ab_half, count, xs, xt, pixels, C, (hipStream_t)stream);
+}
+
+int saunet_bn_backward_coeff_ab(int C, const double* sums, int sums_replicas, int sums_rstride, const float* scale, double* ab, int ab_half,
+                                float* dgamma, float* dbeta, void* stream)
+{
+    if (C < 1 || !sums || !scale || !ab || sums_replicas < 1 || ab_half < C) return set_error(SAUNET_BAD_SHAPE, "bn_backward_coeff_ab: C=%d", C);
+    hipLaunchKernelGGL(bn_bwd_coeff_ab_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, sums, sums_replicas, sums_rstride, scale, ab, ab_half,
+                       dgamma, dbeta);
+    SAUNET_CHECK_LAUNCH("bn_bwd_coeff_ab");
+    return SAUNET_OK;
 }
 
 int saunet_dense_bn1_grads(const saunet_dense_bn1_list* l, void* stream)

@@ -114,6 +114,7 @@ SYNCBN_ALLREDUCES = {"count": 0, "last_step": 0}      # SyncBN statistic exchang
 def begin_step():
     """Called at the start of every SAUNet forward: new scratch arenas, all weight packings refreshed in bulk."""
     SYNCBN_ALLREDUCES["last_step"], SYNCBN_ALLREDUCES["count"] = SYNCBN_ALLREDUCES["count"], 0
+    _FUSED_BLOCK_BUFS.clear(); _PENDING_AB.clear()
     STATS.reset(); GRADS.reset()
     PACKS.prepack()
 
@@ -421,7 +422,7 @@ def conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed=False, out=None,
         bx, p, relu, sums = bn_epi[:4]
         e = L.BnEpilogue()
         e.bn_x, e.ld_bn_x, e.relu = bx.data_ptr(), ld_of(bx), 1 if relu else 0
-        e.accumulate = 1 if (len(bn_epi) > 4 and bn_epi[4]) else 0
+        e.accumulate = int(bn_epi[4]) if len(bn_epi) > 4 and bn_epi[4] else 0          # 1: y += scale * g; 2: y = scale * g
         e.scale, e.shift, e.mean, e.invstd = p.scale.data_ptr(), p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr()
         e.sums = sums.data_ptr()
         e.sums_replicas, e.sums_rstride = (sums.shape[0], sums.stride(0)) if sums.dim() == 3 else (1, 0)
@@ -1466,6 +1467,12 @@ def relu(x):
 # output, writes its channels into the first slice and registers the buffer here; _DenseBlock.forward then adopts it instead of allocating a
 # buffer and copying x0 into it (4 copy launches, ~0.1 ms per step).  Keyed by the slice's address; an entry lives from producer to consumer.
 _DENSE_BASES = {}
+# Hand-off of a transition's share of the linear BN backward to the dense block in front of it (round 5): the block's forward registers its
+# concat buffer here when its backward will run the fused two-launch layers; the transition's backward then stores  d(buf) = scale * g  from
+# its data-gradient epilogue (no apply pass over the C-channel tensor) and leaves the coefficient sums in _PENDING_AB[buf pointer]; the block's
+# backward starts its running sums `ab` from them.  Both are keyed by the FORWARD buffer's address and dropped at the next begin_step().
+_FUSED_BLOCK_BUFS = set()
+_PENDING_AB = {}
 
 
 def reserve_dense_input(n, c, h, w, ctot, dtype, device):
@@ -1476,6 +1483,12 @@ def reserve_dense_input(n, c, h, w, ctot, dtype, device):
         _DENSE_BASES.clear()
     _DENSE_BASES[view.data_ptr()] = base
     return view
+
+
+def _dense_bwd_fused_ok(buf, training, growth, bottleneck, c0, nl):
+    """the block's backward will run saunet_dense_layer_backward_conv2 / _conv1 (bf16 storage, training-mode statistics, DenseNet-121 widths)"""
+    return bool(DENSE_BWD_FUSED and training and buf.is_cuda and buf.dtype == torch.bfloat16 and growth == 32 and bottleneck == 128 and c0 % 8 == 0
+                and ld_of(buf) == buf.shape[1] and 0 < nl <= L.DENSE_LAYERS_MAX)
 
 
 class _DenseBlock(torch.autograd.Function):
@@ -1551,6 +1564,8 @@ class _DenseBlock(torch.autograd.Function):
                    float(cfgs[0][1]), 0.0, None, None, xh[0].data_ptr(), xh[1].data_ptr(), None, None, 1, L.stream())
         ctx.save_for_backward(buf, xh, *params, *saved)
         ctx.meta = (nl, c0, growth, count, training)
+        if _dense_bwd_fused_ok(buf, training, growth, params[2].shape[0] if nl else 0, c0, nl):
+            _FUSED_BLOCK_BUFS.add(buf.data_ptr())
         ctx.mark_non_differentiable(stats)
         ctx.set_materialize_grads(False)           # no zero-filled "gradient" of the statistics tensor in backward
         return buf, stats
@@ -1581,9 +1596,16 @@ class _DenseBlock(torch.autograd.Function):
                        AB[1, lo:hi].data_ptr(), xh[0, lo:hi].data_ptr(), xh[1, lo:hi].data_ptr(), P, hi - lo, L.stream())
 
         grads = [None] * (6 * nl)
-        if (DENSE_BWD_FUSED and training and buf.is_cuda and buf.dtype == torch.bfloat16 and growth == 32 and params[2].shape[0] == 128 and c0 % 8 == 0
-                and ld_of(buf) == ctot and ld_of(dbuf) == ctot and nl <= L.DENSE_LAYERS_MAX):
-            return _DenseBlock._backward_fused(ctx, buf, dbuf, xh, params, saved, grads)
+        pending_ab = _PENDING_AB.pop(buf.data_ptr(), None)          # a transition behind this block left its coefficient sums (see _Transition.backward)
+        if _dense_bwd_fused_ok(buf, training, growth, params[2].shape[0] if nl else 0, c0, nl) and ld_of(dbuf) == ctot:
+            return _DenseBlock._backward_fused(ctx, buf, dbuf, xh, params, saved, grads, pending_ab)
+        if pending_ab is not None:      # (the switch was flipped between forward and backward: settle the transition's correction at once)
+            for lo in range(0, ctot, 256):
+                hi = min(lo + 256, ctot)
+                dsl, xsl = dbuf[:, lo:hi], buf[:, lo:hi]
+                L.call("saunet_bn_backward_correct_ab", dt, dsl.data_ptr(), ld_of(dsl), xsl.data_ptr(), ld_of(xsl), dsl.data_ptr(), ld_of(dsl),
+                       pending_ab[0, 0, lo:hi].data_ptr(), pending_ab.shape[0], pending_ab.stride(0), ctot, float(count), xh[0, lo:hi].data_ptr(),
+                       xh[1, lo:hi].data_ptr(), P, hi - lo, L.stream())
         pend = [] if (buf.is_cuda and DENSE_WGRAD_BATCH_REDUCE) else None   # the 2 x L partial-gradient reductions: one launch
         # default: both weight gradients of every layer are deferred to the end of the block and issued as two GROUPED launches (every layer's
         # dz1 / corrected gradient chunk stays alive until then: 24 x 8 MB at block 3 -- nothing against 288 GB)
@@ -1642,7 +1664,7 @@ class _DenseBlock(torch.autograd.Function):
 
 
     @staticmethod
-    def _backward_fused(ctx, buf, dbuf, xh, params, saved, grads):
+    def _backward_fused(ctx, buf, dbuf, xh, params, saved, grads, pending_ab=None):
         """Round 5: two launches per layer (saunet_dense_layer_backward_conv2 / _conv1) instead of four.  The BatchNorm-backward apply of
         norm2 happens in the conv1 data gradient's operand load, the deferred chunk correction of the linear BN1 backward in the conv2
         data gradient's (a separate streaming pass only on the maps that run the LDS-DMA staged conv2 kernel), and the per-layer
@@ -1652,7 +1674,7 @@ class _DenseBlock(torch.autograd.Function):
         dev = buf.device
         P = n * h * w
         st = L.stream()
-        ab = new_stats(ctot, dev)
+        ab = pending_ab if pending_ab is not None else new_stats(ctot, dev)
         g = new_act(n, 128, h, w, buf.dtype, dev)                   # scratch between the two launches of a layer
         wg1, wg2 = [], []
         bl = L.DenseBn1List()
@@ -1668,7 +1690,8 @@ class _DenseBlock(torch.autograd.Function):
             z1, p1b, p2b = saved[3 * l:3 * l + 3]
             cin = c0 + growth * l
             dz1 = new_act(n, 128, h, w, buf.dtype, dev)
-            dz2 = new_act(n, growth, h, w, buf.dtype, dev) if l + 1 < nl else None      # the last chunk has no consumer inside the block: nothing to correct
+            # the last chunk has no consumer inside the block: nothing to correct unless a transition's sums are pending
+            dz2 = new_act(n, growth, h, w, buf.dtype, dev) if (l + 1 < nl or pending_ab is not None) else None
             s2, s1 = new_stats(128, dev), new_stats(cin, dev)
             dgb2 = torch.empty(2, 128, dtype=torch.float32, device=dev)
             dgb1 = torch.empty(2, cin, dtype=torch.float32, device=dev)
@@ -1762,13 +1785,13 @@ class _Transition(torch.autograd.Function):
             y = new_act(n, z.shape[1], h // 2, w // 2, z.dtype, z.device)
         L.call("saunet_pool2x2_forward", L.dtype_code(z), 0, z.data_ptr(), n, h, w, z.shape[1], ld_of(z), y.data_ptr(), ld_of(y), L.stream())
         ctx.save_for_backward(buf, weight, p.buf)
-        ctx.meta = (count, training)
+        ctx.meta = (count, training, buf.data_ptr() in _FUSED_BLOCK_BUFS)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         buf, weight, pbuf = ctx.saved_tensors
-        count, training = ctx.meta
+        count, training, fold = ctx.meta
         p = BNParams.__new__(BNParams); p.buf = pbuf
         dy = nhwc(dy)
         n, c, h, w = buf.shape
@@ -1777,6 +1800,16 @@ class _Transition(torch.autograd.Function):
         L.call("saunet_pool2x2_backward", L.dtype_code(dy), 0, None, dy.data_ptr(), n, h, w, co, 0, ld_of(dy), dz.data_ptr(), ld_of(dz), 0, L.stream())
         dw = conv_wgrad_raw(buf, dz, weight, 1, 0, pro=(p.scale, p.shift, True))
         sb = new_stats(c, buf.device)
+        if fold and training and DENSE_BWD_FUSED:
+            # linear form: d(buf) = scale * g  straight from the data gradient's epilogue; the -(A + B * xhat) half is applied by the dense block's
+            # backward with every other consumer's share (chunk by chunk, as the gradient is consumed) -- no apply pass over the C-channel tensor
+            da = conv_dgrad_raw(dz, weight, buf.shape, 1, 0, bn_epi=(buf, p, True, sb, 2))
+            ab = new_stats(c, buf.device)
+            dgb = torch.empty(2, c, dtype=torch.float32, device=buf.device)
+            L.call("saunet_bn_backward_coeff_ab", c, sb.data_ptr(), sb.shape[0], sb.stride(0), p.scale.data_ptr(), ab.data_ptr(), c,
+                   dgb[0].data_ptr(), dgb[1].data_ptr(), L.stream())
+            _PENDING_AB[buf.data_ptr()] = ab
+            return da, None, dgb[0], dgb[1], None, None, dw, None, None, None, None
         da = conv_dgrad_raw(dz, weight, buf.shape, 1, 0, bn_epi=(buf, p, True, sb))
         dbuf, _, dg, db = bn_backward(da, buf, p, True, count, training, dx=da, presums=sb)
         return dbuf, None, dg, db, None, None, dw, None, None, None, None

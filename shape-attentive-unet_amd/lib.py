@@ -120,6 +120,7 @@ _SIGS = {
     "saunet_dense_layer_backward_conv1": [C.POINTER(DenseLayerBwd), vp],
     "saunet_bn_backward_correct_ab": [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, f64, vp, vp, i64, i32, vp],
     "saunet_dense_bn1_grads": [C.POINTER(DenseBn1List), vp],
+    "saunet_bn_backward_coeff_ab": [i32, vp, i32, i32, vp, vp, i32, vp, vp, vp],
     "saunet_bilinear_forward": [i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp],
     "saunet_bilinear_backward": [i32, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp],
     "saunet_im2col": [i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp],

@@ -232,7 +232,9 @@ def test_fused_layer_backward_matches_the_four_launch_backward(layers, cin, shap
         # accumulation-order noise -- except where the gradient itself is rounding noise: with no unit masked, norm1's bias gradient is the pixel
         # sum of a BatchNorm-backward output, analytically ~0, and both paths sit 10-20 % (of that tiny norm) from float64
         e_f, e_u, e_fu = rel_l2(grads[True][k], ref[k]), rel_l2(grads[False][k], ref[k]), rel_l2(grads[True][k], grads[False][k])
-        assert e_fu < max(1e-2, 1.5 * e_u), (k, e_fu, e_u)
+        # the folded path rounds d(buf) to bf16 BEFORE the correction is applied, the unfolded one after: the two differ by bf16 rounding of
+        # the gradient buffer (measured 1.1e-2 on dx with both 6e-3 from float64), not by more
+        assert e_fu < max(2e-2, 2.0 * e_u), (k, e_fu, e_u)
         assert e_f < max(1.5 * e_u, 2e-2), (k, e_f, e_u)
 
 
@@ -285,3 +287,58 @@ def test_small_map_conv1_forward_with_bn_prologue_matches_float64(n, h, w, cin, 
     assert rel(params.scale, scale) < 1e-5 and rel(params.shift, shift) < 1e-4 and rel(params.mean, mean) < 1e-5 and rel(params.invstd, invstd) < 1e-5
     assert rel(xh[0, c_lo:cin], invstd[c_lo:]) < 1e-5 and rel(xh[2, c_lo:cin], mean[c_lo:]) < 1e-4
     assert rel(rmean, 0.1 * mean) < 1e-4
+
+
+@pytest.mark.parametrize("layers,cin,shape", [(3, 32, (4, 32, 32)),       # transition with 128 incoming channels: dense_dgrad_kernel, scaled store
+                                              (4, 128, (4, 16, 16)),      # 256 channels -> 128: the implicit-GEMM data gradient's scaled store
+                                              (2, 64, (2, 128, 128))])    # large map: LDS-DMA staged conv2 kernel + correction pass, last chunk included
+def test_transition_backward_folds_into_the_block_and_matches_float64(layers, cin, shape):
+    """dense block -> transition (BN-ReLU-conv1x1-AvgPool2): with the fused layer backward the transition stores d(buf) = scale * g from its data
+    gradient's epilogue and hands its coefficient sums to the block (saunet_bn_backward_coeff_ab), whose layers apply them chunk by chunk -- no
+    BatchNorm-backward apply pass over the block's full-width tensor.  Against the unfolded sequence and float64
+    (torchvision _Transition / _DenseBlock, /root/reference/models/models.py:306-313)."""
+    import saunet_amd as S
+    HF = S.functional
+    torch.manual_seed(31 + layers)
+    n, h, w = shape
+    dtype = torch.bfloat16
+    block = S.modules._DenseBlock(layers, cin).cuda().train()
+    ctot = cin + 32 * layers
+    trans = S.modules._Transition(ctot, ctot // 2).cuda().train()
+    with torch.no_grad():
+        for m in list(block.modules()) + list(trans.modules()):
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(4.0, 6.0)
+    x0 = torch.randn(n, cin, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    cot, grads = None, {}
+    names = [("block." + k, v) for k, v in block.named_parameters()] + [("trans." + k, v) for k, v in trans.named_parameters()]
+    try:
+        for fused in (True, False):
+            HF.DENSE_BWD_FUSED = fused
+            HF.begin_step()
+            for _, v in names:
+                v.grad = None
+            x = x0.clone().requires_grad_(True)
+            buf, st = block(x, with_stats=True)
+            y = trans(buf, st)
+            if cot is None:
+                cot = torch.randn(y.shape, device="cuda").to(dtype)
+            (y.float() * cot.float()).sum().backward()
+            assert not HF._PENDING_AB, "the block must have consumed the transition's coefficient sums"
+            grads[fused] = {"x": x.grad.float().clone(), **{k: v.grad.float().clone() for k, v in names}}
+    finally:
+        HF.DENSE_BWD_FUSED = True
+    # float64 reference
+    d = torch.float64
+    ry, xr, prm = ref_block(block, x0)
+    tp = {k: v.detach().to(d).requires_grad_(True) for k, v in trans.named_parameters()}
+    t = F.batch_norm(ry, None, None, tp["norm.weight"], tp["norm.bias"], True, 0.0, trans.norm.eps)
+    t = F.avg_pool2d(F.conv2d(F.relu(t), tp["conv.weight"]), 2)
+    (t * cot.double()).sum().backward()
+    ref = {"x": xr.grad, **{"block." + k: prm[k].grad for k in prm}, **{"trans." + k: tp[k].grad for k in tp}}
+    for k in grads[True]:
+        e_f, e_u, e_fu = rel_l2(grads[True][k], ref[k]), rel_l2(grads[False][k], ref[k]), rel_l2(grads[True][k], grads[False][k])
+        # the folded path rounds d(buf) to bf16 BEFORE the correction is applied, the unfolded one after: the two differ by bf16 rounding of
+        # the gradient buffer (measured 1.1e-2 on dx with both 6e-3 from float64), not by more
+        assert e_fu < max(2e-2, 2.0 * e_u), (k, e_fu, e_u)
+        assert e_f < max(1.5 * e_u, 2e-2), (k, e_f, e_u)
