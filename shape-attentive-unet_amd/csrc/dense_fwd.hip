@@ -154,13 +154,13 @@ __global__ __launch_bounds__(512) void dense_conv1_fwd_kernel(DenseFwdArgs a)
 
     // ---- epilogue: statistics, transpose through LDS, coalesced stores (the rings are idle now)
     u16* so = (u16*)smem;                                   // [BM][128]
-    float* s_sum = (float*)(smem + BM * DF_BN * 2);         // [2 row groups][2][128]
+    float* s_sum = (float*)(smem + BM * DF_BN * 2);         // [BM / 32 row tiles][2][128]
     const bool do_stats = a.stat_sum != nullptr;
     {
         const int col = wn * 32 + lr;
-        float sv = 0.f, ssv = 0.f;
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i) {
+            float sv = 0.f, ssv = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * (32 * TI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -168,18 +168,25 @@ __global__ __launch_bounds__(512) void dense_conv1_fwd_kernel(DenseFwdArgs a)
                 sv += v; ssv += v * v;
                 Elem<u16>::store(so + row * DF_BN + col, v);
             }
-        if (do_stats) {
-            sv += __shfl_xor(sv, 32, 64); ssv += __shfl_xor(ssv, 32, 64);
-            if (lh == 0) { float* slot = s_sum + wm * 2 * DF_BN; slot[col] = sv; slot[DF_BN + col] = ssv; }
+            if (do_stats) {
+                sv += __shfl_xor(sv, 32, 64); ssv += __shfl_xor(ssv, 32, 64);
+                if (lh == 0) { float* slot = s_sum + (wm * TI + i) * 2 * DF_BN; slot[col] = sv; slot[DF_BN + col] = ssv; }
+            }
         }
     }
     TSTAMP(88);
     __syncthreads();
     if (do_stats && tid < DF_BN) {
-        const float t1 = s_sum[tid] + s_sum[2 * DF_BN + tid], t2 = s_sum[DF_BN + tid] + s_sum[3 * DF_BN + tid];
+        // float partial sums cover 64 rows (two 32-row tiles) exactly like the generic kernel's 64 x 64 tiles; 64-row groups are combined in double
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int g = 0; g < BM / 64; ++g) {
+            t1 += (double)(s_sum[(2 * g) * 2 * DF_BN + tid] + s_sum[(2 * g + 1) * 2 * DF_BN + tid]);
+            t2 += (double)(s_sum[(2 * g) * 2 * DF_BN + DF_BN + tid] + s_sum[(2 * g + 1) * 2 * DF_BN + DF_BN + tid]);
+        }
         const size_t ro = (size_t)(blockIdx.x % a.stat_replicas) * a.stat_rstride;
-        atomicAdd(&a.stat_sum[ro + tid], (double)t1);
-        atomicAdd(&a.stat_sumsq[ro + tid], (double)t2);
+        atomicAdd(&a.stat_sum[ro + tid], t1);
+        atomicAdd(&a.stat_sumsq[ro + tid], t2);
     }
     constexpr int CH = DF_BN / 8;                           // 16 chunks per output row
 #pragma unroll

@@ -468,6 +468,7 @@ def flush_wgrad_reductions(pending):
 
 DENSE_WGRAD_GROUPED = True   # all weight gradients of a dense block as two grouped launches (False: per-layer launches)
 DENSE_COEFF_CORRECT = True   # coefficient + chunk correction of the linear BatchNorm backward in one launch (False: two)
+DENSE_TRANSITION_FOLD = os.environ.get("SAUNET_TRANSITION_FOLD", "1") != "0"  # the transition's BN-backward apply folded into the block's linear form
 DENSE_BWD_FUSED = os.environ.get("SAUNET_DENSE_BWD_FUSED", "1") != "0"       # bf16 training: two launches per dense layer in backward (saunet_dense_layer_backward_conv2 / _conv1; False: the round-4 four)
 
 
@@ -1562,10 +1563,16 @@ class _DenseBlock(torch.autograd.Function):
             L.call("saunet_bn_finalize", ctot, stats[0, 0].data_ptr(), stats[0, 1].data_ptr(), stats.shape[0], stats.stride(0), float(count),
                    None, one.data_ptr(), zero.data_ptr(),
                    float(cfgs[0][1]), 0.0, None, None, xh[0].data_ptr(), xh[1].data_ptr(), None, None, 1, L.stream())
-        ctx.save_for_backward(buf, xh, *params, *saved)
-        ctx.meta = (nl, c0, growth, count, training)
         if _dense_bwd_fused_ok(buf, training, growth, params[2].shape[0] if nl else 0, c0, nl):
             _FUSED_BLOCK_BUFS.add(buf.data_ptr())
+            if bnpro:
+                # the xhat rows of a concat channel are published by the first conv1 that normalises it -- nobody inside the block does that for
+                # the LAST layer's 32 channels, but a transition that folds its BatchNorm backward into this block needs them for its correction
+                lo = ctot - growth
+                L.call("saunet_bn_xhat", growth, stats[0, 0, lo:].data_ptr(), stats[0, 1, lo:].data_ptr(), stats.shape[0], stats.stride(0), float(count),
+                       float(cfgs[0][1]), xh[0, lo:].data_ptr(), xh.stride(0), L.stream())
+        ctx.save_for_backward(buf, xh, *params, *saved)
+        ctx.meta = (nl, c0, growth, count, training)
         ctx.mark_non_differentiable(stats)
         ctx.set_materialize_grads(False)           # no zero-filled "gradient" of the statistics tensor in backward
         return buf, stats
@@ -1800,7 +1807,7 @@ class _Transition(torch.autograd.Function):
         L.call("saunet_pool2x2_backward", L.dtype_code(dy), 0, None, dy.data_ptr(), n, h, w, co, 0, ld_of(dy), dz.data_ptr(), ld_of(dz), 0, L.stream())
         dw = conv_wgrad_raw(buf, dz, weight, 1, 0, pro=(p.scale, p.shift, True))
         sb = new_stats(c, buf.device)
-        if fold and training and DENSE_BWD_FUSED:
+        if fold and training and DENSE_BWD_FUSED and DENSE_TRANSITION_FOLD:
             # linear form: d(buf) = scale * g  straight from the data gradient's epilogue; the -(A + B * xhat) half is applied by the dense block's
             # backward with every other consumer's share (chunk by chunk, as the gradient is consumed) -- no apply pass over the C-channel tensor
             da = conv_dgrad_raw(dz, weight, buf.shape, 1, 0, bn_epi=(buf, p, True, sb, 2))
