@@ -55,20 +55,25 @@ _DP_SHARDS = 1
 # two-channel edge head and the loss stay float32 like in the HIP path.  It separates "error inherent to bf16 storage" from
 # "error of the implementation" in tests/test_hip_parity_bf16.py.
 _BF16_EMU = False
+# mixed-storage study: with _BF16_EMU_F32_MAXHW = m > 0 every tensor on a map of at most m x m pixels (and the weight
+# operand of every convolution whose INPUT map is that small) stays float32 -- "float32 storage on the low-resolution maps, bf16 elsewhere"
+_BF16_EMU_F32_MAXHW = 0
 
 
 class bf16_storage:
-    def __init__(self, on=True):
+    def __init__(self, on=True, f32_max_hw=0):
         self.on = bool(on)
+        self.f32_max_hw = int(f32_max_hw)
 
     def __enter__(self):
-        global _BF16_EMU
-        self.prev, _BF16_EMU = _BF16_EMU, self.on
+        global _BF16_EMU, _BF16_EMU_F32_MAXHW
+        self.prev, _BF16_EMU = (_BF16_EMU, _BF16_EMU_F32_MAXHW), self.on
+        _BF16_EMU_F32_MAXHW = self.f32_max_hw
         return self
 
     def __exit__(self, *exc):
-        global _BF16_EMU
-        _BF16_EMU = self.prev
+        global _BF16_EMU, _BF16_EMU_F32_MAXHW
+        _BF16_EMU, _BF16_EMU_F32_MAXHW = self.prev
 
 
 class _RoundBoth(torch.autograd.Function):
@@ -91,14 +96,18 @@ class _RoundFwd(torch.autograd.Function):
         return g
 
 
+def _small(x):
+    return _BF16_EMU_F32_MAXHW > 0 and x.dim() == 4 and max(x.shape[-2], x.shape[-1]) <= _BF16_EMU_F32_MAXHW
+
+
 def _q(x):
-    """stored activation: value and gradient live in bf16"""
-    return _RoundBoth.apply(x) if _BF16_EMU else x
+    """stored activation: value and gradient live in bf16 (float32 on the small maps of the mixed-storage study)"""
+    return _RoundBoth.apply(x) if (_BF16_EMU and not _small(x)) else x
 
 
-def _qw(w):
-    """weight operand: rounded for the multiply, gradient kept in float32 (master weights are float32)"""
-    return _RoundFwd.apply(w) if _BF16_EMU else w
+def _qw(w, x=None):
+    """weight operand: rounded for the multiply, gradient kept in float32 (master weights are float32); x = the convolution's input"""
+    return _RoundFwd.apply(w) if (_BF16_EMU and not (x is not None and _small(x))) else w
 
 
 class dp_shards:
@@ -153,11 +162,11 @@ def _bn(sd, pre, x, training, momentum=BN_MOM):
 
 
 def _conv(sd, pre, x, stride=1, padding=0):
-    return _q(F.conv2d(x, _qw(sd[pre + ".weight"]), sd.get(pre + ".bias"), stride, padding))
+    return _q(F.conv2d(x, _qw(sd[pre + ".weight"], x), sd.get(pre + ".bias"), stride, padding))
 
 
 def _convT(sd, pre, x):
-    return _q(F.conv_transpose2d(x, _qw(sd[pre + ".weight"]), sd.get(pre + ".bias"), stride=2, padding=1))
+    return _q(F.conv_transpose2d(x, _qw(sd[pre + ".weight"], x), sd.get(pre + ".bias"), stride=2, padding=1))
 
 
 def _up(x, size=None, scale=None):
