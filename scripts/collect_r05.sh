@@ -24,7 +24,7 @@ python scripts/gate_micro.py > $O/micro_gate.txt 2>&1
 ( export SAUNET_HIP_LIB=scripts/_ab/libsaunet_timing.so; for c in conv2fwd conv2wgrad conv1wgrad dec3wgrad conv1dgrad conv1dgrad3 conv2dgrad conv2dgrad3 dec3mm dec5mm conv1fwd conv1fwd3 conv1small3 conv1small4 conv1dgrad3 conv1dgrad4 conv2dgrad3 conv2dgrad4 conv2fwd3 conv2fwd4; do python scripts/phase_timing.py $c 2>&1 | grep -v amdgpu.ids; done ) > $O/phase_timing.txt
 for b in 1 2 3 4; do python scripts/dense_chain_micro.py $b 2>&1 | grep -v amdgpu.ids; SAUNET_DENSE_BWD_FUSED=0 python scripts/dense_chain_micro.py $b 2>&1 | grep -v amdgpu.ids; done > $O/dense_chain.txt
 python scripts/census_table.py 2>&1 | grep -v amdgpu.ids > $O/census_table.txt
-python bench.py --gpus 2 --share-gpu --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_rehearsal_2ranks.json 2>> $O/bench.err
+python bench.py --gpus 2 --share-gpu --steps 5 --warmup 2 --no-cpu-baseline 2>> $O/bench.err | grep "^{" > $O/bench_rehearsal_2ranks.json
 bash scripts/mfma_table.sh > $O/mfma_table.log 2>&1; cp gpurun_out/mfma_table.txt $O/mfma_table.txt
 cp gpurun_out/step_pmc_summary.txt $O/step_pmc_summary.txt; cp gpurun_out/step_pmc.json $O/step_pmc.json
 cp profiles/roofline_pmc.json $O/roofline_pmc.json; cp profiles/r05_roofline_kernel_rocprof.txt profiles/r05_f_step_kernel_stats.txt $O/ 2>/dev/null
