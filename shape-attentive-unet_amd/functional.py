@@ -115,6 +115,7 @@ def begin_step():
     """Called at the start of every SAUNet forward: new scratch arenas, all weight packings refreshed in bulk."""
     SYNCBN_ALLREDUCES["last_step"], SYNCBN_ALLREDUCES["count"] = SYNCBN_ALLREDUCES["count"], 0
     _FUSED_BLOCK_BUFS.clear(); _PENDING_AB.clear()
+    _DENSE_BASES.clear()          # a reserved concat buffer nobody adopted (exception, standalone stem / transition) must not outlive its step
     STATS.reset(); GRADS.reset()
     PACKS.prepack()
 
@@ -1535,25 +1536,25 @@ class _DenseBlock(torch.autograd.Function):
             for l in range(nl_loop):
                 n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
                 n1rm, n1rv, n2rm, n2rv = bufs[4 * l:4 * l + 4]
-                mom, eps = cfgs[l]
+                mom, eps, mom2, eps2 = cfgs[l]
                 cin = c0 + growth * l
                 p1, p2 = BNParams(cin, dev), BNParams(c1w.shape[0], dev)
                 st2 = new_stats(c1w.shape[0], dev)
                 z1 = conv_forward_bnpro(buf[:, :cin], c1w, 1, 0, stats, count, cin - growth if l > 0 else cin, xh, n1w, n1b, n1rm, n1rv, mom, eps,
                                         p1.buf, stats=st2)
-                conv_forward_bnpro(z1, c2w, 1, 1, st2, count, 0, None, n2w, n2b, n2rm, n2rv, mom, eps, p2.buf, out=buf[:, cin:cin + growth],
+                conv_forward_bnpro(z1, c2w, 1, 1, st2, count, 0, None, n2w, n2b, n2rm, n2rv, mom2, eps2, p2.buf, out=buf[:, cin:cin + growth],
                                    stats=stats[:, :, cin:cin + growth])
                 saved += [z1, p1.buf, p2.buf]
             nl_loop = 0
         for l in range(nl_loop):
             n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
             n1rm, n1rv, n2rm, n2rv = bufs[4 * l:4 * l + 4]
-            mom, eps = cfgs[l]
+            mom, eps, mom2, eps2 = cfgs[l]
             cin = c0 + growth * l
             p1 = bn_finalize(stats[:, :, :cin] if training else None, count, n1w, n1b, n1rm, n1rv, mom, eps, training)
             st2 = new_stats(c1w.shape[0], dev) if training else None
             z1 = conv_forward_raw(buf[:, :cin], c1w, None, 1, 0, pro=(p1.scale, p1.shift, True), stats=st2)
-            p2 = bn_finalize(st2, count, n2w, n2b, n2rm, n2rv, mom, eps, training)
+            p2 = bn_finalize(st2, count, n2w, n2b, n2rm, n2rv, mom2, eps2, training)
             conv_forward_raw(z1, c2w, None, 1, 1, pro=(p2.scale, p2.shift, True), out=buf[:, cin:cin + growth],
                              stats=stats[:, :, cin:cin + growth] if training else None)
             saved += [z1, p1.buf, p2.buf]
@@ -1762,16 +1763,16 @@ def dense_block(x0, layers, training):
     """layers: list of modules with norm1, conv1, norm2, conv2.  Returns (concat buffer, its channel statistics)."""
     if not training and not torch.is_grad_enabled() and x0.is_cuda:
         return dense_block_infer(x0, layers), None
-    eps = {float(n.eps) for m in layers for n in (m.norm1, m.norm2)}
+    eps = {float(m.norm1.eps) for m in layers}       # (norm2 of a layer normalises its own 128 channels: its eps / momentum travel per layer)
     if len(eps) > 1:
         # the block shares one set of normalised-input rows (invstd computed once per concat channel) between all its norm1 layers, forward and
         # backward: that is only the BatchNorm of every layer when they agree on eps (torchvision's _DenseLayer always does)
-        raise RuntimeError("dense_block: the BatchNorm layers of one dense block must share eps, got %s" % sorted(eps))
+        raise RuntimeError("dense_block: the norm1 layers of one dense block must share eps, got %s" % sorted(eps))
     params, bufs, cfgs = [], [], []
     for m in layers:
         params += [m.norm1.weight, m.norm1.bias, m.conv1.weight, m.norm2.weight, m.norm2.bias, m.conv2.weight]
         bufs += [m.norm1.running_mean, m.norm1.running_var, m.norm2.running_mean, m.norm2.running_var]
-        cfgs.append((m.norm1.momentum, m.norm1.eps))
+        cfgs.append((m.norm1.momentum, m.norm1.eps, m.norm2.momentum, m.norm2.eps))
         _bump(m.norm1); _bump(m.norm2)
     return _DenseBlock.apply(x0, training, tuple(cfgs), *params, *bufs)
 

@@ -476,3 +476,26 @@ def test_conv_dgrad_accumulates_onto_the_residual_gradient(dtype, shape):
     F.conv2d(xr, q(wt, dtype), None, 1, 1).backward(q(dy, dtype))
     ref = q(base, dtype) + xr.grad
     close(out, ref, TOL[dtype] * (2 if dtype == torch.bfloat16 else 1), "out += dx")
+
+
+@pytest.mark.parametrize("hw", [32, 160])      # 2 x 32 x 32 = 2048 pixels: exact f32 MFMA; 2 x 160 x 160 = 51200 >= 16384: 3 x bf16 split MFMA
+def test_f32_split_nonfinite_operand_poisons_only_its_outputs(hw):
+    """float32 storage, one +Inf in the input of a 3x3 convolution: the outputs inside its 3x3 footprint are non-finite -- +-Inf
+    from the exact f32 MFMA of small launches, NaN from the split MFMA of large ones (csrc/common.h f32_split3: h = Inf, x - h = NaN; the guard
+    was measured at +6 % of the float32 step and not adopted) -- and EVERY output outside the footprint is finite and equals the clean run."""
+    import saunet_amd
+    HF = saunet_amd.functional
+    torch.manual_seed(3)
+    x = torch.randn(2, 32, hw, hw, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.randn(32, 32, 3, 3, device="cuda") * 0.05)
+    clean = HF.conv_forward_raw(x, w, None, 1, 1).clone()
+    x2 = x.clone(); x2[1, 5, 10, 12] = float("inf")
+    y = HF.conv_forward_raw(x2, w, None, 1, 1)
+    torch.cuda.synchronize()
+    foot = torch.zeros(2, 1, hw, hw, dtype=torch.bool, device="cuda"); foot[1, :, 9:12, 11:14] = True
+    bad = ~torch.isfinite(y)
+    assert bool(bad[foot.expand_as(bad)].all())                      # every channel reads channel 5 with a non-zero weight
+    assert not bool(bad[~foot.expand_as(bad)].any())
+    assert torch.equal(y[~foot.expand_as(y)], clean[~foot.expand_as(clean)])
+    if hw * hw * 2 < 16384:
+        assert bool(torch.isinf(y[foot.expand_as(y)]).all())         # exact f32 MFMA: Inf propagates as Inf
