@@ -93,17 +93,21 @@ def test_mask_to_edges_matches_loader_formulation():
 
 
 def test_dense_block_refuses_batchnorm_layers_with_different_eps():
-    """the fused dense block shares one normalisation (invstd per concat channel) between all its norm1 layers: layers that disagree on eps
-    must be refused before anything is launched (torchvision _DenseLayer, /root/reference/models/models.py:306-313, always agrees)"""
+    """the fused dense block shares one normalisation (invstd per concat channel) between all its norm1 layers: layers whose NORM1 eps disagree
+    must be refused before anything is launched (torchvision _DenseLayer, /root/reference/models/models.py:306-313, always agrees).  norm2
+    normalises a layer's own 128 channels: its eps / momentum travel per layer and may differ -- such a block passes the guard (and,
+    on this CPU-only box, stops at the device check instead)."""
     import pytest
     import saunet_amd
     from saunet_amd import functional as HF
 
     class Layer(torch.nn.Module):
-        def __init__(self, cin, eps2):
+        def __init__(self, cin, eps1, eps2):
             super().__init__()
-            self.norm1 = torch.nn.BatchNorm2d(cin); self.conv1 = torch.nn.Conv2d(cin, 128, 1, bias=False)
+            self.norm1 = torch.nn.BatchNorm2d(cin, eps=eps1); self.conv1 = torch.nn.Conv2d(cin, 128, 1, bias=False)
             self.norm2 = torch.nn.BatchNorm2d(128, eps=eps2); self.conv2 = torch.nn.Conv2d(128, 32, 3, padding=1, bias=False)
-    layers = [Layer(64, 1e-5), Layer(96, 1e-3)]
     with pytest.raises(RuntimeError, match="share eps"):
-        HF.dense_block(torch.zeros(1, 64, 16, 16), layers, True)
+        HF.dense_block(torch.zeros(1, 64, 16, 16), [Layer(64, 1e-5, 1e-5), Layer(96, 1e-3, 1e-5)], True)
+    with pytest.raises(RuntimeError) as e:
+        HF.dense_block(torch.zeros(1, 64, 16, 16), [Layer(64, 1e-5, 1e-5), Layer(96, 1e-5, 1e-3)], True)
+    assert "share eps" not in str(e.value)
