@@ -101,3 +101,53 @@ def test_forward_workspace_query(lib):
     assert handle.saunet_conv2d_forward_workspace(C.byref(desc(32, 16, 1536, 512))) == 0
     assert handle.saunet_conv2d_forward_workspace(C.byref(desc(32, 8, 1024, 512, dtype=0))) == 0
     assert handle.saunet_conv2d_forward_workspace(C.byref(desc(2, 8, 1024, 512))) == 0                                # N % 4 != 0: not cell mode
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """the host mirror's ctypes structures against the C compiler's view of include/saunet_hip.h (sizes and the offsets of the last fields): a field
+    added on one side only would shift every later pointer silently"""
+    import ctypes as C
+    import subprocess
+    from saunet_amd import lib as L
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "saunet_hip.h"\n'
+                   'int main(void) {\n'
+                   '  printf("%zu %zu %zu\\n", sizeof(saunet_conv_desc), offsetof(saunet_conv_desc, workspace), offsetof(saunet_conv_desc, workspace_bytes));\n'
+                   '  printf("%zu %zu %zu\\n", sizeof(saunet_dense_layer_bwd), offsetof(saunet_dense_layer_bwd, count), offsetof(saunet_dense_layer_bwd, dbeta2));\n'
+                   '  printf("%zu %zu %zu\\n", sizeof(saunet_dense_bn1_list), offsetof(saunet_dense_bn1_list, cin), offsetof(saunet_dense_bn1_list, dbeta));\n'
+                   '  printf("%zu %zu %zu\\n", sizeof(saunet_bn_epilogue), offsetof(saunet_bn_epilogue, sums), offsetof(saunet_bn_epilogue, sums_rstride));\n'
+                   '  printf("%zu %zu %zu\\n", sizeof(saunet_bn_prologue), offsetof(saunet_bn_prologue, params), offsetof(saunet_bn_prologue, running_var));\n'
+                   '  return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    rows = [tuple(int(v) for v in l.split()) for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines()]
+    want = [(C.sizeof(L.ConvDesc), L.ConvDesc.workspace.offset, L.ConvDesc.workspace_bytes.offset),
+            (C.sizeof(L.DenseLayerBwd), L.DenseLayerBwd.count.offset, L.DenseLayerBwd.dbeta2.offset),
+            (C.sizeof(L.DenseBn1List), L.DenseBn1List.cin.offset, L.DenseBn1List.dbeta.offset),
+            (C.sizeof(L.BnEpilogue), L.BnEpilogue.sums.offset, L.BnEpilogue.sums_rstride.offset),
+            (C.sizeof(L.BnPrologue), L.BnPrologue.params.offset, L.BnPrologue.running_var.offset)]
+    assert rows == want, (rows, want)
+
+
+def test_bench_reads_the_kernel_ranking_of_the_committed_profile():
+    """bench.py's roofline takes its kernels from the committed rocprofv3 table of the round: the parser must return the [families] first row and the
+    top symbols of the [symbols] section, with names in the form the library's launch log uses"""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    finally:
+        sys.argv = argv
+    path = os.path.join(ROOT, b.STATS_FILE)
+    assert os.path.exists(path), "profiles/ lacks this round's kernel table: %s" % b.STATS_FILE
+    syms, fams = b.read_kernel_ranking(path)
+    first_family_row = next(l for l in open(path).read().split("# [families]")[1].splitlines()[2:] if l.strip())
+    assert fams[0][0] in first_family_row and fams[0][0].endswith("_kernel")
+    assert all("_kernel" in s[0] and "(" not in s[0] and "saunet::" not in s[0] for s in syms[:10])
+    assert syms[0][1] >= syms[1][1] >= syms[2][1] > 0
+    assert b._main_symbol("bn_bwd_correct_ab_kernel<unsigned short, 8>+dense_dgrad3_kernel<true, false>")[0] == "dense_dgrad3_kernel<true, false>"
+    assert b._norm_symbol("void saunet::conv_igemm_fwd_kernel<unsigned short, 64, 64, 32, 32, 8, false>(saunet::IgemmArgs)") == \
+        "conv_igemm_fwd_kernel<unsigned short, 64, 64, 32, 32, 8, false>"
+    assert b._norm_symbol("wgrad_reduce_multi") == "wgrad_reduce_multi_kernel"
