@@ -636,7 +636,7 @@ def extras(args, S, dev):
         # three of the five seeds of tests/test_hip_dice.py (the full table: profiles/r04_dice.json); the reference arm is DATA from the committed
         # fixture tests/golden/dice_ref.npz (the real reference trained on the CPU from the same weights / batches, oracle/make_golden_dice.py)
         ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "dice_ref.npz")
-        d = dice.paired_study(seeds=(304, 305, 307), ref_npz=ref if os.path.exists(ref) else None)
+        d = dice.paired_study(seeds=(304, 305, 306, 307, 308), ref_npz=ref if os.path.exists(ref) else None)      # all five seeds of the reference fixture: CI half-widths 0.012-0.018 (three seeds: 0.03-0.05)
         out["val_dice"] = {"protocol": d["protocol"], "seeds": d["seeds"],
                            "rows": [{k: r[k] for k in ("seed", "f32", "bf16", "ref") if k in r} for r in d["rows"]],
                            "mean_f32": d["mean_dice_f32"], "mean_bf16": d["mean_dice_bf16"], "mean_ref": d.get("mean_dice_ref"),
