@@ -282,6 +282,17 @@ __device__ __forceinline__ void rep_sum2(const double* __restrict__ a, const dou
 {
     double va = 0.0, vb = 0.0;
     int r = 0;
+    // sixteen replicas (the usual count) in ONE round trip: these chains sit in the prologue of every small-map kernel, where a second
+    // dependent batch is a microsecond of a 10 us launch; the summation order (pairs, then groups of eight in replica order) is unchanged
+    for (; r + 16 <= reps; r += 16) {
+        double t[16], u[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { t[j] = a[(size_t)(r + j) * rstride + i]; u[j] = b[(size_t)(r + j) * rstride + i]; }
+        va += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        vb += ((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]));
+        va += ((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15]));
+        vb += ((u[8] + u[9]) + (u[10] + u[11])) + ((u[12] + u[13]) + (u[14] + u[15]));
+    }
     for (; r + 8 <= reps; r += 8) {
         double t[8], u[8];
 #pragma unroll

@@ -34,6 +34,9 @@ bool tile_fwd_accumulate_supported(const saunet_conv_desc* d);
 bool mm_fwd_supported(const saunet_conv_desc* d, const void* x, const void* w, const void* y, const float* ps, const saunet_bn_epilogue* epi);
 int mm_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* ssum, double* ssq, hipStream_t st);
 int64_t mm_forward_workspace(const saunet_conv_desc* d);
+bool dense_conv2_small_supported(const saunet_conv_desc* d, const void* x, const void* w, const void* y, const float* bias);
+int dense_conv2_small_forward(const saunet_conv_desc* d, const void* x, const void* w, void* y, double* ssum, double* ssq, const saunet_bn_prologue* bnp,
+                              hipStream_t st);
 bool dense_conv1_small_supported(const saunet_conv_desc* d, const void* x, const void* w, const void* y, const float* bias);
 int dense_conv1_small_forward(const saunet_conv_desc* d, const void* x, const void* w, void* y, double* ssum, double* ssq, const saunet_bn_prologue* bnp,
                               hipStream_t st);
@@ -716,6 +719,8 @@ int saunet_conv2d_forward_bnpro(const saunet_conv_desc* d, const void* x, const 
     if (p.replicas < 1) p.replicas = 1;
     if (d->pro_relu && d->Ho == d->H && d->Wo == d->W && dense_conv1_small_supported(d, x, w, y, bias))
         return dense_conv1_small_forward(d, x, w, y, ssum, ssq, &p, st);      // DenseNet conv1 on the low-resolution blocks (csrc/dense_fwd.hip)
+    if (p.c_lo == 0 && dense_conv2_small_supported(d, x, w, y, bias))
+        return dense_conv2_small_forward(d, x, w, y, ssum, ssq, &p, st);      // DenseNet conv2 on the low-resolution blocks
     if (!d->transposed && igemm_supported(d)) {
         int ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
         if (ho != d->Ho || wo != d->Wo) return set_error(SAUNET_BAD_SHAPE, "conv: Ho/Wo %dx%d != %dx%d", d->Ho, d->Wo, ho, wo);

@@ -237,6 +237,194 @@ int dense_conv1_small_forward(const saunet_conv_desc* d, const void* x, const vo
     return SAUNET_OK;
 }
 
+
+// =====================================================================================================================================
+// DenseNet conv2 (3x3, 128 -> 32, pad 1) forward with the BatchNorm + ReLU prologue of norm2 on the LOW-RESOLUTION blocks (torchvision
+// _DenseLayer.norm2 / relu2 / conv2, /root/reference/models/models.py:306-313).  The resident 3x3 kernel (conv_tile.hip) gives a 16 x 16 map ONE
+// workgroup per image (32 of 256 CUs at block 4) and spends 7k of its 18k cycles copying the 72 KB of weights through registers before the first
+// halo arrives.  Here a workgroup owns an 8 x 8 pixel tile (128 workgroups at block 4, 512 at block 3) and requests EVERYTHING it will ever read
+// at kernel start by LDS-DMA -- the 10 x 10 x 128-channel halo (25 KB) and all 32 x 9 x 128 weights (72 KB) -- derives the BatchNorm coefficients
+// while the requests are in flight, applies BN + ReLU (and the zero padding, which belongs to the ACTIVATED tensor) in place to the pieces it
+// requested itself, and then runs the whole K = 1152 product in one go: wave (m, q) = pixel half m x quarter q of the 72 k-steps, 18 MFMAs each,
+// partial accumulators summed through the LDS.  Two barriers per workgroup.
+struct DenseConv2Args {
+    const u16* z; int ldz; const u16* w; u16* y; int ldy;
+    double* stat_sum; double* stat_sumsq; int stat_replicas, stat_rstride;
+    int N, H, W, tiles_x, tiles_y;
+    saunet_bn_prologue bnp;
+};
+constexpr int C2_HP = 10;                                       // halo pixels per row of an 8-wide tile
+constexpr int C2_W_PIECES = 32 * 144 / 64;                      // 72 requests: 32 rows x 144 chunks of 16 B
+template <int TH> struct C2Layout {                             // TH = tile rows (8 or 16), 8 columns
+    static constexpr int PIX = TH * 8, MT = TH / 4, KQ = 8 / MT, KSTEPS = 72 / KQ;      // 32-pixel MFMA tiles, K parts per tile, k-steps per wave
+    static constexpr int HALO = (TH + 2) * C2_HP, HALO_PIECES = (HALO * 16 + 63) / 64, HPW = (HALO_PIECES + 7) / 8;
+    static constexpr int OFF_W = HALO_PIECES * 1024;
+    static constexpr int OFF_PRO = OFF_W + C2_W_PIECES * 1024;  // float[2][128]
+    static constexpr int OFF_RED = OFF_PRO + 1024;              // float[KQ][PIX][32] = 32 KB
+    static constexpr int OFF_SUM = OFF_RED + KQ * PIX * 32 * 4; // float[8 waves][2][32]
+    static constexpr int LDS = OFF_SUM + 8 * 2 * 32 * 4;
+};
+static __device__ u32x4 g_c2_zeros[4];
+
+template <int TH>
+__global__ __launch_bounds__(512) void dense_conv2_fwd_kernel(DenseConv2Args a)
+{
+    using LY = C2Layout<TH>;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 31, lh = lane >> 5;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    float* s_pro = (float*)(smem + LY::OFF_PRO);
+    const int t = blockIdx.x, txi = t % a.tiles_x, r1 = t / a.tiles_x, tyi = r1 % a.tiles_y, n = r1 / a.tiles_y;
+    const int y0 = tyi * TH - 1, x0 = txi * 8 - 1;
+    const u16* img = a.z + (size_t)n * a.H * a.W * a.ldz;
+
+    // ---- requests.  Halo piece p covers halo pixels 4p .. 4p+3; lane l delivers slot (pixel 4p + (l >> 4), slot l & 15), which holds logical
+    // chunk  slot ^ key(pixel),  key = (hx & 3) | (hy & 3) << 2: the 16 lanes of a ds_read_b128 group read 4 consecutive pixels of 4 consecutive
+    // rows (tile rows are 8 wide) and so cover all 16 bank groups.  Out-of-image pixels source a zero page (and are zeroed again after the prologue).
+    int hchunk[LY::HPW]; bool hin[LY::HPW];
+#pragma unroll
+    for (int j = 0; j < LY::HPW; ++j) {
+        const int piece = wave + 8 * j;
+        const int hp = piece * 4 + (lane >> 4), hy = hp / C2_HP, hx = hp - hy * C2_HP;
+        const int c = (lane & 15) ^ ((hx & 3) | ((hy & 3) << 2));
+        const int iy = y0 + hy, ix = x0 + hx;
+        hin[j] = piece < LY::HALO_PIECES && hp < LY::HALO && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        hchunk[j] = c;
+        if (piece < LY::HALO_PIECES)
+            mm_dma16(hin[j] ? (const void*)(img + ((size_t)iy * a.W + ix) * a.ldz + c * 8) : (const void*)&g_c2_zeros[lane & 3], lds0 + piece * 1024);
+    }
+    // weights: row co = 1152 contiguous elements ([tap][ci]) = 144 chunks; LDS image [32][144] chunks, lane-linear per request; slot s of row r holds
+    // logical chunk  s ^ (r & 15)  (XOR inside aligned groups of 16 chunks: rows are 9 x 256 B apart and would all hit the same bank group)
+#pragma unroll
+    for (int j = 0; j < C2_W_PIECES / 8; ++j) {
+        const int q = (wave + 8 * j) * 64 + lane, row = q / 144, sl = q - row * 144;
+        const int c = (sl & ~15) | ((sl & 15) ^ (row & 15));
+        mm_dma16(a.w + (size_t)row * 1152 + c * 8, lds0 + LY::OFF_W + (wave + 8 * j) * 1024);
+    }
+    bn_prologue_fill<512>(a.bnp, 128, 128, s_pro, blockIdx.x == 0);
+    __syncthreads();
+    // ---- BN + ReLU in place on this wave's own halo pieces (the weights may still be in flight: C2_W_PIECES / 8 = 9 requests behind them)
+    mm_wait_vm<C2_W_PIECES / 8>();
+#pragma unroll
+    for (int j = 0; j < LY::HPW; ++j) {
+        const int piece = wave + 8 * j;
+        if (piece < LY::HALO_PIECES) {
+            unsigned char* q = smem + piece * 1024 + lane * 16;
+            float f[8];
+            Vec16<u16>::unpack(*(const u32x4*)q, f);
+            const int c0 = hchunk[j] * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 sc = *(const f32x4*)(s_pro + c0 + 4 * h), sh = *(const f32x4*)(s_pro + 128 + c0 + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[4 * h + e] = hin[j] ? fmaxf(fmaf(f[4 * h + e], sc[e], sh[e]), 0.f) : 0.f;
+            }
+            *(u32x4*)q = Vec16<u16>::pack(f);
+        }
+    }
+    mm_wait_vm<0>();
+    mm_barrier();
+    // ---- the product: wave (m, q): pixels 32m .. 32m+31 of the tile (4 rows of 8), k-steps KSTEPS*q .. of the 72 (k-step = tap * 8 + 16-channel group)
+    const int wm = wave % LY::MT, wq = wave / LY::MT;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+        const int py = wm * 4 + (lr >> 3), px = lr & 7;
+        const unsigned char* sw = smem + LY::OFF_W + lr * (144 * 16);
+#pragma unroll
+        for (int i = 0; i < LY::KSTEPS; ++i) {
+            const int ks = wq * LY::KSTEPS + i, tap = ks >> 3, cg = ks & 7, kh = tap / 3, kw = tap - kh * 3;
+            const int hy = py + kh, hx = px + kw, hp = hy * C2_HP + hx;
+            const u32x4 af = *(const u32x4*)(smem + hp * 256 + (((2 * cg + lh) ^ ((hx & 3) | ((hy & 3) << 2))) << 4));
+            const int bc = ks * 2 + lh;
+            const u32x4 bf = *(const u32x4*)(sw + (((bc & ~15) | ((bc & 15) ^ (lr & 15))) << 4));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bf), acc, 0, 0, 0);
+        }
+    }
+    // ---- sum the K parts through the LDS: partial [q][pixel][channel] float
+    float* s_red = (float*)(smem + LY::OFF_RED);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        s_red[(wq * LY::PIX + row) * 32 + lr] = acc[r];
+    }
+    __syncthreads();
+    // thread -> (pixel, 4 consecutive channels): PIX x 8 items, PIX / 64 per thread; a wave's 64 threads cover 8 pixels x 8 channel groups
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int c4 = (tid & 7) * 4;
+#pragma unroll
+    for (int it = 0; it < LY::PIX / 64; ++it) {
+        const int prow = (tid >> 3) + it * 64;
+        f32x4 v = *(const f32x4*)(s_red + prow * 32 + c4);
+#pragma unroll
+        for (int qq = 1; qq < LY::KQ; ++qq) { const f32x4 u = *(const f32x4*)(s_red + (qq * LY::PIX + prow) * 32 + c4); v += u; }
+        const int oy = tyi * TH + (prow >> 3), ox = txi * 8 + (prow & 7);
+        u16* yo = a.y + ((size_t)(n * a.H + oy) * a.W + ox) * a.ldy + c4;
+        *(uint2*)yo = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+    }
+    if (a.stat_sum != nullptr) {
+        // per-channel sum / sum of squares over the tile: lanes of equal (tid & 7) hold the same channels -> xor-shuffle over bits 3..5, one slot
+        // per wave, fixed-order fold
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+        float* s_sum = (float*)(smem + LY::OFF_SUM);
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s_sum[(wave * 2) * 32 + c4 + e] = s1[e]; s_sum[(wave * 2 + 1) * 32 + c4 + e] = s2[e]; }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) { t1 += s_sum[(w8 * 2) * 32 + tid]; t2 += s_sum[(w8 * 2 + 1) * 32 + tid]; }
+            const size_t ro = (size_t)(blockIdx.x % a.stat_replicas) * a.stat_rstride;
+            atomicAdd(&a.stat_sum[ro + tid], (double)t1);
+            atomicAdd(&a.stat_sumsq[ro + tid], (double)t2);
+        }
+    }
+}
+
+bool dense_conv2_small_supported(const saunet_conv_desc* d, const void* x, const void* w, const void* y, const float* bias)
+{
+    static const bool on = ab_env_on("SAUNET_DENSE_CONV2_SMALL");       // A/B switch (variant builds only)
+    const long tiles = (long)d->N * (d->H / 8) * (d->W / 8);
+    return on && d->dtype == SAUNET_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->transposed && d->Cin == 128 && d->Cout == 32 &&
+           d->ldx == 128 && d->ldy % 4 == 0 && d->H % 8 == 0 && d->W % 8 == 0 && d->Ho == d->H && d->Wo == d->W && bias == nullptr && !d->epi_relu &&
+           d->pro_relu && tiles >= 1 && tiles <= 1024 && !(((uintptr_t)x | (uintptr_t)w) & 15) && !((uintptr_t)y & 7) && (long)d->N * d->H * d->W < (1L << 30);
+}
+
+int dense_conv2_small_forward(const saunet_conv_desc* d, const void* x, const void* w, void* y, double* ssum, double* ssq, const saunet_bn_prologue* bnp,
+                              hipStream_t st)
+{
+    DenseConv2Args a;
+    a.z = (const u16*)x; a.ldz = d->ldx; a.w = (const u16*)w; a.y = (u16*)y; a.ldy = d->ldy;
+    a.stat_sum = ssum; a.stat_sumsq = ssq; a.stat_replicas = d->stat_replicas > 1 ? d->stat_replicas : 1; a.stat_rstride = d->stat_rstride;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.tiles_x = d->W / 8; a.tiles_y = d->H / 8;
+    a.bnp = *bnp;
+    // 16 x 8 tiles while they still give every CU a workgroup (block 3 at B = 32: 256), 8 x 8 tiles below that
+    static const int force_th = ab_env_int("SAUNET_DENSE_CONV2_TH", 0);       // A/B switch (variant builds only)
+    const bool tall = force_th ? force_th == 16 && d->H % 16 == 0 : (d->H % 16 == 0 && (long)d->N * (d->H / 16) * (d->W / 8) >= 256);
+    static DeviceOnce attr;
+    if (attr.first()) {
+        (void)hipFuncSetAttribute((const void*)dense_conv2_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)dense_conv2_fwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if (tall) {
+        a.tiles_y = d->H / 16;
+        hipLaunchKernelGGL(dense_conv2_fwd_kernel<16>, dim3(a.N * a.tiles_x * a.tiles_y), dim3(512), C2Layout<16>::LDS, st, a);
+        SAUNET_CHECK_LAUNCH("dense_conv2_fwd_kernel<16>");
+    } else {
+        hipLaunchKernelGGL(dense_conv2_fwd_kernel<8>, dim3(a.N * a.tiles_x * a.tiles_y), dim3(512), C2Layout<8>::LDS, st, a);
+        SAUNET_CHECK_LAUNCH("dense_conv2_fwd_kernel<8>");
+    }
+    return SAUNET_OK;
+}
+
 }  // namespace saunet
 
 SAUNET_TIMING_READER(dense_fwd)

@@ -427,3 +427,43 @@ def test_layer_backward_conv2_entry_matches_float64(shape, corrected):
     scale1 = float(G.abs().sum((0, 2, 3)).max())
     assert float((sums[:128] - G.sum((0, 2, 3))).abs().max()) <= 2e-5 * scale1
     assert float((sums[128:] - (G * xhat2).sum((0, 2, 3))).abs().max()) <= 2e-5 * float((G * xhat2).abs().sum((0, 2, 3)).max()) + 1e-4 * scale1
+
+
+@pytest.mark.parametrize("n,h,w", [(8, 16, 16), (2, 32, 32), (3, 8, 24), (1, 8, 8), (32, 32, 32)])      # last: 16 x 8 tiles (256 workgroups)
+def test_small_map_conv2_forward_with_bn_prologue_matches_float64(n, h, w):
+    """dense_conv2_fwd_kernel (csrc/dense_fwd.hip, round 5): out = conv3x3(relu(BN(z1)), pad 1) written into a channel slice of the concat buffer, the
+    BatchNorm coefficients derived in the kernel from z1's raw sums, zero padding applied to the ACTIVATED tensor, operands staged by LDS-DMA, the
+    K = 1152 product split over wave quarters and summed through the LDS -- against float64 on the bf16-rounded operands, with the output statistics
+    and the parameter block (torchvision _DenseLayer.norm2 -> relu2 -> conv2, /root/reference/models/models.py:306-313)."""
+    import saunet_amd as S
+    HF = S.functional
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(h * 7 + w)
+    z1 = (torch.randn(n, 128, h, w, generator=g) * 1.3 + 0.2).cuda().to(dt).contiguous(memory_format=torch.channels_last)
+    weight = torch.nn.Parameter((torch.randn(32, 128, 3, 3, generator=g) * 0.05).cuda())
+    gamma = torch.empty(128).uniform_(0.5, 1.5, generator=g).cuda(); beta = torch.empty(128).uniform_(-0.3, 0.3, generator=g).cuda()
+    count = n * h * w
+    HF.STATS.reset(); HF.GRADS.reset()
+    st2 = HF.bn_stats(z1)
+    buf = torch.zeros(n, 96, h, w, device="cuda", dtype=dt).contiguous(memory_format=torch.channels_last)
+    params = HF.BNParams(128, "cuda")
+    rm, rv = torch.zeros(128, device="cuda"), torch.ones(128, device="cuda")
+    st_out = HF.new_stats(96, "cuda")
+    HF.L.load().saunet_launch_log()
+    HF.conv_forward_bnpro(z1, weight, 1, 1, st2, count, 0, None, gamma, beta, rm, rv, 0.1, 1e-5, params.buf, out=buf[:, 32:64], stats=st_out[:, :, 32:64])
+    launched = HF.L.load().saunet_launch_log().decode()
+    assert "dense_conv2_fwd_kernel" in launched, launched
+    sums = st_out.sum(0).double().cpu()
+    torch.cuda.synchronize()
+    xd = z1.double()
+    mean = xd.mean((0, 2, 3)); var = xd.var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = gamma.double() * invstd; shift = beta.double() - mean * scale
+    a = torch.relu(xd * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).to(dt).double()
+    ref = F.conv2d(a, weight.detach().to(dt).double(), padding=1)
+    assert rel(buf[:, 32:64], ref) < 1e-2, rel(buf[:, 32:64], ref)
+    assert float(buf[:, :32].abs().max()) == 0.0 and float(buf[:, 64:].abs().max()) == 0.0           # neighbouring slices untouched
+    assert (sums[0, 32:64] - ref.sum((0, 2, 3)).cpu()).abs().max() <= 2e-3 * ref.abs().sum((0, 2, 3)).max().cpu()
+    assert (sums[1, 32:64] - (ref * ref).sum((0, 2, 3)).cpu()).abs().max() <= 2e-3 * (ref * ref).sum((0, 2, 3)).max().cpu()
+    assert float(sums[:, :32].abs().max()) == 0.0
+    assert rel(params.scale, scale) < 1e-5 and rel(params.shift, shift) < 1e-4
