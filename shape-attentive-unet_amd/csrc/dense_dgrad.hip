@@ -655,6 +655,267 @@ bool dense_dgrad_supported(const saunet_conv_desc* d, const float* bias, const f
            bias == nullptr && ps == nullptr && d->Cout <= 2048 && (long)d->N * d->H * d->W < (1L << 31);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the conv1 data gradient of the fused layer backward on the LOW-RESOLUTION blocks, NON-transposed and LDS-staged.
+// dense_dgrad_kernel above computes the product transposed so that x / dbuf travel as 16-byte row pieces without LDS -- the right trade on the
+// large maps (HBM-bound, long persistent loops), but its epilogue then holds 16 CHANNELS of one pixel per lane: per-channel coefficients come from
+// LDS for every element and the two BatchNorm sums need transposing DPP reductions -- ~490 VALU instructions per 64-channel step and wave for 16
+// MFMAs, and with two waves per SIMD that VALU stream IS the step on blocks 3 / 4 (PMC: VALU 24 %, 38 % waiting, 4.7k cycles per step).
+// Here rows = pixels, columns = channels:
+//   * a lane owns ONE channel and 16 pixels of a 32 x 32 MFMA tile: scale / shift / xhat coefficients are four registers, the two sums are a
+//     per-lane add + one cross-half shuffle -- ~8 VALU per element;
+//   * every operand arrives by LDS-DMA: the G and z1 tiles (128 pixels x 128), BN2-backward applied in place by the requesting wave (dz1, written
+//     out once per pixel tile: no channel groups re-transforming the same rows), then the A fragments stay in registers and per 64-channel step
+//     the weight rows, the x tile (mask, xhat) and the dbuf tile (read-modify-write IN the LDS, stored back as whole 16-byte row pieces);
+//   * software pipeline of one stage: the product of step j (weights W(j)) runs interleaved with the epilogue of step j - 1 (x / dbuf tile
+//     (j - 1)); W is requested one stage before its product and x / dbuf one stage before their epilogue, so both rings are two slots
+//     (2 x 16 KB + 2 x 32 KB) and a stage has ONE barrier; the partial BatchNorm sums of up to 8 steps wait in LDS for one fold + atomics;
+//   * the steps of a pixel tile may be split over blockIdx.y when the map has fewer than 256 tiles (block 4).
+// Measured (MI355X, scripts/dense_chain_micro.py): block 3 backward 82.6 -> 76.8 us / layer, block 4 53.7 -> 46.4.  On block 3 the kernel now
+// moves its ~150 MB (x read, dbuf read + write, G / z1 / dz1 once) in 35 us: ~4.2 TB/s, the rate every HBM-bound kernel of this step reaches
+// (profiles/r05_step_pmc_summary.txt), so neither the pipelining (same time as the unpipelined loop) nor BM = 64 with two independent 4-wave
+// blocks per CU (slower: a third more DMA requests per pixel) changes it -- what is left there is byte count, not schedule.
+template <int BM_> struct DgLdsLayout {
+    static constexpr int BM = BM_, BN = 64, NW = BM / 16, THREADS = NW * 64;     // waves: BM / 32 pixel groups x 2 channel groups
+    static constexpr int A_BYTES = BM * 256, Z_BYTES = BM * 256;                 // G / dz1 tile, z1 tile (128 channels = 256 B rows)
+    static constexpr int W_BYTES = BN * 256, X_BYTES = BM * BN * 2, Y_BYTES = BM * BN * 2, XY_BYTES = X_BYTES + Y_BYTES;
+    static constexpr int OFF_XY = 0;                                             // two x / dbuf slots = the A / z1 space once the fragments are in registers
+    static constexpr int OFF_W = 2 * XY_BYTES;                                   // two weight slots
+    static_assert(A_BYTES + Z_BYTES <= OFF_W, "prologue tiles overlay the x / dbuf ring only");
+    static constexpr int MAX_STEPS = 8;                                          // 64-channel steps whose partial sums the ring holds before a fold
+    static constexpr int OFF_PART = OFF_W + 2 * W_BYTES;                         // float[MAX_STEPS][BM / 32 row waves][2][64] partial sums; before the
+    static constexpr int PART_STEP = (BM / 32) * 128;                            // loop its first 1.5 KB hold the float[3][128] BN2-backward coefficients
+    static constexpr int LDS = OFF_PART + MAX_STEPS * PART_STEP * 4;
+    static_assert(MAX_STEPS * PART_STEP * 4 >= 3 * 128 * 4, "coefficient overlay");
+};
+// byte offset of 16-byte chunk c (0..15) of row r in a [rows][16] chunk image (256-byte rows)
+__device__ __forceinline__ int dgl_off(int r, int c) { return (r * 16 + (c ^ (r & 15))) * 16; }
+
+#ifndef SAUNET_DGL_VALU
+#define SAUNET_DGL_VALU 20
+#endif
+template <int BM>
+__global__ __launch_bounds__(DgLdsLayout<BM>::THREADS) void dense_conv1_dgrad_lds_kernel(DenseDgradArgs a)
+{
+    using LY = DgLdsLayout<BM>;
+    constexpr int NT = LY::THREADS, WPIECES = 16 / LY::NW;        // weight pieces per wave and step (x / dbuf: always two, G / z1: always four)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;                     // BM / 32 pixel groups of 32 x 2 channel groups of 32
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int m0 = blockIdx.x * LY::BM;
+    const int nsteps = (a.Cin + LY::BN - 1) / LY::BN;
+    const int spg = (nsteps + gridDim.y - 1) / gridDim.y;        // steps per channel group
+    const int j0 = blockIdx.y * spg, j1 = min(j0 + spg, nsteps);
+    if (j0 >= j1) return;
+    float* s_cf = (float*)(smem + LY::OFF_PART);
+    const int P = (int)a.P;
+
+    // ---- requests of one 64-channel step: 16 weight pieces of 1 KB (one step ahead of the product) and BM / 8 pieces each of x and dbuf
+    // (one step ahead of the epilogue, which runs one step behind the product)
+    auto issue_w = [&](int j) {
+        const int c0 = j * LY::BN;
+        const unsigned dst = lds0 + LY::OFF_W + ((j - j0) & 1) * LY::W_BYTES;
+#pragma unroll
+        for (int q = 0; q < WPIECES; ++q) {
+            // weight rows c0 + 4 piece .. +3 (row = input channel of conv1, 128 K-contiguous elements); rows past Cin repeat the last one
+            const int piece = wave * WPIECES + q, row = piece * 4 + (lane >> 4), c = (lane & 15) ^ (row & 15);
+            mm_dma16(a.w + (size_t)min(c0 + row, a.Cin - 1) * 128 + c * 8, dst + piece * 1024);
+        }
+    };
+    auto issue_xy = [&](int j) {
+        const int c0 = j * LY::BN;
+        const unsigned dst = lds0 + LY::OFF_XY + ((j - j0) & 1) * LY::XY_BYTES;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            // pixel rows of 128 B (64 channels), 8 pixels per piece; channels past the buffer row end are clamped (never used)
+            const int piece = wave * 2 + q, px = piece * 8 + (lane >> 3), ch = lane & 7;
+            const size_t m = (size_t)min(m0 + px, P - 1);
+            const int cc = min(c0 + ch * 8, a.Cin - 8);
+            mm_dma16(a.x + m * a.ldx + cc, dst + piece * 1024);
+            mm_dma16(a.y + m * a.ldy + cc, dst + LY::X_BYTES + piece * 1024);
+        }
+    };
+    // ---- prologue: G and z1 tiles (four pieces each per wave), the first step's weights, the BN2-backward coefficients meanwhile
+    TSTAMP_INIT();
+    TSTAMP(90);
+    int arow[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int piece = wave * 4 + q, row = piece * 4 + (lane >> 4), c = (lane & 15) ^ (row & 15);
+        const size_t m = (size_t)min(m0 + row, P - 1);
+        arow[q] = row | (c << 8);
+        mm_dma16(a.g + m * a.ldg + c * 8, lds0 + piece * 1024);
+        mm_dma16(a.z + m * a.ldz + c * 8, lds0 + LY::A_BYTES + piece * 1024);
+    }
+    issue_w(j0);
+    for (int k = tid; k < 128; k += NT) {
+        double S1, S2;
+        rep_sum2(a.sums2, a.sums2 + 128, a.reps2, a.rstride2, k, S1, S2);
+        const float sc = a.p2[k], mu = a.p2[256 + k], is = a.p2[384 + k];
+        const float m1 = (float)(S1 / a.count), m2 = (float)(S2 / a.count);
+        s_cf[k] = sc; s_cf[128 + k] = -sc * is * m2; s_cf[256 + k] = -sc * (m1 - mu * is * m2);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && a.dgamma2) { a.dbeta2[k] = (float)S1; a.dgamma2[k] = (float)S2; }
+    }
+    __syncthreads();
+    TSTAMP(91);
+    mm_wait_vm<WPIECES>();                                        // the G / z1 pieces have landed (the weights of the first step may not have)
+    // dz1 = a*G + b*z1 + c in place, on the pieces this wave requested; written out once per pixel tile (by channel group 0)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int piece = wave * 4 + q, row = arow[q] & 0xff, c = arow[q] >> 8;
+        unsigned char* pg = smem + piece * 1024 + lane * 16;
+        float G[8], Z[8], d[8];
+        Vec16<u16>::unpack(*(const u32x4*)pg, G);
+        Vec16<u16>::unpack(*(const u32x4*)(pg + LY::A_BYTES), Z);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 ca = *(const f32x4*)(s_cf + c * 8 + 4 * h), cb = *(const f32x4*)(s_cf + 128 + c * 8 + 4 * h), cc = *(const f32x4*)(s_cf + 256 + c * 8 + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[4 * h + e] = fmaf(ca[e], G[4 * h + e], fmaf(cb[e], Z[4 * h + e], cc[e]));
+        }
+        const u32x4 v = Vec16<u16>::pack(d);
+        *(u32x4*)pg = v;
+        if (blockIdx.y == 0 && m0 + row < P) *(u32x4*)(a.dz + (size_t)(m0 + row) * a.lddz + c * 8) = v;
+    }
+    __syncthreads();
+    // the wave's A fragments (its 32 pixels x K = 128) stay in registers for every step; after this barrier the A / z1 space is stage slot 0
+    u32x4 af[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) af[ks] = *(const u32x4*)(smem + dgl_off(wm * 32 + lr, 2 * ks + lh));
+    __syncthreads();
+
+    TSTAMP(92);
+    float* s_part = (float*)(smem + LY::OFF_PART);                // [step][row waves][2][64]: folded once after the loop
+    // the lane's per-channel coefficients, fetched two steps ahead of their use (a global load at the epilogue would expose its whole latency)
+    auto coeffs = [&](int j, float& sc, float& sh, float& a1, float& a0) {
+        const int chs = min(j * LY::BN + wn * 32 + lr, a.Cin - 1);
+        sc = a.scale[chs]; sh = a.shift[chs]; a1 = a.invstd[chs]; a0 = a.mean[chs];
+    };
+    const int col = wn * 32 + lr;
+    float nsc, nsh, na1, na0, sc = 0.f, sh = 0.f, a1 = 0.f, a0 = 0.f;
+    coeffs(j0, nsc, nsh, na1, na0);
+    f32x16 accp;                                                  // the product of the previous step, waiting for its epilogue
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[r] = 0.f;
+    // One pipeline stage: the product of step j (matrix pipe, weights from LDS) interleaved with the epilogue of step j - 1 (vector pipe, its
+    // x / dbuf tile from LDS): the two waves of a SIMD are always in the same stage (one barrier per step), so the overlap has to be inside the
+    // instruction stream.  MM / EP switch the halves off for the first and the last stage.
+    auto stage = [&](int j, auto MM, auto EP) {
+        constexpr bool mm = decltype(MM)::value, ep = decltype(EP)::value;
+        TSTAMP(93);
+        mm_wait_vm<0>();                                          // W(j) and x / dbuf (j - 1), both requested one stage ago; the last stage's stores
+        TSTAMP(94);
+        mm_barrier();                                             // the only barrier of a stage: every wave is done with the slots refilled below
+        TSTAMP(95);
+        if (mm) {
+            if (j + 1 < j1) issue_w(j + 1);
+            issue_xy(j);
+        }
+        TSTAMP(96);
+        const unsigned char* sw = smem + LY::OFF_W + ((j - j0) & 1) * LY::W_BYTES;
+        unsigned char* sx = smem + LY::OFF_XY + ((j - 1 - j0) & 1) * LY::XY_BYTES;
+        unsigned char* sy = sx + LY::X_BYTES;
+        u16 xs[16], ys[16], out[16];
+        if (ep) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                xs[r] = *(const u16*)(sx + row * 128 + col * 2);
+                ys[r] = *(const u16*)(sy + row * 128 + col * 2);
+            }
+        }
+        u32x4 bf[8];
+        if (mm) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) bf[ks] = *(const u32x4*)(sw + dgl_off(wn * 32 + lr, 2 * ks + lh));
+        }
+        __builtin_amdgcn_sched_barrier(0);                        // every LDS read of the stage is in flight before the first MFMA / VALU instruction
+        const bool cok = (j - 1) * LY::BN + col < a.Cin;
+        float s1 = 0.f, s2 = 0.f;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (mm) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[ks]), __builtin_bit_cast(bf16x8_t, bf[ks]), acc, 0, 0, 0);
+            if (ep) {
+#pragma unroll
+                for (int r = 2 * ks; r < 2 * ks + 2; ++r) {
+                    const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float xf = __uint_as_float((unsigned)xs[r] << 16), yf = __uint_as_float((unsigned)ys[r] << 16);
+                    const bool keep = (int)cok & (int)(m0 + row < P) & (int)(fmaf(xf, sc, sh) > 0.f);
+                    const float Dm = keep ? accp[r] : 0.f;
+                    s1 += Dm; s2 = fmaf(Dm, fmaf(xf, a1, a0), s2);
+                    out[r] = __builtin_bit_cast(u16, (__bf16)fmaf(sc, Dm, yf));
+                }
+            }
+        }
+        if (mm && ep) {
+            // pin the interleave: one MFMA (64 matrix-pipe cycles), then the vector work of two pixels
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, SAUNET_DGL_VALU, 0);
+            }
+        }
+        TSTAMP(97);
+        if (ep) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                *(u16*)(sy + row * 128 + col * 2) = out[r];
+            }
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lh == 0) { float* sp = s_part + ((j - 1 - j0) % LY::MAX_STEPS) * LY::PART_STEP + wm * 128; sp[col] = s1; sp[64 + col] = s2; }
+            TSTAMP(98);
+            // the wave's own 32 pixels x 32 channels of the dbuf tile back as 16-byte row pieces (32 rows x 4 pieces: two per lane): no other
+            // wave's writes are read, and a wave's LDS operations execute in program order
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int q = lane + i * 64, px = wm * 32 + (q >> 2), cq = wn * 4 + (q & 3);
+                if (m0 + px < P && (j - 1) * LY::BN + cq * 8 < a.Cin)
+                    *(u32x4*)(a.y + (size_t)(m0 + px) * a.ldy + (j - 1) * LY::BN + cq * 8) = *(const u32x4*)(sy + px * 128 + cq * 16);
+            }
+        }
+        if (mm) {
+            accp = acc;
+            sc = nsc; sh = nsh; a1 = na1; a0 = -na0 * na1;
+            if (j + 1 < j1) coeffs(j + 1, nsc, nsh, na1, na0);
+        }
+        TSTAMP(99);
+    };
+    // fold the row waves' partial sums of steps [first, first + n) (fixed order) and add them to the replicas: (step, channel) pairs over the block
+    auto fold = [&](int first, int n) {
+        __syncthreads();
+        for (int q = tid; q < n * 64; q += NT) {
+            const int jj = q >> 6, cl = q & 63, c = (first + jj) * LY::BN + cl;
+            if (c >= a.Cin) continue;
+            const float* sp = s_part + ((first + jj - j0) % LY::MAX_STEPS) * LY::PART_STEP + cl;
+            float t1, t2;
+            if (BM == 128) { t1 = ((sp[0] + sp[128]) + (sp[256] + sp[384])); t2 = ((sp[64] + sp[192]) + (sp[320] + sp[448])); }
+            else           { t1 = sp[0] + sp[128]; t2 = sp[64] + sp[192]; }
+            const size_t ro = (size_t)(blockIdx.x % a.reps) * a.rstride;
+            atomicAdd(&a.sums[ro + c], (double)t1);
+            atomicAdd(&a.sums[ro + a.Cin + c], (double)t2);
+            if (a.ab) {
+                const float scc = a.scale[c];
+                const size_t ra = (size_t)(blockIdx.x % a.ab_reps) * a.ab_rstride;
+                atomicAdd(&a.ab[ra + c], (double)(scc * t1));
+                atomicAdd(&a.ab[ra + a.ab_half + c], (double)(scc * t2));
+            }
+        }
+    };
+    stage(j0, std::true_type{}, std::false_type{});
+    int folded = j0;                                              // steps below this one are in the replicas
+    for (int j = j0 + 1; j < j1; ++j) {
+        stage(j, std::true_type{}, std::true_type{});             // epilogue of step j - 1
+        if (j - folded == LY::MAX_STEPS) { fold(folded, LY::MAX_STEPS); folded = j; }   // the ring is full; the next stage's barrier orders its re-use
+    }
+    stage(j1, std::false_type{}, std::true_type{});
+    fold(folded, j1 - folded);
+}
+
 static int launch_dense_dgrad(DenseDgradArgs& a, bool apply, hipStream_t st)
 {
     // channels per block: 256 (weights copied to LDS once per block) when every wave gets many pixel tiles, fewer on the
@@ -668,6 +929,26 @@ static int launch_dense_dgrad(DenseDgradArgs& a, bool apply, hipStream_t st)
         // Cin = 320 with at most 256 channels per group is 2 x 160, not 256 + 64
         const int ng = (a.Cin + a.group - 1) / a.group;
         a.group = ((a.Cin + ng - 1) / ng + 31) & ~31;
+    }
+    static const bool lds_on = ab_env_on("SAUNET_DG_LDS");       // A/B (variant builds only)
+    static const int lds_bm = ab_env_int("SAUNET_DG_LDS_BM", 128);   // 64: two 4-wave blocks per CU -- measured slower (a third more DMA requests per pixel)
+    if (apply && lds_on && ntp < 4096 && a.Cin % 8 == 0 && a.Cin >= 64 && a.ldg == 128 && a.ldz == 128 && a.lddz == 128 && a.accumulate == 1 && a.relu) {
+        // low-resolution maps: the LDS-staged kernel; the 64-channel steps split over blockIdx.y until the chip is full
+        const int bm = lds_bm == 128 ? 128 : 64, slots = bm == 128 ? 256 : 512;
+        const int tiles = (int)((a.P + bm - 1) / bm), nsteps = (a.Cin + 63) / 64;
+        int ng = slots / tiles; if (ng < 1) ng = 1; if (ng > nsteps) ng = nsteps;
+        const int spg = (nsteps + ng - 1) / ng; ng = (nsteps + spg - 1) / spg;
+        {
+            static DeviceOnce attr0;
+            if (attr0.first()) {
+                (void)hipFuncSetAttribute((const void*)dense_conv1_dgrad_lds_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, DgLdsLayout<128>::LDS);
+                (void)hipFuncSetAttribute((const void*)dense_conv1_dgrad_lds_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, DgLdsLayout<64>::LDS);
+            }
+            if (bm == 128) hipLaunchKernelGGL(dense_conv1_dgrad_lds_kernel<128>, dim3(tiles, ng), dim3(512), DgLdsLayout<128>::LDS, st, a);
+            else           hipLaunchKernelGGL(dense_conv1_dgrad_lds_kernel<64>, dim3(tiles, ng), dim3(256), DgLdsLayout<64>::LDS, st, a);
+            SAUNET_CHECK_LAUNCH(bm == 128 ? "dense_conv1_dgrad_lds_kernel<128>" : "dense_conv1_dgrad_lds_kernel<64>");
+            return SAUNET_OK;
+        }
     }
     const int groups = (a.Cin + a.group - 1) / a.group;
     const int gcp = ((a.Cin < a.group ? a.Cin : a.group) + 31) & ~31;
