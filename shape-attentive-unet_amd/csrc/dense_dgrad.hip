@@ -597,6 +597,157 @@ __global__ __launch_bounds__((HALO ? 8 : DG_WAVES) * 64, HALO ? 1 : 2) void dens
     }
 }
 
+// ---- small maps (blocks 3 / 4: 1024 / 256 runs of 32 pixels): the per-wave kernel above gives every wave ALL 128 output channels of one run --
+// 72 dependent MFMAs and four transposed epilogues in a row behind a 75 KB weight copy into LDS that is used once (phase stamps, 16 x 16 x 32
+// images: copy + barrier 5.8k cycles, fragment loads 1.8k, four x (MFMA 0.95k + epilogue 1.6k), fold -- 22k cycles for 2.4 GFLOP).  Here the
+// four waves of a workgroup are the four 32-channel tiles of ONE run:
+//   * a wave's 32 x 288 weight rows go straight from global memory into its registers (18 fragments; no LDS copy, nothing to wait for but the load);
+//   * the 18 gradient fragments of the run are loaded -- and, CORR, corrected -- once, taps dealt over the waves, and exchanged through LDS (double
+//     buffered: one barrier per run);
+//   * the product is NOT transposed (rows = pixels, columns = channels; the same fragments with the MFMA operands swapped), so a lane owns one
+//     channel: scale / shift / xhat coefficients are four registers and the two BatchNorm sums a per-lane add + one cross-half shuffle, carried
+//     in registers to ONE pair of atomics per channel and wave -- the transposed epilogue (16 channels of one pixel per lane: coefficient vectors
+//     from LDS per element, transposing DPP reductions) measured 2.4-2.9k cycles per 32 x 32 tile, this one ~0.8k; z1 and the output pass through
+//     wave-private LDS tiles as 16-byte row pieces (80-byte pitch: the two lane halves, four rows apart, fall on different banks).
+constexpr int D3CW_PITCH = 80;
+template <bool CORR>
+__global__ __launch_bounds__(256, 2) void dense_dgrad3_cw_kernel(DenseDgrad3Args a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_frag[2][18 * 1024];    // [buffer][tap * 2 + k half][lane] 16-byte fragments
+    __shared__ __attribute__((aligned(16))) unsigned char s_zt[4][32 * D3CW_PITCH];   // [wave]: z1 of the wave's 32 channels, 32 pixel rows
+    __shared__ __attribute__((aligned(16))) unsigned char s_ot[4][32 * D3CW_PITCH];   // [wave]: the output tile
+    __shared__ float s_cc[64];
+    TSTAMP_INIT();
+    TSTAMP(50);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 31, lh = lane >> 5;
+    const int ct = wave * 32;
+    u32x4 wf[18];
+    {
+        const u16* wrow = a.w + (size_t)(ct + lr) * 288 + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks) wf[ks] = *(const u32x4*)(wrow + ks * 16);
+    }
+    // this lane's channel: the BN2 mask and xhat coefficients
+    const float sc = a.scale[ct + lr], sh = a.shift[ct + lr], a1 = a.invstd[ct + lr], a0 = -a.mean[ct + lr] * a1;
+    if constexpr (CORR) {
+        if (threadIdx.x < 32) {
+            const int c = threadIdx.x;
+            double A, B;
+            rep_sum2(a.ab, a.ab + a.ab_half, a.ab_reps, a.ab_rstride, c, A, B);
+            const float Af = (float)(A / a.count), Bf = (float)(B / a.count);
+            s_cc[c] = fmaf(Bf, a.xt[c], Af); s_cc[32 + c] = Bf * a.xs[c];
+        }
+    }
+    const unsigned ntp = (a.P + 31) / 32;
+    float red1 = 0.f, red2 = 0.f;
+    unsigned char* zt = s_zt[wave];
+    unsigned char* ot = s_ot[wave];
+    int it = 0;
+    for (unsigned tp = blockIdx.x; tp < ntp; tp += gridDim.x, ++it) {
+        const unsigned p = tp * 32u + lr;
+        const bool live = p < a.P;
+        const unsigned pc = live ? p : a.P - 1;
+        const unsigned n = a.dHW.div(pc), rem = pc - n * (unsigned)(a.H * a.W);
+        const int py = (int)a.dW.div(rem), px = (int)(rem - (unsigned)py * a.W);
+        // this wave's taps of the run: wave, wave + 4, wave + 8
+        u32x4 gv0[3], gv1[3], xv0[3], xv1[3];
+        bool okt[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int tap = wave + 4 * q;
+            if (tap < 9) {
+                const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+                okt[q] = live && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+                const size_t pix = (size_t)n * a.H * a.W + (size_t)(okt[q] ? yy : py) * a.W + (okt[q] ? xx : px);
+                const u16* row = a.g + pix * a.ldg + lh * 8;
+                gv0[q] = *(const u32x4*)row; gv1[q] = *(const u32x4*)(row + 16);
+                if constexpr (CORR) {
+                    const u16* xrow = a.xc + pix * a.ldxc + lh * 8;
+                    xv0[q] = *(const u32x4*)xrow; xv1[q] = *(const u32x4*)(xrow + 16);
+                }
+            }
+        }
+        // z1 of the wave's 32 channels: 32 rows x 4 pieces of 16 bytes, two per lane
+        u32x4 zv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = lane + 64 * i, row = q >> 2, piece = q & 3;
+            zv[i] = *(const u32x4*)(a.z + (size_t)min(tp * 32u + row, a.P - 1) * a.ldz + ct + piece * 8);
+        }
+        if (CORR && it == 0) __syncthreads();          // the correction coefficients are in LDS
+        TSTAMP(51);
+        unsigned char* fb = s_frag[it & 1];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int tap = wave + 4 * q;
+            if (tap < 9) {
+                u32x4 v0 = gv0[q], v1 = gv1[q];
+                if constexpr (CORR) {
+                    float gv[8], xv[8];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        Vec16<u16>::unpack(h ? v1 : v0, gv); Vec16<u16>::unpack(h ? xv1[q] : xv0[q], xv);
+                        const f32x4 ca0 = *(const f32x4*)(s_cc + 16 * h + 8 * lh), ca1 = *(const f32x4*)(s_cc + 16 * h + 8 * lh + 4);
+                        const f32x4 cb0 = *(const f32x4*)(s_cc + 32 + 16 * h + 8 * lh), cb1 = *(const f32x4*)(s_cc + 32 + 16 * h + 8 * lh + 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { gv[j] -= fmaf(cb0[j], xv[j], ca0[j]); gv[4 + j] -= fmaf(cb1[j], xv[4 + j], ca1[j]); }
+                        if (h) v1 = Vec16<u16>::pack(gv); else v0 = Vec16<u16>::pack(gv);
+                    }
+                    if (tap == 4 && live) {            // the corrected gradient of this lane's own pixel: what the conv2 weight gradient reads later
+                        u16* gcrow = a.gc + (size_t)pc * a.ldgc + lh * 8;
+                        *(u32x4*)gcrow = v0; *(u32x4*)(gcrow + 16) = v1;
+                    }
+                }
+                *(u32x4*)(fb + (2 * tap) * 1024 + lane * 16) = okt[q] ? v0 : u32x4{0u, 0u, 0u, 0u};
+                *(u32x4*)(fb + (2 * tap + 1) * 1024 + lane * 16) = okt[q] ? v1 : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = lane + 64 * i, row = q >> 2, piece = q & 3;
+            *(u32x4*)(zt + row * D3CW_PITCH + piece * 16) = zv[i];
+        }
+        TSTAMP(52);
+        __syncthreads();
+        TSTAMP(53);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks) {
+            const u32x4 gf = *(const u32x4*)(fb + ks * 1024 + lane * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, gf), __builtin_bit_cast(bf16x8_t, wf[ks]), acc, 0, 0, 0);
+        }
+        u16 zs[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zs[r] = *(const u16*)(zt + ((r & 3) + 8 * (r >> 2) + 4 * lh) * D3CW_PITCH + lr * 2);
+        TSTAMP(54);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float zf = __uint_as_float((unsigned)zs[r] << 16);
+            const bool keep = (int)(tp * 32u + row < a.P) & (int)(!a.relu | (fmaf(zf, sc, sh) > 0.f));
+            const float Gv = keep ? acc[r] : 0.f;
+            s1 += Gv; s2 = fmaf(Gv, fmaf(zf, a1, a0), s2);
+            *(u16*)(ot + row * D3CW_PITCH + lr * 2) = __builtin_bit_cast(u16, (__bf16)Gv);
+        }
+        red1 += s1 + __shfl_xor(s1, 32, 64); red2 += s2 + __shfl_xor(s2, 32, 64);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = lane + 64 * i, row = q >> 2, piece = q & 3;
+            if (tp * 32u + row < a.P) *(u32x4*)(a.y + (size_t)(tp * 32u + row) * a.ldy + ct + piece * 8) = *(const u32x4*)(ot + row * D3CW_PITCH + piece * 16);
+        }
+        TSTAMP(55);
+    }
+    if (lane < 32) {
+        const size_t ro = (size_t)(blockIdx.x % a.reps) * a.rstride;
+        atomicAdd(&a.sums[ro + ct + lane], (double)red1);
+        atomicAdd(&a.sums[ro + 128 + ct + lane], (double)red2);
+    }
+    TSTAMP(57);
+}
+
 // maps on which the conv2 data gradient runs the LDS-DMA staged (HALO) kernel: multiples of 16 with at least one 16 x 16 tile per CU
 static bool dense_dgrad3_halo(int N, int H, int W)
 {
@@ -619,6 +770,17 @@ static int launch_dense_dgrad3(DenseDgrad3Args& a, bool corr, hipStream_t st)
         (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
+    }
+    static const bool cw_on = ab_env_on("SAUNET_DGRAD3_CW");     // A/B (variant builds only)
+    const long runs = ((long)a.P + 31) / 32;
+    if (cw_on && runs <= 2048 && !(!corr && dense_dgrad3_halo(a.N, a.H, a.W))) {
+        // low-resolution maps: one 32-pixel run per workgroup at a time, its waves = the four 32-channel tiles
+        static const long cw_blocks = ab_env_int("SAUNET_DGRAD3_CW_BLOCKS", 512);
+        const long bx = runs < cw_blocks ? runs : cw_blocks;
+        if (corr) hipLaunchKernelGGL(dense_dgrad3_cw_kernel<true>, dim3((unsigned)bx), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(dense_dgrad3_cw_kernel<false>, dim3((unsigned)bx), dim3(256), 0, st, a);
+        SAUNET_CHECK_LAUNCH(corr ? "dense_dgrad3_cw_kernel<true>" : "dense_dgrad3_cw_kernel<false>");
+        return SAUNET_OK;
     }
     if (!corr && dense_dgrad3_halo(a.N, a.H, a.W)) {
         // one 8-wave workgroup per CU, 16 x 16 tiles: only for maps with at least one tile per CU
@@ -932,7 +1094,8 @@ static int launch_dense_dgrad(DenseDgradArgs& a, bool apply, hipStream_t st)
     }
     static const bool lds_on = ab_env_on("SAUNET_DG_LDS");       // A/B (variant builds only)
     static const int lds_bm = ab_env_int("SAUNET_DG_LDS_BM", 128);   // 64: two 4-wave blocks per CU -- measured slower (a third more DMA requests per pixel)
-    if (apply && lds_on && ntp < 4096 && a.Cin % 8 == 0 && a.Cin >= 64 && a.ldg == 128 && a.ldz == 128 && a.lddz == 128 && a.accumulate == 1 && a.relu) {
+    static const long lds_maxtp = ab_env_int("SAUNET_DG_LDS_MAXTP", 4097);   // block 2 (64 x 64 x 32 images = 4096 tiles) included: 175.9 -> 165.5 us / layer backward; block 1 is slower with it (424 -> 436)
+    if (apply && lds_on && ntp < lds_maxtp && a.Cin % 8 == 0 && a.Cin >= 64 && a.ldg == 128 && a.ldz == 128 && a.lddz == 128 && a.accumulate == 1 && a.relu) {
         // low-resolution maps: the LDS-staged kernel; the 64-channel steps split over blockIdx.y until the chip is full
         const int bm = lds_bm == 128 ? 128 : 64, slots = bm == 128 ? 256 : 512;
         const int tiles = (int)((a.P + bm - 1) / bm), nsteps = (a.Cin + 63) / 64;
