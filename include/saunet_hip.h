@@ -179,7 +179,8 @@ int saunet_conv2d_wgrad_grouped(const saunet_wgrad_group* g, void* workspace, in
  * dz2 == NULL: the chunk needs no correction (the block's last layer: nothing was accumulated into ab for it); conv2 then reads dbuf directly.
  * All accumulators are float64, replicated [R][2][C] like the statistics, zero-initialised by the caller. */
 typedef struct saunet_dense_layer_bwd {
-    int32_t N, H, W, Cin, Ctot, reserved;
+    int32_t N, H, W, Cin, Ctot;
+    int32_t c_begin;                            /* _conv1 only: 0, or the first channel this call touches (layer pairs below) */
     const void* buf; void* dbuf;                /* [P][Ctot] concat activations / gradient (channel stride Ctot) */
     const float* xhat; int32_t ld_xhat, reserved2;   /* [5][ld_xhat]: xs, xt, mean, invstd, var of the concat channels (saunet_bn_xhat / _bnpro) */
     double* ab; int32_t ab_replicas, ab_rstride;     /* [R][2][Ctot] */
@@ -193,6 +194,15 @@ typedef struct saunet_dense_layer_bwd {
 } saunet_dense_layer_bwd;
 int saunet_dense_layer_backward_conv2(const saunet_dense_layer_bwd* l, void* stream);
 int saunet_dense_layer_backward_conv1(const saunet_dense_layer_bwd* l, void* stream);
+/* Layer PAIRS (round 5): the conv1 data gradient is bound by the read of buf[:, :Cin] and the read-modify-write of dbuf[:, :Cin]; two
+ * consecutive layers touch the same rows.  Only the top 32-channel chunk of layer l is needed before layer l - 1 can start (its conv2 data
+ * gradient reads that chunk of dbuf), so a pair runs as
+ *     _conv2(hi);  _conv1(hi with c_begin = hi.Cin - 32);  _conv2(lo);  _conv1_pair(hi, lo)
+ * where _conv1_pair adds BOTH layers' contributions to dbuf[:, :lo.Cin] in one pass (lo.Cin == hi.Cin - 32; hi.dz1 is read, lo.dz1 written,
+ * sums1 / ab of both layers updated for those channels).  _pair_supported: 1 when the geometry runs the LDS-staged kernels that implement
+ * the window and the pair (low-resolution maps), else 0 -- the caller then issues the two-launch sequence per layer. */
+int saunet_dense_layer_backward_pair_supported(const saunet_dense_layer_bwd* hi);
+int saunet_dense_layer_backward_conv1_pair(const saunet_dense_layer_bwd* hi, const saunet_dense_layer_bwd* lo, void* stream);
 /* ab[0][c] += scale[c] * S1[c],  ab[0][ab_half + c] += scale[c] * S2[c]  (S = the replicated BatchNorm-backward sums of a consumer that stored
  * y = scale * g: the transition behind a dense block), dgamma = S2, dbeta = S1: the coefficient half of the linear BN backward in the running
  * float64 form the fused dense-layer backward reads. */

@@ -78,6 +78,33 @@ elif case in ("k4lds3", "k4lds4"):
     d.sums1, d.sums1_replicas, d.sums1_rstride = s1.data_ptr(), s1.shape[0], s1.stride(0)
     d.dgamma2, d.dbeta2 = dgb[0].data_ptr(), dgb[1].data_ptr()
     run = lambda: L.call("saunet_dense_layer_backward_conv1", C.byref(d), L.stream())
+elif case in ("k4pair3", "k4pair2"):
+    unit = "dense_dgrad"
+    import ctypes as C
+    cin, ctot, h = {"k4pair3": (640, 1024, 32), "k4pair2": (320, 512, 64)}[case]
+    L = S.lib
+    buf = act(ctot, h); dbuf = act(ctot, h); g = act(128, h)
+    xh = torch.zeros(5, ctot, device="cuda"); ab = torch.zeros(HF.STAT_R, 2, ctot, dtype=torch.float64, device="cuda")
+    keep = []
+    def desc(c):
+        z1 = act(128, h); dz1 = act(128, h)
+        w = torch.nn.Parameter(torch.randn(128, c, 1, 1, device="cuda") * 0.05)
+        p1 = HF.BNParams(c, "cuda"); p1.buf[0].uniform_(0.5, 1.5); p1.buf[1].normal_(0, 0.3); p1.buf[2].normal_(0, 0.3); p1.buf[3].uniform_(0.5, 1.5)
+        p2 = HF.BNParams(128, "cuda"); p2.buf[0].uniform_(0.5, 1.5); p2.buf[1].normal_(0, 0.3); p2.buf[2].normal_(0, 0.3); p2.buf[3].uniform_(0.5, 1.5)
+        s1 = torch.zeros(HF.STAT_R, 2, c, dtype=torch.float64, device="cuda"); s2 = torch.randn(HF.STAT_R, 2, 128, dtype=torch.float64, device="cuda")
+        dgb = torch.zeros(2, 128, device="cuda"); w1p = HF.PACKS.get(w, L.PACK_DGRAD, dt)
+        d = L.DenseLayerBwd()
+        d.N, d.H, d.W, d.Cin, d.Ctot = n, h, h, c, ctot
+        d.buf, d.dbuf, d.xhat, d.ld_xhat = buf.data_ptr(), dbuf.data_ptr(), xh.data_ptr(), xh.stride(0)
+        d.ab, d.ab_replicas, d.ab_rstride, d.count = ab.data_ptr(), ab.shape[0], ab.stride(0), float(n * h * h)
+        d.z1, d.g, d.dz1, d.w1_dgrad, d.p1, d.p2 = z1.data_ptr(), g.data_ptr(), dz1.data_ptr(), w1p.data_ptr(), p1.buf.data_ptr(), p2.buf.data_ptr()
+        d.sums2, d.sums2_replicas, d.sums2_rstride = s2.data_ptr(), s2.shape[0], s2.stride(0)
+        d.sums1, d.sums1_replicas, d.sums1_rstride = s1.data_ptr(), s1.shape[0], s1.stride(0)
+        d.dgamma2, d.dbeta2 = dgb[0].data_ptr(), dgb[1].data_ptr()
+        keep.extend([z1, dz1, w, p1, p2, s1, s2, dgb, w1p])
+        return d
+    dhi, dlo = desc(cin + 32), desc(cin)
+    run = lambda: L.call("saunet_dense_layer_backward_conv1_pair", C.byref(dhi), C.byref(dlo), L.stream())
 elif case in ("conv1dgrad", "conv1dgrad3", "conv1dgrad4"):
     unit = "dense_dgrad"
     cin, ctot, h = {"conv1dgrad": (192, 256, 128), "conv1dgrad3": (640, 1024, 32), "conv1dgrad4": (768, 1024, 16)}[case]

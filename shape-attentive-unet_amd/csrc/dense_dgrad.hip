@@ -40,6 +40,7 @@ struct DenseDgradArgs {
     float* dgamma2; float* dbeta2;                  // [128] out (written by block (0, 0))
     // running coefficient sums of the block's "linear" BN1 backward: ab[r][0][c] += scale[c] * sum G, ab[r][1][c] += scale[c] * sum G * xhat
     double* ab; int ab_reps, ab_rstride, ab_half;
+    int c_begin;                                    // LDS-staged kernel only: channels below c_begin are left alone (the layer pair's second launch covers them)
 };
 
 constexpr int DG_GROUP = 256;          // channels per block (weights of one group live in LDS: 256 rows x 272 B)
@@ -866,9 +867,9 @@ __global__ __launch_bounds__(DgLdsLayout<BM>::THREADS) void dense_conv1_dgrad_ld
     const int wm = wave >> 1, wn = wave & 1;                     // BM / 32 pixel groups of 32 x 2 channel groups of 32
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int m0 = blockIdx.x * LY::BM;
-    const int nsteps = (a.Cin + LY::BN - 1) / LY::BN;
-    const int spg = (nsteps + gridDim.y - 1) / gridDim.y;        // steps per channel group
-    const int j0 = blockIdx.y * spg, j1 = min(j0 + spg, nsteps);
+    const int nsteps = (a.Cin + LY::BN - 1) / LY::BN, jb = a.c_begin / LY::BN;
+    const int spg = (nsteps - jb + gridDim.y - 1) / gridDim.y;   // steps per channel group
+    const int j0 = jb + blockIdx.y * spg, j1 = min(j0 + spg, nsteps);
     if (j0 >= j1) return;
     float* s_cf = (float*)(smem + LY::OFF_PART);
     const int P = (int)a.P;
@@ -993,7 +994,7 @@ __global__ __launch_bounds__(DgLdsLayout<BM>::THREADS) void dense_conv1_dgrad_ld
             for (int ks = 0; ks < 8; ++ks) bf[ks] = *(const u32x4*)(sw + dgl_off(wn * 32 + lr, 2 * ks + lh));
         }
         __builtin_amdgcn_sched_barrier(0);                        // every LDS read of the stage is in flight before the first MFMA / VALU instruction
-        const bool cok = (j - 1) * LY::BN + col < a.Cin;
+        const bool cok = (j - 1) * LY::BN + col < a.Cin && (j - 1) * LY::BN + col >= a.c_begin;
         float s1 = 0.f, s2 = 0.f;
         f32x16 acc;
 #pragma unroll
@@ -1036,7 +1037,7 @@ __global__ __launch_bounds__(DgLdsLayout<BM>::THREADS) void dense_conv1_dgrad_ld
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int q = lane + i * 64, px = wm * 32 + (q >> 2), cq = wn * 4 + (q & 3);
-                if (m0 + px < P && (j - 1) * LY::BN + cq * 8 < a.Cin)
+                if (m0 + px < P && (j - 1) * LY::BN + cq * 8 < a.Cin && (j - 1) * LY::BN + cq * 8 >= a.c_begin)
                     *(u32x4*)(a.y + (size_t)(m0 + px) * a.ldy + (j - 1) * LY::BN + cq * 8) = *(const u32x4*)(sy + px * 128 + cq * 16);
             }
         }
@@ -1052,7 +1053,7 @@ __global__ __launch_bounds__(DgLdsLayout<BM>::THREADS) void dense_conv1_dgrad_ld
         __syncthreads();
         for (int q = tid; q < n * 64; q += NT) {
             const int jj = q >> 6, cl = q & 63, c = (first + jj) * LY::BN + cl;
-            if (c >= a.Cin) continue;
+            if (c >= a.Cin || c < a.c_begin) continue;
             const float* sp = s_part + ((first + jj - j0) % LY::MAX_STEPS) * LY::PART_STEP + cl;
             float t1, t2;
             if (BM == 128) { t1 = ((sp[0] + sp[128]) + (sp[256] + sp[384])); t2 = ((sp[64] + sp[192]) + (sp[320] + sp[448])); }
@@ -1078,6 +1079,256 @@ __global__ __launch_bounds__(DgLdsLayout<BM>::THREADS) void dense_conv1_dgrad_ld
     fold(folded, j1 - folded);
 }
 
+// ---- two layers in one pass (round 5).  The conv1 data gradient is HBM-bound on x (read) and dbuf (read + write), 6 * Cin bytes per pixel and
+// layer; layer l - 1 reads and writes the same rows again, one 32-channel chunk shorter.  The only dependency between the two is that chunk: the
+// conv2 data gradient of layer l - 1 needs dbuf[:, Cin_l - 32 : Cin_l] with layer l's contribution.  So layer l first runs the kernel above on
+// that chunk alone (c_begin = Cin_l - 32: one 64-channel step), then -- after layer l - 1's conv2 data gradient -- this kernel adds BOTH layers'
+// contributions to the channels below it in one read-modify-write:  hi = layer l (its dz1 is final: A fragments straight from global memory),
+// lo = layer l - 1 (dz1 from G and z1 as above).  Per 64-channel step two products (weights of both layers by DMA), one x / dbuf tile, one
+// epilogue with two masks and four sums.  Bytes per pixel of the pair at Cin = 624:  5.5 KB instead of 8.8 KB.
+struct DenseDgradPairArgs { DenseDgradArgs lo, hi; };
+struct DgPairLayout {
+    static constexpr int BM = 128, BN = 64, NW = 8, THREADS = 512;
+    static constexpr int A_BYTES = BM * 256, Z_BYTES = BM * 256;
+    static constexpr int W_BYTES = BN * 256, X_BYTES = BM * BN * 2, Y_BYTES = BM * BN * 2, STAGE = 2 * W_BYTES + X_BYTES + Y_BYTES;   // 64 KB
+    static constexpr int OFF_S0 = 0, OFF_S1 = STAGE;             // slot 0 is the G / z1 space of the prologue
+    static_assert(A_BYTES + Z_BYTES <= STAGE, "prologue tiles overlay slot 0 only");
+    static constexpr int MAX_STEPS = 4, PART_STEP = 2 * 4 * 128;  // float[MAX_STEPS][layer][4 row waves][2][64]
+    static constexpr int OFF_PART = 2 * STAGE;
+    static constexpr int LDS = OFF_PART + MAX_STEPS * PART_STEP * 4;   // 144 KB
+};
+
+__global__ __launch_bounds__(512) void dense_conv1_dgrad_pair_kernel(DenseDgradPairArgs pa)
+{
+    using LY = DgPairLayout;
+    const DenseDgradArgs& a = pa.lo;
+    const DenseDgradArgs& b = pa.hi;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int m0 = blockIdx.x * LY::BM;
+    const int nsteps = (a.Cin + LY::BN - 1) / LY::BN;            // the channels of the SHORTER layer: a.Cin = b.Cin - 32 = b.c_begin
+    float* s_cf = (float*)(smem + LY::OFF_PART);
+    float* s_part = (float*)(smem + LY::OFF_PART);
+    const int P = (int)a.P;
+    TSTAMP_INIT();
+    TSTAMP(90);
+    // layer l's A fragments (its dz1 rows, final) straight from global memory: 8 x 16 bytes per lane, consumed at the first product
+    u32x4 af2[8];
+    {
+        const u16* row = b.dz + (size_t)min(m0 + wm * 32 + lr, P - 1) * b.lddz + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) af2[ks] = *(const u32x4*)(row + ks * 16);
+    }
+    auto issue = [&](int j, int slot_off) {
+        const int c0 = j * LY::BN;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int piece = wave * 2 + q;
+            {   // weight rows c0 + 4 piece .. + 3 of both layers; rows past Cin repeat the last one
+                const int row = piece * 4 + (lane >> 4), c = (lane & 15) ^ (row & 15);
+                const size_t off = (size_t)min(c0 + row, a.Cin - 1) * 128 + c * 8;
+                mm_dma16(a.w + off, lds0 + slot_off + piece * 1024);
+                mm_dma16(b.w + off, lds0 + slot_off + LY::W_BYTES + piece * 1024);
+            }
+            {
+                const int px = piece * 8 + (lane >> 3), ch = lane & 7;
+                const size_t m = (size_t)min(m0 + px, P - 1);
+                const int cc = min(c0 + ch * 8, a.Cin - 8);
+                mm_dma16(a.x + m * a.ldx + cc, lds0 + slot_off + 2 * LY::W_BYTES + piece * 1024);
+                mm_dma16(a.y + m * a.ldy + cc, lds0 + slot_off + 2 * LY::W_BYTES + LY::X_BYTES + piece * 1024);
+            }
+        }
+    };
+    // layer l - 1's operand: G and z1 tiles by LDS-DMA (fragment-shaped global loads of the same rows measured 6k cycles slower: 64 separate
+    // 16-byte segments per instruction), BN2 backward applied in place by the requesting wave, dz1 written out for the deferred weight gradient
+    int arow[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int piece = wave * 4 + q, row = piece * 4 + (lane >> 4), c = (lane & 15) ^ (row & 15);
+        const size_t m = (size_t)min(m0 + row, P - 1);
+        arow[q] = row | (c << 8);
+        mm_dma16(a.g + m * a.ldg + c * 8, lds0 + piece * 1024);
+        mm_dma16(a.z + m * a.ldz + c * 8, lds0 + LY::A_BYTES + piece * 1024);
+    }
+    issue(0, LY::OFF_S1);
+    for (int k = tid; k < 128; k += LY::THREADS) {
+        double S1, S2;
+        rep_sum2(a.sums2, a.sums2 + 128, a.reps2, a.rstride2, k, S1, S2);
+        const float sc = a.p2[k], mu = a.p2[256 + k], is = a.p2[384 + k];
+        const float m1 = (float)(S1 / a.count), m2 = (float)(S2 / a.count);
+        s_cf[k] = sc; s_cf[128 + k] = -sc * is * m2; s_cf[256 + k] = -sc * (m1 - mu * is * m2);
+        if (blockIdx.x == 0 && a.dgamma2) { a.dbeta2[k] = (float)S1; a.dgamma2[k] = (float)S2; }
+    }
+    __syncthreads();
+    mm_wait_vm<8>();                                              // the G / z1 pieces have landed (the eight requests of step 0 may not have)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int piece = wave * 4 + q, row = arow[q] & 0xff, c = arow[q] >> 8;
+        unsigned char* pg = smem + piece * 1024 + lane * 16;
+        float G[8], Z[8], d[8];
+        Vec16<u16>::unpack(*(const u32x4*)pg, G);
+        Vec16<u16>::unpack(*(const u32x4*)(pg + LY::A_BYTES), Z);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 ca = *(const f32x4*)(s_cf + c * 8 + 4 * h), cb = *(const f32x4*)(s_cf + 128 + c * 8 + 4 * h), cc = *(const f32x4*)(s_cf + 256 + c * 8 + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[4 * h + e] = fmaf(ca[e], G[4 * h + e], fmaf(cb[e], Z[4 * h + e], cc[e]));
+        }
+        const u32x4 v = Vec16<u16>::pack(d);
+        *(u32x4*)pg = v;
+        if (m0 + row < P) *(u32x4*)(a.dz + (size_t)(m0 + row) * a.lddz + c * 8) = v;
+    }
+    __syncthreads();
+    u32x4 af1[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) af1[ks] = *(const u32x4*)(smem + dgl_off(wm * 32 + lr, 2 * ks + lh));
+    __syncthreads();
+
+    const int col = wn * 32 + lr;
+    auto coeffs = [&](const DenseDgradArgs& L, int j, float& sc, float& sh, float& a1, float& a0) {
+        const int chs = min(j * LY::BN + col, a.Cin - 1);
+        sc = L.scale[chs]; sh = L.shift[chs]; a1 = L.invstd[chs]; a0 = L.mean[chs];
+    };
+    float n1[4], n2[4];
+    coeffs(a, 0, n1[0], n1[1], n1[2], n1[3]);
+    coeffs(b, 0, n2[0], n2[1], n2[2], n2[3]);
+    // The partial sums of MAX_STEPS steps are folded (fixed order) into ONE (sum, sum * xhat) pair per thread -- 4 steps x 2 layers x 64 channels =
+    // 512 entries -- and kept in registers; the float64 atomics all go out after the last step.  (Issued inside the loop they cost a stage: the
+    // next stage's vmcnt(0) waited for their acknowledgement, 12k cycles per fold with 256 workgroups adding to the same 16 replicas.)
+    constexpr int MAX_FOLDS = 4;                                  // 16 steps: Cin <= 1024
+    float ft1[MAX_FOLDS], ft2[MAX_FOLDS];
+    auto fold = [&](int k, int first, int n) {
+        __syncthreads();
+        const int jj = tid >> 7, layer = (tid >> 6) & 1, cl = tid & 63;
+        float t1 = 0.f, t2 = 0.f;
+        if (jj < n) {
+            const float* sp = s_part + ((first + jj) % LY::MAX_STEPS) * LY::PART_STEP + layer * 512 + cl;
+            t1 = ((sp[0] + sp[128]) + (sp[256] + sp[384])); t2 = ((sp[64] + sp[192]) + (sp[320] + sp[448]));
+        }
+#pragma unroll
+        for (int i = 0; i < MAX_FOLDS; ++i) if (i == k) { ft1[i] = t1; ft2[i] = t2; }
+    };
+    auto publish = [&](int k, int first, int n) {
+        const int jj = tid >> 7, layer = (tid >> 6) & 1, cl = tid & 63, c = (first + jj) * LY::BN + cl;
+        if (jj >= n || c >= a.Cin) return;
+        const DenseDgradArgs& L = layer ? b : a;
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAX_FOLDS; ++i) if (i == k) { t1 = ft1[i]; t2 = ft2[i]; }
+        const size_t ro = (size_t)(blockIdx.x % L.reps) * L.rstride;
+        atomicAdd(&L.sums[ro + c], (double)t1);
+        atomicAdd(&L.sums[ro + L.Cin + c], (double)t2);
+        if (L.ab) {
+            const float scc = L.scale[c];
+            const size_t ra = (size_t)(blockIdx.x % L.ab_reps) * L.ab_rstride;
+            atomicAdd(&L.ab[ra + c], (double)(scc * t1));
+            atomicAdd(&L.ab[ra + L.ab_half + c], (double)(scc * t2));
+        }
+    };
+    int folded = 0;
+    TSTAMP(92);
+    for (int j = 0; j < nsteps; ++j) {
+        const int slot_off = (j & 1) ? LY::OFF_S0 : LY::OFF_S1;
+        TSTAMP(93);
+        mm_wait_vm<0>();
+        TSTAMP(94);
+        mm_barrier();                                             // the only barrier of a step
+        TSTAMP(95);
+        if (j + 1 < nsteps) issue(j + 1, (j & 1) ? LY::OFF_S1 : LY::OFF_S0);
+        TSTAMP(96);
+        const float sc1 = n1[0], sh1 = n1[1], x1 = n1[2], o1 = -n1[3] * n1[2];
+        const float sc2 = n2[0], sh2 = n2[1], x2 = n2[2], o2 = -n2[3] * n2[2];
+        if (j + 1 < nsteps) { coeffs(a, j + 1, n1[0], n1[1], n1[2], n1[3]); coeffs(b, j + 1, n2[0], n2[1], n2[2], n2[3]); }
+        const unsigned char* sw1 = smem + slot_off;
+        const unsigned char* sw2 = sw1 + LY::W_BYTES;
+        unsigned char* sx = smem + slot_off + 2 * LY::W_BYTES;
+        unsigned char* sy = sx + LY::X_BYTES;
+        u16 xs[16], ys[16], out[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            xs[r] = *(const u16*)(sx + row * 128 + col * 2);
+            ys[r] = *(const u16*)(sy + row * 128 + col * 2);
+        }
+        f32x16 acc1, acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const u32x4 bf1 = *(const u32x4*)(sw1 + dgl_off(wn * 32 + lr, 2 * ks + lh));
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af1[ks]), __builtin_bit_cast(bf16x8_t, bf1), acc1, 0, 0, 0);
+        }
+        TSTAMP(97);
+        // layer l's product (matrix pipe) runs under layer l - 1's half of the epilogue (vector pipe): the two waves of a SIMD are in the same
+        // phase (one barrier per step), so the overlap has to be in the instruction stream
+        const bool cok = j * LY::BN + col < a.Cin;
+        float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+        float D1[16], xf[16];
+        u32x4 bf2[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) bf2[ks] = *(const u32x4*)(sw2 + dgl_off(wn * 32 + lr, 2 * ks + lh));
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af2[ks]), __builtin_bit_cast(bf16x8_t, bf2[ks]), acc2, 0, 0, 0);
+#pragma unroll
+            for (int r = 2 * ks; r < 2 * ks + 2; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                xf[r] = __uint_as_float((unsigned)xs[r] << 16);
+                const int ok = (int)cok & (int)(m0 + row < P);
+                D1[r] = (ok & (int)(fmaf(xf[r], sc1, sh1) > 0.f)) ? acc1[r] : 0.f;
+                s1a += D1[r]; s2a = fmaf(D1[r], fmaf(xf[r], x1, o1), s2a);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float yf = __uint_as_float((unsigned)ys[r] << 16);
+            const int ok = (int)cok & (int)(m0 + row < P);
+            const float D2 = (ok & (int)(fmaf(xf[r], sc2, sh2) > 0.f)) ? acc2[r] : 0.f;
+            s1b += D2; s2b = fmaf(D2, fmaf(xf[r], x2, o2), s2b);
+            // the later layer first: the order its own launch would have added them in
+            out[r] = __builtin_bit_cast(u16, (__bf16)fmaf(sc1, D1[r], fmaf(sc2, D2, yf)));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            *(u16*)(sy + row * 128 + col * 2) = out[r];
+        }
+        s1a += __shfl_xor(s1a, 32, 64); s2a += __shfl_xor(s2a, 32, 64); s1b += __shfl_xor(s1b, 32, 64); s2b += __shfl_xor(s2b, 32, 64);
+        if (lh == 0) {
+            float* sp = s_part + (j % LY::MAX_STEPS) * LY::PART_STEP + wm * 128;
+            sp[col] = s1a; sp[64 + col] = s2a; sp[512 + col] = s1b; sp[512 + 64 + col] = s2b;
+        }
+        TSTAMP(98);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = lane + i * 64, px = wm * 32 + (q >> 2), cq = wn * 4 + (q & 3);
+            if (m0 + px < P && j * LY::BN + cq * 8 < a.Cin)
+                *(u32x4*)(a.y + (size_t)(m0 + px) * a.ldy + j * LY::BN + cq * 8) = *(const u32x4*)(sy + px * 128 + cq * 16);
+        }
+        TSTAMP(99);
+        if (j + 1 - folded == LY::MAX_STEPS) { fold(folded / LY::MAX_STEPS, folded, LY::MAX_STEPS); folded = j + 1; }
+    }
+    if (folded < nsteps) fold(folded / LY::MAX_STEPS, folded, nsteps - folded);
+    for (int k = 0; k * LY::MAX_STEPS < nsteps; ++k) publish(k, k * LY::MAX_STEPS, min(LY::MAX_STEPS, nsteps - k * LY::MAX_STEPS));
+}
+
+// maps on which the fused layer backward's conv1 data gradient runs the LDS-staged kernel (dense_conv1_dgrad_lds_kernel): up to 4096 runs of 32
+// pixels -- block 2 (64 x 64 x 32 images) included: 175.9 -> 165.5 us / layer backward; block 1 is slower with it (424 -> 436)
+static bool dense_lds_conv1_range(long P, int Cin)
+{
+    static const bool lds_on = ab_env_on("SAUNET_DG_LDS");       // A/B (variant builds only)
+    static const long lds_maxtp = ab_env_int("SAUNET_DG_LDS_MAXTP", 4097);
+    return lds_on && (P + 31) / 32 < lds_maxtp && Cin % 8 == 0 && Cin >= 64;
+}
+
 static int launch_dense_dgrad(DenseDgradArgs& a, bool apply, hipStream_t st)
 {
     // channels per block: 256 (weights copied to LDS once per block) when every wave gets many pixel tiles, fewer on the
@@ -1092,13 +1343,12 @@ static int launch_dense_dgrad(DenseDgradArgs& a, bool apply, hipStream_t st)
         const int ng = (a.Cin + a.group - 1) / a.group;
         a.group = ((a.Cin + ng - 1) / ng + 31) & ~31;
     }
-    static const bool lds_on = ab_env_on("SAUNET_DG_LDS");       // A/B (variant builds only)
     static const int lds_bm = ab_env_int("SAUNET_DG_LDS_BM", 128);   // 64: two 4-wave blocks per CU -- measured slower (a third more DMA requests per pixel)
-    static const long lds_maxtp = ab_env_int("SAUNET_DG_LDS_MAXTP", 4097);   // block 2 (64 x 64 x 32 images = 4096 tiles) included: 175.9 -> 165.5 us / layer backward; block 1 is slower with it (424 -> 436)
-    if (apply && lds_on && ntp < lds_maxtp && a.Cin % 8 == 0 && a.Cin >= 64 && a.ldg == 128 && a.ldz == 128 && a.lddz == 128 && a.accumulate == 1 && a.relu) {
+
+    if (apply && dense_lds_conv1_range((long)a.P, a.Cin) && a.ldg == 128 && a.ldz == 128 && a.lddz == 128 && a.accumulate == 1 && a.relu) {
         // low-resolution maps: the LDS-staged kernel; the 64-channel steps split over blockIdx.y until the chip is full
         const int bm = lds_bm == 128 ? 128 : 64, slots = bm == 128 ? 256 : 512;
-        const int tiles = (int)((a.P + bm - 1) / bm), nsteps = (a.Cin + 63) / 64;
+        const int tiles = (int)((a.P + bm - 1) / bm), nsteps = (a.Cin + 63) / 64 - a.c_begin / 64;
         int ng = slots / tiles; if (ng < 1) ng = 1; if (ng > nsteps) ng = nsteps;
         const int spg = (nsteps + ng - 1) / ng; ng = (nsteps + spg - 1) / spg;
         {
@@ -1113,6 +1363,7 @@ static int launch_dense_dgrad(DenseDgradArgs& a, bool apply, hipStream_t st)
             return SAUNET_OK;
         }
     }
+    if (a.c_begin) return set_error(SAUNET_BAD_SHAPE, "dense conv1 data gradient: a channel window needs the LDS-staged kernel (saunet_dense_layer_backward_pair_supported)");
     const int groups = (a.Cin + a.group - 1) / a.group;
     const int gcp = ((a.Cin < a.group ? a.Cin : a.group) + 31) & ~31;
     const int ns = (gcp + 63) / 64;                      // 64-channel steps of a full group (a shorter last group masks its surplus steps)
@@ -1233,7 +1484,46 @@ int saunet_dense_layer_backward_conv1(const saunet_dense_layer_bwd* l, void* str
     a.sums2 = l->sums2; a.reps2 = l->sums2_replicas; a.rstride2 = l->sums2_rstride; a.p2 = l->p2; a.count = l->count;
     a.dgamma2 = l->dgamma2; a.dbeta2 = l->dbeta2;
     a.ab = l->ab; a.ab_reps = l->ab_replicas; a.ab_rstride = l->ab_rstride; a.ab_half = l->Ctot;
+    a.c_begin = l->c_begin;
+    if (l->c_begin < 0 || l->c_begin >= l->Cin || l->c_begin % 32) return set_error(SAUNET_BAD_SHAPE, "dense_layer_backward_conv1: bad channel window");
     return launch_dense_dgrad(a, true, (hipStream_t)stream);
+}
+
+int saunet_dense_layer_backward_pair_supported(const saunet_dense_layer_bwd* hi)
+{
+    if (!hi) return 0;
+    const long P = (long)hi->N * hi->H * hi->W;
+    // the LDS-staged kernel's range (launch_dense_dgrad), one 128-pixel tile per CU at least, and a shorter layer of at least one step
+    return dense_lds_conv1_range(P, hi->Cin) && (P + 127) / 128 >= 192 && hi->Cin - 32 >= 64 && hi->Cin % 32 == 0;
+}
+
+int saunet_dense_layer_backward_conv1_pair(const saunet_dense_layer_bwd* hi, const saunet_dense_layer_bwd* lo, void* stream)
+{
+    if (int rc = dense_layer_check(hi, "dense_layer_backward_conv1_pair")) return rc;
+    if (int rc = dense_layer_check(lo, "dense_layer_backward_conv1_pair")) return rc;
+    if (!saunet_dense_layer_backward_pair_supported(hi) || lo->Cin != hi->Cin - 32 || lo->N != hi->N || lo->H != hi->H || lo->W != hi->W || lo->Ctot != hi->Ctot ||
+        lo->buf != hi->buf || lo->dbuf != hi->dbuf || lo->ab != hi->ab)
+        return set_error(SAUNET_BAD_SHAPE, "dense_layer_backward_conv1_pair: not a supported pair of consecutive layers of one block");
+    if (!hi->w1_dgrad || !hi->p1 || !hi->sums1 || !hi->dz1 || !lo->w1_dgrad || !lo->p1 || !lo->sums1 || !lo->dz1 || hi->sums1_replicas < 1 || lo->sums1_replicas < 1)
+        return set_error(SAUNET_BAD_SHAPE, "dense_layer_backward_conv1_pair: incomplete descriptor");
+    auto fill = [](const saunet_dense_layer_bwd* l, DenseDgradArgs& a) {
+        a.g = (const u16*)l->g; a.ldg = 128; a.w = (const u16*)l->w1_dgrad; a.x = (const u16*)l->buf; a.ldx = l->Ctot; a.y = (u16*)l->dbuf; a.ldy = l->Ctot;
+        a.scale = l->p1; a.shift = l->p1 + l->Cin; a.mean = l->p1 + 2 * l->Cin; a.invstd = l->p1 + 3 * l->Cin;
+        a.sums = l->sums1; a.reps = l->sums1_replicas; a.rstride = l->sums1_rstride;
+        a.P = (unsigned)((long)l->N * l->H * l->W); a.Cin = l->Cin; a.relu = 1; a.accumulate = 1;
+        a.z = (const u16*)l->z1; a.ldz = 128; a.dz = (u16*)l->dz1; a.lddz = 128;
+        a.sums2 = l->sums2; a.reps2 = l->sums2_replicas; a.rstride2 = l->sums2_rstride; a.p2 = l->p2; a.count = l->count;
+        a.dgamma2 = l->dgamma2; a.dbeta2 = l->dbeta2;
+        a.ab = l->ab; a.ab_reps = l->ab_replicas; a.ab_rstride = l->ab_rstride; a.ab_half = l->Ctot;
+    };
+    DenseDgradPairArgs pa{};
+    fill(lo, pa.lo); fill(hi, pa.hi);
+    const int tiles = (int)((pa.lo.P + 127) / 128);
+    static DeviceOnce attr;
+    if (attr.first()) (void)hipFuncSetAttribute((const void*)dense_conv1_dgrad_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DgPairLayout::LDS);
+    hipLaunchKernelGGL(dense_conv1_dgrad_pair_kernel, dim3(tiles), dim3(512), DgPairLayout::LDS, (hipStream_t)stream, pa);
+    SAUNET_CHECK_LAUNCH("dense_conv1_dgrad_pair_kernel");
+    return SAUNET_OK;
 }
 
 }  // extern "C"

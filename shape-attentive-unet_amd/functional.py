@@ -469,6 +469,10 @@ def flush_wgrad_reductions(pending):
 
 DENSE_WGRAD_GROUPED = True   # all weight gradients of a dense block as two grouped launches (False: per-layer launches)
 DENSE_COEFF_CORRECT = True   # coefficient + chunk correction of the linear BatchNorm backward in one launch (False: two)
+# Layer pairs in the fused dense backward (round 5): two consecutive layers add their conv1 data gradients to dbuf in ONE pass over buf / dbuf
+# where the library supports it (saunet_dense_layer_backward_pair_supported: the low-resolution blocks); SAUNET_DENSE_BWD_PAIRS=0 restores the
+# per-layer sequence (A/B, tests).
+DENSE_BWD_PAIRS = os.environ.get("SAUNET_DENSE_BWD_PAIRS", "1") != "0"
 DENSE_TRANSITION_FOLD = os.environ.get("SAUNET_TRANSITION_FOLD", "1") != "0"  # the transition's BN-backward apply folded into the block's linear form
 DENSE_BWD_FUSED = os.environ.get("SAUNET_DENSE_BWD_FUSED", "1") != "0"       # bf16 training: two launches per dense layer in backward (saunet_dense_layer_backward_conv2 / _conv1; False: the round-4 four)
 
@@ -1688,12 +1692,16 @@ class _DenseBlock(torch.autograd.Function):
         bl = L.DenseBn1List()
         bl.count, bl.replicas = nl, STAT_R
         keep = []
-        d = L.DenseLayerBwd()
-        d.N, d.H, d.W, d.Ctot = n, h, w, ctot
-        d.buf, d.dbuf, d.xhat, d.ld_xhat = buf.data_ptr(), dbuf.data_ptr(), xh.data_ptr(), xh.stride(0)
-        d.ab, d.ab_replicas, d.ab_rstride, d.count = ab.data_ptr(), ab.shape[0], ab.stride(0), float(count)
-        d.g = g.data_ptr()
-        for l in reversed(range(nl)):
+        def descriptor():
+            d = L.DenseLayerBwd()
+            d.N, d.H, d.W, d.Ctot = n, h, w, ctot
+            d.buf, d.dbuf, d.xhat, d.ld_xhat = buf.data_ptr(), dbuf.data_ptr(), xh.data_ptr(), xh.stride(0)
+            d.ab, d.ab_replicas, d.ab_rstride, d.count = ab.data_ptr(), ab.shape[0], ab.stride(0), float(count)
+            d.g = g.data_ptr()
+            return d
+
+        def fill(d, l):
+            """descriptor of layer l + its bookkeeping (weight-gradient work lists, BatchNorm gradient slots)"""
             n1w, n1b, c1w, n2w, n2b, c2w = params[6 * l:6 * l + 6]
             z1, p1b, p2b = saved[3 * l:3 * l + 3]
             cin = c0 + growth * l
@@ -1704,20 +1712,37 @@ class _DenseBlock(torch.autograd.Function):
             dgb2 = torch.empty(2, 128, dtype=torch.float32, device=dev)
             dgb1 = torch.empty(2, cin, dtype=torch.float32, device=dev)
             w2p, w1p = PACKS.get(c2w, L.PACK_DGRAD, buf.dtype), PACKS.get(c1w, L.PACK_DGRAD, buf.dtype)
-            d.Cin = cin
+            d.Cin, d.c_begin = cin, 0
             d.z1, d.dz1, d.dz2 = z1.data_ptr(), dz1.data_ptr(), (dz2.data_ptr() if dz2 is not None else None)
             d.w2_dgrad, d.w1_dgrad, d.p1, d.p2 = w2p.data_ptr(), w1p.data_ptr(), p1b.data_ptr(), p2b.data_ptr()
             d.sums2, d.sums2_replicas, d.sums2_rstride = s2.data_ptr(), s2.shape[0], s2.stride(0)
             d.sums1, d.sums1_replicas, d.sums1_rstride = s1.data_ptr(), s1.shape[0], s1.stride(0)
             d.dgamma2, d.dbeta2 = dgb2[0].data_ptr(), dgb2[1].data_ptr()
-            L.call("saunet_dense_layer_backward_conv2", C.byref(d), st)
-            L.call("saunet_dense_layer_backward_conv1", C.byref(d), st)
             wg2.append((l, z1, dz2 if dz2 is not None else dbuf[:, cin:cin + growth], c2w, (p2b[0], p2b[1])))
             wg1.append((l, buf[:, :cin], dz1, c1w, (p1b[0], p1b[1])))
             bl.sums[l], bl.rstride[l], bl.cin[l] = s1.data_ptr(), s1.stride(0), cin
             bl.dgamma[l], bl.dbeta[l] = dgb1[0].data_ptr(), dgb1[1].data_ptr()
-            keep += [s1, s2, w2p, w1p]
+            keep.extend([s1, s2, w2p, w1p])
             grads[6 * l], grads[6 * l + 1], grads[6 * l + 3], grads[6 * l + 4] = dgb1[0], dgb1[1], dgb2[0], dgb2[1]
+
+        d, d_lo = descriptor(), descriptor()
+        lib = L.load()
+        l = nl - 1
+        while l >= 0:
+            fill(d, l)
+            L.call("saunet_dense_layer_backward_conv2", C.byref(d), st)
+            if DENSE_BWD_PAIRS and l >= 1 and growth == 32 and lib.saunet_dense_layer_backward_pair_supported(C.byref(d)) == 1:
+                # layers l and l - 1 share one pass over buf / dbuf (saunet_hip.h: layer pairs): the top chunk of layer l first -- it is what
+                # layer l - 1's conv2 data gradient reads -- then both layers' contributions to the channels below it
+                d.c_begin = d.Cin - growth
+                L.call("saunet_dense_layer_backward_conv1", C.byref(d), st)
+                fill(d_lo, l - 1)
+                L.call("saunet_dense_layer_backward_conv2", C.byref(d_lo), st)
+                L.call("saunet_dense_layer_backward_conv1_pair", C.byref(d), C.byref(d_lo), st)
+                l -= 2
+            else:
+                L.call("saunet_dense_layer_backward_conv1", C.byref(d), st)
+                l -= 1
         L.call("saunet_dense_bn1_grads", C.byref(bl), st)
         pend = [] if DENSE_WGRAD_BATCH_REDUCE else None
         for plist, slot, ks, pd in ((wg2, 5, 3, 1), (wg1, 2, 1, 0)):

@@ -63,7 +63,7 @@ class WgradGroup(C.Structure):
 
 class DenseLayerBwd(C.Structure):
     """saunet_dense_layer_bwd"""
-    _fields_ = [(n, C.c_int32) for n in "N H W Cin Ctot reserved".split()] + [
+    _fields_ = [(n, C.c_int32) for n in "N H W Cin Ctot c_begin".split()] + [
         ("buf", C.c_void_p), ("dbuf", C.c_void_p), ("xhat", C.c_void_p), ("ld_xhat", C.c_int32), ("reserved2", C.c_int32),
         ("ab", C.c_void_p), ("ab_replicas", C.c_int32), ("ab_rstride", C.c_int32), ("count", C.c_double),
         ("z1", C.c_void_p), ("g", C.c_void_p), ("dz1", C.c_void_p), ("dz2", C.c_void_p), ("w2_dgrad", C.c_void_p), ("w1_dgrad", C.c_void_p),
@@ -118,6 +118,8 @@ _SIGS = {
     "saunet_bn_backward_coeff_correct": [i32, i32, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp, vp, i64, vp],
     "saunet_dense_layer_backward_conv2": [C.POINTER(DenseLayerBwd), vp],
     "saunet_dense_layer_backward_conv1": [C.POINTER(DenseLayerBwd), vp],
+    "saunet_dense_layer_backward_pair_supported": [C.POINTER(DenseLayerBwd)],
+    "saunet_dense_layer_backward_conv1_pair": [C.POINTER(DenseLayerBwd), C.POINTER(DenseLayerBwd), vp],
     "saunet_bn_backward_correct_ab": [i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, f64, vp, vp, i64, i32, vp],
     "saunet_dense_bn1_grads": [C.POINTER(DenseBn1List), vp],
     "saunet_bn_backward_coeff_ab": [i32, vp, i32, i32, vp, vp, i32, vp, vp, vp],

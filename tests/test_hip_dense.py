@@ -247,6 +247,62 @@ def test_fused_layer_backward_matches_the_four_launch_backward(layers, cin, shap
         assert e_f < max(1.5 * e_u, 2e-2), (k, e_f, e_u)
 
 
+@pytest.mark.parametrize("layers,cin,shape", [(5, 64, (8, 64, 64)),        # pairs (4, 3) and (2, 1), layer 0 alone; Cin_hi % 64 == 0 and == 32
+                                              (4, 96, (6, 64, 64)),        # exactly 192 tiles of 128 pixels: the smallest supported map
+                                              (4, 64, (7, 60, 60))])       # ragged: 25 200 pixels (a partial last tile), map off the 16-pixel grid
+def test_layer_pairs_match_the_per_layer_fused_backward(layers, cin, shape):
+    """Round 5: two consecutive layers add their conv1 data gradients to the block's gradient buffer in one pass
+    (saunet_dense_layer_backward_conv1 with a channel window + saunet_dense_layer_backward_conv1_pair) against the per-layer sequence on the
+    same bf16 block.  The pair rounds the buffer to bf16 once where the sequence rounds twice, so the two agree to that rounding; both are held
+    to float64 (torchvision _DenseLayer backward, /root/reference/models/models.py:306-313)."""
+    import ctypes as C
+    import saunet_amd as S
+    HF = S.functional
+    torch.manual_seed(5 + layers)
+    n, h, w = shape
+    dtype = torch.bfloat16
+    block = S.modules._DenseBlock(layers, cin).cuda().train()
+    with torch.no_grad():
+        for m in block.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(4.0, 6.0)       # away from the ReLU kink: no mask flips between the runs
+    d = S.lib.DenseLayerBwd(); d.N, d.H, d.W, d.Cin, d.Ctot = n, h, w, cin + 32 * (layers - 1), cin + 32 * layers
+    assert S.lib.load().saunet_dense_layer_backward_pair_supported(C.byref(d)) == 1       # the geometry really runs the pair kernel
+    x0 = torch.randn(n, cin, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    cot, grads = None, {}
+    assert HF.DENSE_BWD_PAIRS is True and HF.DENSE_BWD_FUSED is True
+    try:
+        for pairs in (True, False):
+            HF.DENSE_BWD_PAIRS = pairs
+            block.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            y = block(x)
+            if cot is None:
+                cot = torch.randn(y.shape, device="cuda").to(dtype)
+            entries, orig = [], S.lib.call
+            S.lib.call = lambda name, *args: (entries.append(name), orig(name, *args))[1]
+            try:
+                (y.float() * cot.float()).sum().backward()
+            finally:
+                S.lib.call = orig
+            assert ("saunet_dense_layer_backward_conv1_pair" in entries) == pairs and entries.count("saunet_dense_layer_backward_conv2") == layers
+            assert entries.count("saunet_dense_layer_backward_conv1_pair") == (layers // 2 if pairs else 0)
+            grads[pairs] = {"x": x.grad.float().clone(), **{k: v.grad.float().clone() for k, v in block.named_parameters()}}
+    finally:
+        HF.DENSE_BWD_PAIRS = True
+    ry, xr, prm = ref_block(block, x0)
+    (ry * cot.double()).sum().backward()
+    ref = {"x": xr.grad, **{k: prm[k].grad for k in prm}}
+    for k in grads[True]:
+        e_p, e_s, e_ps = rel_l2(grads[True][k], ref[k]), rel_l2(grads[False][k], ref[k]), rel_l2(grads[True][k], grads[False][k])
+        if k.endswith("conv2.weight") or k.endswith("norm2.bias") or k.endswith("norm1.bias"):
+            # rounding residue of analytically cancelling pixel sums in this all-units-on regime: bounded, not gated (see the test above)
+            assert e_p < max(0.5, 2.0 * e_s), (k, e_p, e_s)
+            continue
+        assert e_ps < max(2e-2, 2.0 * e_s), (k, e_ps, e_s)
+        assert e_p < max(1.5 * e_s, 2e-2), (k, e_p, e_s)
+
+
 @pytest.mark.parametrize("n,h,w,cin,c_lo", [(8, 16, 16, 512, 480),      # block-4 geometry in small: 64-pixel tiles
                                             (2, 16, 16, 288, 256),      # Cin % 64 == 32: the last stage reads past Cin and must contribute exact zeros
                                             (32, 32, 32, 352, 320),     # 32768 pixels: 128-pixel tiles
