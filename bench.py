@@ -230,7 +230,13 @@ def _call_work(name, args, esz):
         return (P * (chunk + 128 + 128) + 9 * 32 * 128) * esz, 2.0 * P * 288 * 128
     if name == "saunet_dense_layer_backward_conv1":
         l = obj(args[0]); P = l.N * l.H * l.W
-        return (P * (3 * 128 + 3 * l.Cin) + 128 * l.Cin) * esz, 2.0 * P * 128 * l.Cin
+        cw = l.Cin - l.c_begin                                   # a layer pair's first launch touches the top chunk only
+        return (P * (3 * 128 + 3 * cw) + 128 * cw) * esz, 2.0 * P * 128 * cw
+    if name == "saunet_dense_layer_backward_conv1_pair":
+        # G, z1 of the lower layer read, its dz1 written, the upper layer's dz1 read; x read, dbuf read + written over the lower layer's channels;
+        # both layers' weight rows of those channels
+        lo = obj(args[1]); P = lo.N * lo.H * lo.W
+        return (P * (4 * 128 + 3 * lo.Cin) + 2 * 128 * lo.Cin) * esz, 2.0 * P * 128 * lo.Cin * 2
     if name == "saunet_bn_backward_apply":
         P, Cc = args[24], args[25]
         return P * Cc * esz * (3 + (1 if args[17] else 0) + (1 if args[5] else 0) + (1 if args[20] else 0)), 0.0

@@ -21,8 +21,8 @@ python scripts/mm_micro.py all > $O/micro_mm.txt 2>&1
 python scripts/convt_wgrad_micro.py > $O/micro_convt_wgrad.txt 2>&1
 python scripts/gate_micro.py > $O/micro_gate.txt 2>&1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d /tmp/gatep -o g -- python $R/scripts/gate_micro.py 5 > /dev/null 2>&1; python $R/scripts/prof_summary.py /tmp/gatep/g_results.db 1 | grep -E "gate|calls" ) >> $O/micro_gate.txt 2>&1
-( export SAUNET_HIP_LIB=scripts/_ab/libsaunet_timing.so; for c in conv2fwd conv2wgrad conv1wgrad dec3wgrad conv1dgrad conv1dgrad3 conv2dgrad conv2dgrad3 dec3mm dec5mm conv1fwd conv1fwd3 conv1small3 conv1small4 conv1dgrad3 conv1dgrad4 conv2dgrad3 conv2dgrad4 conv2fwd3 conv2fwd4; do python scripts/phase_timing.py $c 2>&1 | grep -v amdgpu.ids; done ) > $O/phase_timing.txt
-for b in 1 2 3 4; do python scripts/dense_chain_micro.py $b 2>&1 | grep -v amdgpu.ids; SAUNET_DENSE_BWD_FUSED=0 python scripts/dense_chain_micro.py $b 2>&1 | grep -v amdgpu.ids; done > $O/dense_chain.txt
+( export SAUNET_HIP_LIB=scripts/_ab/libsaunet_timing.so; for c in conv2fwd conv2wgrad conv1wgrad dec3wgrad conv1dgrad conv1dgrad3 conv2dgrad conv2dgrad3 dec3mm dec5mm conv1fwd conv1fwd3 conv1small3 conv1small4 conv1dgrad3 conv1dgrad4 conv2dgrad3 conv2dgrad4 conv2fwd3 conv2fwd4 k4lds3 k4lds4 k4pair3 k4pair2; do python scripts/phase_timing.py $c 2>&1 | grep -v amdgpu.ids; done ) > $O/phase_timing.txt
+for b in 1 2 3 4; do python scripts/dense_chain_micro.py $b 2>&1 | grep -v amdgpu.ids; ( echo -n "[layer pairs off] "; SAUNET_DENSE_BWD_PAIRS=0 python scripts/dense_chain_micro.py $b 2>&1 | grep -v amdgpu.ids | tail -1 ); SAUNET_DENSE_BWD_FUSED=0 python scripts/dense_chain_micro.py $b 2>&1 | grep -v amdgpu.ids; done > $O/dense_chain.txt
 python scripts/census_table.py 2>&1 | grep -v amdgpu.ids > $O/census_table.txt
 python bench.py --gpus 2 --share-gpu --steps 5 --warmup 2 --no-cpu-baseline 2>> $O/bench.err | grep "^{" > $O/bench_rehearsal_2ranks.json
 bash scripts/mfma_table.sh > $O/mfma_table.log 2>&1; cp gpurun_out/mfma_table.txt $O/mfma_table.txt

@@ -78,6 +78,24 @@ elif case in ("k4lds3", "k4lds4"):
     d.sums1, d.sums1_replicas, d.sums1_rstride = s1.data_ptr(), s1.shape[0], s1.stride(0)
     d.dgamma2, d.dbeta2 = dgb[0].data_ptr(), dgb[1].data_ptr()
     run = lambda: L.call("saunet_dense_layer_backward_conv1", C.byref(d), L.stream())
+elif case in ("k3corr1", "k3corr2"):
+    unit = "dense_dgrad"
+    import ctypes as C
+    cin, ctot, h = {"k3corr1": (160, 256, 128), "k3corr2": (320, 512, 64)}[case]
+    L = S.lib
+    buf = act(ctot, h); dbuf = act(ctot, h); g = act(128, h); z1 = act(128, h); dz2 = act(32, h)
+    xh = torch.rand(5, ctot, device="cuda"); ab = torch.randn(HF.STAT_R, 2, ctot, dtype=torch.float64, device="cuda")
+    w2 = torch.nn.Parameter(torch.randn(32, 128, 3, 3, device="cuda") * 0.05)
+    p2 = HF.BNParams(128, "cuda"); p2.buf[0].uniform_(0.5, 1.5); p2.buf[1].normal_(0, 0.3); p2.buf[2].normal_(0, 0.3); p2.buf[3].uniform_(0.5, 1.5)
+    s2 = torch.zeros(HF.STAT_R, 2, 128, dtype=torch.float64, device="cuda")
+    w2p = HF.PACKS.get(w2, L.PACK_DGRAD, dt)
+    d = L.DenseLayerBwd()
+    d.N, d.H, d.W, d.Cin, d.Ctot = n, h, h, cin, ctot
+    d.buf, d.dbuf, d.xhat, d.ld_xhat = buf.data_ptr(), dbuf.data_ptr(), xh.data_ptr(), xh.stride(0)
+    d.ab, d.ab_replicas, d.ab_rstride, d.count = ab.data_ptr(), ab.shape[0], ab.stride(0), float(n * h * h)
+    d.z1, d.g, d.dz2, d.w2_dgrad, d.p2 = z1.data_ptr(), g.data_ptr(), dz2.data_ptr(), w2p.data_ptr(), p2.buf.data_ptr()
+    d.sums2, d.sums2_replicas, d.sums2_rstride = s2.data_ptr(), s2.shape[0], s2.stride(0)
+    run = lambda: L.call("saunet_dense_layer_backward_conv2", C.byref(d), L.stream())
 elif case in ("k4pair3", "k4pair2"):
     unit = "dense_dgrad"
     import ctypes as C

@@ -1458,6 +1458,8 @@ int saunet_dense_layer_backward_conv2(const saunet_dense_layer_bwd* l, void* str
     }
     const double* ab = l->ab + l->Cin;
     if (dense_dgrad3_halo(l->N, l->H, l->W)) {     // large maps: a streaming correction pass into dz2, then the LDS-DMA staged kernel over dz2
+        // (the correction folded into the halo buffer of a non-transposed form of that kernel was built and measured slower: registers --
+        // scripts/probes/dense_dgrad3_halo2_rejected.hip)
         if (int rc = bn_backward_correct_ab(SAUNET_BF16, chunk, l->Ctot, (const u16*)l->buf + l->Cin, l->Ctot, l->dz2, 32, ab, l->ab_replicas, l->ab_rstride,
                                             l->Ctot, l->count, l->xhat + l->Cin, l->xhat + l->ld_xhat + l->Cin, P, 32, st)) return rc;
         a.g = (const u16*)l->dz2; a.ldg = 32;

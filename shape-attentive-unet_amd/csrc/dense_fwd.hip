@@ -202,10 +202,11 @@ __global__ __launch_bounds__(512) void dense_conv1_fwd_kernel(DenseFwdArgs a)
 bool dense_conv1_small_supported(const saunet_conv_desc* d, const void* x, const void* w, const void* y, const float* bias)
 {
     static const bool on = ab_env_on("SAUNET_DENSE_CONV1_SMALL");       // A/B switch (variant builds only)
+    static const long maxtiles = ab_env_int("SAUNET_DENSE_CONV1_MAXTILES", 384);
     const long P = (long)d->N * d->H * d->W;
     return on && d->dtype == SAUNET_BF16 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->transposed && d->Cout == DF_BN &&
            d->Cin % 32 == 0 && d->Cin >= 128 && d->Cin <= 4096 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->ldx >= ((d->Cin + 63) & ~63) &&
-           bias == nullptr && !d->epi_relu && (P + 127) / 128 < 384 && P >= 64 && P < (1L << 30) &&
+           bias == nullptr && !d->epi_relu && (P + 127) / 128 < maxtiles && P >= 64 && P < (1L << 30) &&
            !(((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15);
 }
 
