@@ -311,10 +311,14 @@ def live_kernel_census(S, step_fn, dtype):
             continue
         sym, inc = _main_symbol(log)
         ms = e0.elapsed_time(e1)
-        r = out.setdefault(sym, {"ms": 0.0, "launches": 0, "algorithmic_bytes": 0.0, "flops": 0.0, "priced_ms": 0.0, "includes": set()})
+        r = out.setdefault(sym, {"ms": 0.0, "launches": 0, "algorithmic_bytes": 0.0, "flops": 0.0, "priced_ms": 0.0, "roof_ms": 0.0, "includes": set()})
         r["ms"] += ms; r["launches"] += 1; r["includes"].update(inc)
         if work is not None:
             r["algorithmic_bytes"] += work[0]; r["flops"] += work[1]; r["priced_ms"] += ms
+            # the launch's own roofline time: whichever of the two bounds is the longer for THIS geometry (a family mixes HBM-bound and
+            # matrix-bound launches; its aggregate flop/byte would price all of them against one peak)
+            peak_tf = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
+            r["roof_ms"] += max(work[0] / (HBM_PEAK_GBS * 1e9), work[1] / (peak_tf * 1e12)) * 1e3
     return out
 
 
@@ -374,6 +378,9 @@ def census_roofline(S, step_fn, dtype, args):
         # bytes are known for the priced calls only: the rate is taken over THEIR time (ms stays the whole symbol's time)
         e = _roofline_entry(label, pms if pms > 0 else ms, n, by, fl, dtype)
         e["ms"] = round(ms, 4)
+        roof = sum(census[s_]["roof_ms"] for s_ in symbols if s_ in census)
+        # sum over the launches of max(bytes / HBM peak, FLOPs / MFMA peak) over their measured time: the per-launch roofline fraction
+        e["frac_per_launch_bound"] = round(roof / pms, 4) if pms > 0 else None
         e["priced_fraction_of_ms"] = round(pms / ms, 3) if ms > 0 else None
         e["rocprof_ms_per_step"] = round(rocprof_us / 1e3, 4) if rocprof_us is not None else None
         tr = [pmc[s_]["traffic_bytes_per_step"] for s_ in symbols if s_ in pmc]

@@ -120,10 +120,12 @@ def test_grouped_weight_gradients_refuse_untiled_maps():
 
 
 
-@pytest.mark.parametrize("shape,relu", [((4, 128, 128), True), ((8, 64, 128), True), ((16, 64, 64), False), ((2, 32, 32), True)])
+@pytest.mark.parametrize("shape,relu", [((4, 128, 128), True), ((8, 64, 128), True), ((16, 64, 64), False), ((2, 32, 32), True),
+                                        ((3, 10, 10), True), ((1, 7, 9), False),          # ragged: 300 / 63 pixels, a partial last 32-pixel run
+                                        ((40, 50, 50), True)])                            # 100 000 pixels, off the 16-pixel grid and above 2048 runs: the per-wave kernel
 def test_conv2_data_gradient_with_norm2_reduction_matches_float64(shape, relu):
-    """dense_dgrad3_kernel, both tilings (csrc/dense_dgrad.hip): maps with >= 256 16 x 16 tiles take the LDS-DMA halo variant, the last
-    case the per-wave one.  dz1 = mask * conv_transpose(dz2 chunk, w) out of a channel slice of the block buffer, plus the two BatchNorm
+    """The three conv2 data-gradient kernels (csrc/dense_dgrad.hip): maps with >= 256 16 x 16 tiles take the LDS-DMA halo variant, maps of at
+    most 2048 runs of 32 pixels the channel-wave kernel (dense_dgrad3_cw_kernel: (2, 32, 32) and the ragged cases), the rest the per-wave one.  dz1 = mask * conv_transpose(dz2 chunk, w) out of a channel slice of the block buffer, plus the two BatchNorm
     backward sums of norm2, against float64 on the bf16-rounded operands (/root/reference/models/models.py:35-41)."""
     import saunet_amd as S
     H = S.functional
