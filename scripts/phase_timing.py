@@ -16,6 +16,14 @@ if case in ("conv2fwd", "conv2fwd3", "conv2fwd4"):
     sc = torch.rand(128, device="cuda") + 0.5; sh = torch.randn(128, device="cuda") * 0.1
     out = HF.new_act(n, 32, hh, hh, dt, "cuda"); st = torch.zeros(HF.STAT_R, 2, 32, dtype=torch.float64, device="cuda")
     run = lambda: HF.conv_forward_raw(x, w, None, 1, 1, pro=(sc, sh, True), out=out, stats=st)
+elif case in ("conv2fwdbn1", "conv2fwdbn2"):
+    unit = "dense_fwd"
+    hh = {"conv2fwdbn1": 128, "conv2fwdbn2": 64}[case]
+    z1 = act(128, hh); w = torch.nn.Parameter(torch.randn(32, 128, 3, 3, device="cuda") * 0.03)
+    gamma = torch.rand(128, device="cuda") + 0.5; beta = torch.randn(128, device="cuda") * 0.1
+    st2 = HF.bn_stats(z1); buf = HF.new_act(n, 96, hh, hh, dt, "cuda"); params = HF.BNParams(128, "cuda")
+    rm, rv = torch.zeros(128, device="cuda"), torch.ones(128, device="cuda"); st_out = HF.new_stats(96, "cuda")
+    run = lambda: HF.conv_forward_bnpro(z1, w, 1, 1, st2, n * hh * hh, 0, None, gamma, beta, rm, rv, 0.1, 1e-5, params.buf, out=buf[:, 32:64], stats=st_out[:, :, 32:64])
 elif case in ("conv2wgrad", "conv1wgrad", "dec3wgrad"):
     cin, h, cout, k = {"conv2wgrad": (128, 128, 32, 3), "conv1wgrad": (192, 128, 128, 1), "dec3wgrad": (512, 64, 128, 3)}[case]
     x = act(cin, h); dy = act(cout, h); w = torch.nn.Parameter(torch.randn(cout, cin, k, k, device="cuda") * 0.03)
