@@ -103,6 +103,43 @@ def test_forward_workspace_query(lib):
     assert handle.saunet_conv2d_forward_workspace(C.byref(desc(2, 8, 1024, 512))) == 0                                # N % 4 != 0: not cell mode
 
 
+def test_dense_layer_pair_queries_and_argument_checks(lib):
+    """saunet_dense_layer_backward_pair_supported is host logic (no device call): 1 only where the LDS-staged kernels run with at least 192
+    tiles of 128 pixels and a lower layer of at least 64 channels (SAUNET_BAD_SHAPE = -1 otherwise); saunet_dense_layer_backward_conv1_pair / _conv1 reject what is not a pair of
+    consecutive layers of one block, or a bad channel window, with a status code and a message -- before any launch."""
+    import ctypes as C
+    handle = lib.load()
+
+    def desc(n, h, w, cin, ctot, base=0x10000):
+        d = lib.DenseLayerBwd()
+        d.N, d.H, d.W, d.Cin, d.Ctot, d.c_begin = n, h, w, cin, ctot, 0
+        for i, f in enumerate(("buf", "dbuf", "xhat", "ab", "z1", "g", "dz1", "dz2", "w2_dgrad", "w1_dgrad", "p1", "p2", "sums2", "sums1", "dgamma2", "dbeta2")):
+            setattr(d, f, base + 0x1000 * i)             # never dereferenced: every call below fails its argument checks first
+        d.ld_xhat, d.ab_replicas, d.ab_rstride, d.count = ctot, 16, 2 * ctot, float(n * h * w)
+        d.sums2_replicas, d.sums2_rstride, d.sums1_replicas, d.sums1_rstride = 16, 256, 16, 2 * cin
+        return d
+
+    q = handle.saunet_dense_layer_backward_pair_supported
+    assert q(C.byref(desc(32, 32, 32, 640, 1024))) == 1          # block 3 of the bench geometry: 256 tiles
+    assert q(C.byref(desc(32, 64, 64, 320, 512))) == 1           # block 2: 1024 tiles, the largest map the LDS-staged kernel takes
+    assert q(C.byref(desc(32, 128, 128, 160, 256))) == 0         # block 1: the transposed kernel's range
+    assert q(C.byref(desc(32, 16, 16, 768, 1024))) == 0          # block 4: 64 tiles -- the steps are split over workgroups instead
+    assert q(C.byref(desc(6, 64, 64, 96, 256))) == 1 and q(C.byref(desc(6, 64, 64, 64, 256))) == 0     # the lower layer needs one 64-channel step
+    assert q(None) == 0
+    hi, lo = desc(32, 32, 32, 640, 1024), desc(32, 32, 32, 608, 1024)
+    bad = desc(32, 32, 32, 576, 1024)                              # not the layer below hi
+    assert handle.saunet_dense_layer_backward_conv1_pair(C.byref(hi), C.byref(bad), None) == -1
+    assert b"consecutive layers" in handle.saunet_last_error()
+    other = desc(32, 32, 32, 608, 1024, base=0x900000)             # right size, another block's buffers
+    assert handle.saunet_dense_layer_backward_conv1_pair(C.byref(hi), C.byref(other), None) == -1
+    small_hi, small_lo = desc(32, 16, 16, 640, 1024), desc(32, 16, 16, 608, 1024)
+    assert handle.saunet_dense_layer_backward_conv1_pair(C.byref(small_hi), C.byref(small_lo), None) == -1      # unsupported geometry: refused, not approximated
+    hi.c_begin = 100                                               # windows start on 32-channel chunks
+    assert handle.saunet_dense_layer_backward_conv1(C.byref(hi), None) == -1
+    assert b"channel window" in handle.saunet_last_error()
+    del lo
+
+
 def test_ctypes_structs_match_the_header_layout(tmp_path):
     """the host mirror's ctypes structures against the C compiler's view of include/saunet_hip.h (sizes and the offsets of the last fields): a field
     added on one side only would shift every later pointer silently"""
