@@ -1263,48 +1263,55 @@ __global__ __launch_bounds__(512) void dense_conv1_dgrad_pair_kernel(DenseDgradP
         TSTAMP(97);
         // layer l's product (matrix pipe) runs under layer l - 1's half of the epilogue (vector pipe): the two waves of a SIMD are in the same
         // phase (one barrier per step), so the overlap has to be in the instruction stream
+        // Two pixels per instruction: v_pk_fma_f32 / v_pk_add_f32 on register pairs (the accumulator rows r, r + 1 are consecutive pixels of the
+        // lane's channel) -- 23 vector instructions per pixel pair instead of 34; with two waves per SIMD in the same phase the epilogue's
+        // issue time is the stage's longest part.
+        typedef float f2 __attribute__((ext_vector_type(2)));
         const bool cok = j * LY::BN + col < a.Cin;
-        float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
-        float D1[16], xf[16];
+        f2 s1a = {0.f, 0.f}, s2a = {0.f, 0.f}, s1b = {0.f, 0.f}, s2b = {0.f, 0.f};
+        f2 D1[8], xf[8];
+        const f2 vsc1 = {sc1, sc1}, vsh1 = {sh1, sh1}, vx1 = {x1, x1}, vo1 = {o1, o1}, vsc2 = {sc2, sc2}, vsh2 = {sh2, sh2}, vx2 = {x2, x2}, vo2 = {o2, o2};
         u32x4 bf2[8];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) bf2[ks] = *(const u32x4*)(sw2 + dgl_off(wn * 32 + lr, 2 * ks + lh));
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af2[ks]), __builtin_bit_cast(bf16x8_t, bf2[ks]), acc2, 0, 0, 0);
-#pragma unroll
-            for (int r = 2 * ks; r < 2 * ks + 2; ++r) {
-                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                xf[r] = __uint_as_float((unsigned)xs[r] << 16);
-                const int ok = (int)cok & (int)(m0 + row < P);
-                D1[r] = (ok & (int)(fmaf(xf[r], sc1, sh1) > 0.f)) ? acc1[r] : 0.f;
-                s1a += D1[r]; s2a = fmaf(D1[r], fmaf(xf[r], x1, o1), s2a);
-            }
+            const int r = 2 * ks, row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;        // rows r and r + 1 are pixels row, row + 1
+            xf[ks] = f2{__uint_as_float((unsigned)xs[r] << 16), __uint_as_float((unsigned)xs[r + 1] << 16)};
+            const f2 t = __builtin_elementwise_fma(xf[ks], vsc1, vsh1);
+            const int ok0 = (int)cok & (int)(m0 + row < P), ok1 = (int)cok & (int)(m0 + row + 1 < P);
+            D1[ks] = f2{(ok0 & (int)(t[0] > 0.f)) ? acc1[r] : 0.f, (ok1 & (int)(t[1] > 0.f)) ? acc1[r + 1] : 0.f};
+            s1a += D1[ks]; s2a = __builtin_elementwise_fma(D1[ks], __builtin_elementwise_fma(xf[ks], vx1, vo1), s2a);
         }
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float yf = __uint_as_float((unsigned)ys[r] << 16);
-            const int ok = (int)cok & (int)(m0 + row < P);
-            const float D2 = (ok & (int)(fmaf(xf[r], sc2, sh2) > 0.f)) ? acc2[r] : 0.f;
-            s1b += D2; s2b = fmaf(D2, fmaf(xf[r], x2, o2), s2b);
+        for (int ks = 0; ks < 8; ++ks) {
+            const int r = 2 * ks, row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const f2 yf = {__uint_as_float((unsigned)ys[r] << 16), __uint_as_float((unsigned)ys[r + 1] << 16)};
+            const f2 t = __builtin_elementwise_fma(xf[ks], vsc2, vsh2);
+            const int ok0 = (int)cok & (int)(m0 + row < P), ok1 = (int)cok & (int)(m0 + row + 1 < P);
+            const f2 D2 = {(ok0 & (int)(t[0] > 0.f)) ? acc2[r] : 0.f, (ok1 & (int)(t[1] > 0.f)) ? acc2[r + 1] : 0.f};
+            s1b += D2; s2b = __builtin_elementwise_fma(D2, __builtin_elementwise_fma(xf[ks], vx2, vo2), s2b);
             // the later layer first: the order its own launch would have added them in
-            out[r] = __builtin_bit_cast(u16, (__bf16)fmaf(sc1, D1[r], fmaf(sc2, D2, yf)));
+            const f2 o = __builtin_elementwise_fma(vsc1, D1[ks], __builtin_elementwise_fma(vsc2, D2, yf));
+            const unsigned pk = pack_bf16x2(o[0], o[1]);
+            out[r] = (u16)pk; out[r + 1] = (u16)(pk >> 16);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             *(u16*)(sy + row * 128 + col * 2) = out[r];
         }
-        s1a += __shfl_xor(s1a, 32, 64); s2a += __shfl_xor(s2a, 32, 64); s1b += __shfl_xor(s1b, 32, 64); s2b += __shfl_xor(s2b, 32, 64);
+        float t1a = s1a[0] + s1a[1], t2a = s2a[0] + s2a[1], t1b = s1b[0] + s1b[1], t2b = s2b[0] + s2b[1];
+        t1a += __shfl_xor(t1a, 32, 64); t2a += __shfl_xor(t2a, 32, 64); t1b += __shfl_xor(t1b, 32, 64); t2b += __shfl_xor(t2b, 32, 64);
         if (lh == 0) {
             float* sp = s_part + (j % LY::MAX_STEPS) * LY::PART_STEP + wm * 128;
-            sp[col] = s1a; sp[64 + col] = s2a; sp[512 + col] = s1b; sp[512 + 64 + col] = s2b;
+            sp[col] = t1a; sp[64 + col] = t2a; sp[512 + col] = t1b; sp[512 + 64 + col] = t2b;
         }
         TSTAMP(98);
 #pragma unroll
