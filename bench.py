@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--dry-run", action="store_true", help="host-side rehearsal of the N>1 path WITHOUT a GPU (gloo): real SAUNet parameter set, "
                     "synthetic gradients, bucketed all-reduce overlapped with the backward hooks, timing protocol and JSON line; no kernel runs")
+    ap.add_argument("--rehearsal-roofline", action="store_true", help="with --share-gpu: keep the live roofline census (a COLLECTIVE step on every rank) in the rehearsal")
     ap.add_argument("--share-gpu", action="store_true", help="REHEARSAL of the N>1 path on a 1-GPU box: the N ranks run the real HIP step on the SAME GPU and "
                     "exchange gradients / SyncBN statistics over gloo (SAUNET_SHARE_GPU=1, SAUNET_DIST_BACKEND=gloo): real kernels, real bucket / hook / "
                     "overlap logic and the bench's own timing protocol; the line is marked `rehearsal` and carries no multi-GPU `value`")
@@ -318,7 +319,10 @@ def live_kernel_census(S, step_fn, dtype):
             # the launch's own roofline time: whichever of the two bounds is the longer for THIS geometry (a family mixes HBM-bound and
             # matrix-bound launches; its aggregate flop/byte would price all of them against one peak)
             peak_tf = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
-            r["roof_ms"] += max(work[0] / (HBM_PEAK_GBS * 1e9), work[1] / (peak_tf * 1e12)) * 1e3
+            t_hbm, t_mfma = work[0] / (HBM_PEAK_GBS * 1e9), work[1] / (peak_tf * 1e12)
+            r["roof_ms"] += max(t_hbm, t_mfma) * 1e3
+            bb = r.setdefault("by_bound", {}).setdefault("hbm" if t_hbm >= t_mfma else "mfma", [0.0, 0, 0.0, 0.0])
+            bb[0] += ms; bb[1] += 1; bb[2] += work[0]; bb[3] += work[1]
     return out
 
 
@@ -383,6 +387,24 @@ def census_roofline(S, step_fn, dtype, args):
         e["frac_per_launch_bound"] = round(roof / pms, 4) if pms > 0 else None
         e["priced_fraction_of_ms"] = round(pms / ms, 3) if ms > 0 else None
         e["rocprof_ms_per_step"] = round(rocprof_us / 1e3, 4) if rocprof_us is not None else None
+        # the same launches split by THEIR OWN bound: a family that mixes HBM-bound and matrix-bound geometries is
+        # priced twice, each part against the peak that bounds it
+        split = {}
+        for s_ in symbols:
+            for bnd, (bms, bn, bby, bfl) in census.get(s_, {}).get("by_bound", {}).items():
+                a = split.setdefault(bnd, [0.0, 0, 0.0, 0.0]); a[0] += bms; a[1] += bn; a[2] += bby; a[3] += bfl
+        if split:
+            peak_tf_ = MFMA_BF16_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS
+            e["by_bound"] = {}
+            for bnd, (bms, bn, bby, bfl) in split.items():
+                if bms <= 0:
+                    continue
+                if bnd == "hbm":
+                    e["by_bound"]["hbm"] = {"launches": bn, "ms": round(bms, 4), "achieved": round(bby / (bms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                            "unit": "GB/s", "frac": round(bby / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                else:
+                    e["by_bound"]["mfma"] = {"launches": bn, "ms": round(bms, 4), "achieved": round(bfl / (bms * 1e-3) / 1e12, 1), "peak": peak_tf_,
+                                             "unit": "TFLOP/s", "frac": round(bfl / (bms * 1e-3) / 1e12 / peak_tf_, 4)}
         tr = [pmc[s_]["traffic_bytes_per_step"] for s_ in symbols if s_ in pmc]
         e["traffic"] = int(sum(tr)) if tr else None
         if inc:
@@ -530,8 +552,28 @@ def cpu_baseline(size):
                 sd[k].grad = None
             ts.append(time.time() - t0)
         sweep[t] = round(min(ts[1:]), 4)
-        if sweep[t] > 4.0 and len(sweep) > 1:      # far off the optimum already: stop burning the budget
+        if sweep[t] > 4.0 and len(sweep) > 1:      # far off the optimum already: stop burning the budget (the all-cores point is taken below)
             break
+    if phys not in sweep and phys <= 256:
+        # SURVEY 8(d) asks for ALL physical cores: that point is always on the line next to the fastest setting (one warm-up + one timed
+        # forward + backward at B = 2: with one thread per core the small-channel layers spend their time in thread wake-ups)
+        torch.set_num_threads(phys)
+        sd = Wt.make_state_dict(spec, 0)
+        for k in keys:
+            sd[k].requires_grad_(True)
+        img, seg, edge = Wt.synthetic_batch(2, size, size)
+        canny = R.canny_branch(img)
+        ts = []
+        for it in range(2):
+            t0 = time.time()
+            loss, *_ = R.segmentation_step(sd, img, seg, edge, True, canny=canny)
+            loss.backward()
+            for k in keys:
+                sd[k].grad = None
+            ts.append(time.time() - t0)
+            if ts[-1] > 60.0:
+                break
+        sweep[phys] = round(ts[-1], 4)
     cores = min(sweep, key=sweep.get)
     torch.set_num_threads(cores)
     runs = []
@@ -556,6 +598,7 @@ def cpu_baseline(size):
         runs.append({"B": B, "s_per_iter": round(med, 4), "slices_per_s": round(B / med, 3), "warmup": min(warm, len(times) - len(steady)), "timed": len(steady)})
     best = max(runs, key=lambda r: r["slices_per_s"])
     return {"value": best["slices_per_s"], "unit": "slices/s", "cores": torch.get_num_threads(), "host_cpus": ncpu, "physical_cores": phys, "kind": "port",
+            "all_physical_cores": ({"threads": phys, "s_per_fwd_bwd_b2": sweep[phys], "slices_per_s": round(2.0 / sweep[phys], 3)} if phys in sweep else None),
             "runs": runs, "thread_sweep_s_per_fwd_bwd_b2": {str(k): v for k, v in sweep.items()},
             "sample": "oracle restatement (PyTorch CPU fp32) %dx%d, fwd+bwd+SGD, median s/iter: B=2 3 warm-up + 10 timed, B=8 1 + 4 (bounded); "
                       "%d intra-op threads (fastest of the sweep) on a host with %d physical cores / %d logical CPUs" % (size, size, torch.get_num_threads(), phys, ncpu)}
@@ -924,6 +967,19 @@ def main():
                 "replicas_identical": bool(torch.equal(lo, hi)), "physical_gpus": torch.cuda.device_count()}
     final_loss = float(loss.detach().float())
 
+    # The live census drives REAL training steps (SyncBN all-reduces, hook-launched bucket all-reduces, buckets.finish()): with N > 1 it is
+    # a collective operation, so EVERY rank runs it (rank 0 alone deadlocked the group); only rank 0's table is reported.
+    census_out = None
+    want_roofline = not args.no_roofline and (not (args.share_gpu and world > 1) or args.rehearsal_roofline)
+    if want_roofline and world > 1:
+        try:
+            census_out = census_roofline(S, eager_step, dtype, args)
+        except Exception as e:
+            import traceback
+            census_out = {"error": str(e)[:200], "where": traceback.format_exc()[-400:]}
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         slices = args.batch * world * args.steps / dt
@@ -945,10 +1001,12 @@ def main():
             out["rehearsal"] = "%d ranks share 1 GPU over gloo: real HIP step + bucketed all-reduce / SyncBN exchange under the bench's timing protocol; not a scaling measurement" % world
             out["rehearsal_slices_per_s"] = out["value"]
             out["value"] = None
-        if not args.no_roofline and not (args.share_gpu and world > 1):
+        if want_roofline:
             try:
                 # the dominant kernels of THIS round's committed profile, timed live over one real step's launch mix
-                out["roofline"] = census_roofline(S, eager_step, dtype, args)
+                out["roofline"] = census_out if census_out is not None else census_roofline(S, eager_step, dtype, args)
+                if "error" in out["roofline"]:
+                    raise RuntimeError(out["roofline"]["error"])
                 # round 1-4's headline kernel stays on the line as a fourth entry (one geometry + its 58-launch mix)
                 dd = kernel_roofline(S, dtype, args.batch, args.size, launch_mix=not args.no_launch_mix)
                 dd["traffic"] = pmc_traffic(dd["kernel"])

@@ -55,6 +55,11 @@ typedef struct saunet_conv_desc {
 } saunet_conv_desc;
 
 const char* saunet_last_error(void);
+/* ABI version of the structs and entry points in this header.  History: 1 = rounds 1-4; 2 = round 5's layout (saunet_conv_desc grew
+ * `workspace` / `workspace_bytes`, the saunet_dense_layer_* entries) -- that round still answered 1; 3 = round 6.  A caller built
+ * against another header must refuse to run:  if (saunet_version() != SAUNET_ABI_VERSION) abort();  -- the library reads every descriptor
+ * field of ITS header, a shorter struct from an older header would be read past its end. */
+#define SAUNET_ABI_VERSION 3
 int saunet_version(void);
 /* names of the kernels the calling thread's API calls have launched since the previous call of this function, joined by '+' (a name is the
  * kernel's symbol without "_kernel", e.g. "conv_igemm_fwd", "bn_bwd_correct_ab+dense_dgrad3"); thread-local, valid until the next call.
@@ -396,6 +401,16 @@ int saunet_dual_loss_backward(int dtype, const void* logits, int ldl, const void
 /* inference head (models/models.py:96-109 `softmax(pred, dim=1)`; train.py:47 argmax): prob [P][C] float32 (row stride ldp) and / or
  * label [P] int64 = first maximum; either output may be NULL.  C in {2, 4, 8}. */
 int saunet_softmax_argmax(int dtype, const void* logits, int ldl, int64_t pixels, int C, float* prob, int ldp, int64_t* label, void* stream);
+/* SegmentationModuleBase.pixel_acc(pred, label, num_class) (/root/reference/models/models.py:51-74) for a caller that holds a prediction tensor:
+ * pred = class scores of N x HW pixels, element (n, c, p) at pred[n*stride_n + c*stride_c + p*stride_p] (NCHW: HW*C, HW, 1; NHWC: HW*C, 1, C),
+ * kind 0 float32 / 1 bf16 / 2 int64 / 3 uint8; the class of a pixel is the FIRST maximum (torch.max).  label [N*HW] int64.
+ * counts: 2 + 3*(C-1) zero-initialised uint64 (exact integer counts: deterministic).  out[0] = acc over the pixels with label >= 1,
+ * out[c] = Jaccard of class c = 1 .. C-1, computed in float32 with the reference's +1e-10.  C <= 16. */
+int saunet_pixel_metrics(int kind, const void* pred, int64_t stride_n, int64_t stride_c, int64_t stride_p, const int64_t* label, int64_t N, int64_t HW,
+                         int C, void* counts, float* out, void* stream);
+/* SegmentationModuleBase.jaccard(pred, label) (models/models.py:76-78): sum(long(pred) & label) / (sum(pred) + sum(label) - sum(long(pred) & label)) over n
+ * elements.  sums: 24 zero-initialised bytes (two int64 + one float64).  out[0] float32 (0/0 -> nan, like the reference). */
+int saunet_binary_jaccard(int kind, const void* pred, const int64_t* label, int64_t n, void* sums, float* out, void* stream);
 
 
 /* ---- Canny branch on device (models/models.py:359-363; replaces the host cv2.Canny round trip) --

@@ -18,7 +18,7 @@ for fold in (True, False):
     buf = buf0.clone().requires_grad_(True)
     st = HF.bn_stats(buf)
     if fold:
-        HF._FUSED_BLOCK_BUFS.add(buf.data_ptr())
+        st._saunet_fused_block = (buf.data_ptr(), float(trans.norm.eps))
     y = trans(buf, st)
     if cot is None:
         cot = torch.randn(y.shape, device="cuda").to(dt)

@@ -566,7 +566,7 @@ const char* saunet_launch_log(void)
     g_launches[g_launch_cur][0] = 0;
     return r;
 }
-int saunet_version(void) { return 1; }
+int saunet_version(void) { return SAUNET_ABI_VERSION; }
 
 int saunet_init(int device)
 {

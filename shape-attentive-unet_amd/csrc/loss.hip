@@ -174,6 +174,89 @@ __global__ __launch_bounds__(256) void softmax_argmax_generic_kernel(const T* __
     }
 }
 
+
+// ---- SegmentationModuleBase.pixel_acc / .jaccard with the reference's own signatures (/root/reference/models/models.py:51-78): a prediction
+// tensor and a label map in, ratios out.  Integer counts accumulate in 64-bit atomics (exact, hence order-independent and deterministic).
+// kind: 0 float32, 1 bf16, 2 int64, 3 uint8 / bool
+__device__ __forceinline__ float metric_load(const void* p, long i, int kind)
+{
+    if (kind == 0) return ((const float*)p)[i];
+    if (kind == 1) return Elem<u16>::load((const u16*)p + i);
+    if (kind == 2) return (float)((const int64_t*)p)[i];
+    return (float)((const unsigned char*)p)[i];
+}
+
+constexpr int METRIC_MAXC = 16;
+
+// counts: [0] sum valid * (argmax == label)  [1] sum valid  then per class c = 1 .. C-1: [2 + 3(c-1)] |P_c & Y_c|, [+1] |Y_c|, [+2] |P_c|
+__global__ __launch_bounds__(256) void pixel_metrics_kernel(const void* __restrict__ pred, int kind, long sn, long sc, long sp,
+                                                            const int64_t* __restrict__ label, long HW, long P, int C,
+                                                            unsigned long long* __restrict__ counts)
+{
+    unsigned cnt[2 + 3 * (METRIC_MAXC - 1)];
+    const int nc = 2 + 3 * (C - 1);
+#pragma unroll
+    for (int k = 0; k < 2 + 3 * (METRIC_MAXC - 1); ++k) cnt[k] = 0;
+    for (long p = blockIdx.x * 256L + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        const long n = p / HW, q = p - n * HW;
+        const long base = n * sn + q * sp;
+        float m = metric_load(pred, base, kind); int am = 0;
+        for (int c = 1; c < C; ++c) { const float z = metric_load(pred, base + c * sc, kind); if (z > m) { m = z; am = c; } }   // torch.max: first maximum
+        const long y = label[p];
+        if (y >= 1) { cnt[1] += 1; if (am == y) cnt[0] += 1; }
+#pragma unroll
+        for (int c = 1; c < METRIC_MAXC; ++c) {
+            if (c < C) {
+                const bool v = (y == c), h = (am == c);
+                cnt[2 + 3 * (c - 1)] += (v && h); cnt[3 + 3 * (c - 1)] += v; cnt[4 + 3 * (c - 1)] += h;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2 + 3 * (METRIC_MAXC - 1); ++k) {
+        if (k < nc) {
+            unsigned v = cnt[k];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counts[k], (unsigned long long)v);
+        }
+    }
+}
+
+__global__ void pixel_metrics_finalize_kernel(const unsigned long long* __restrict__ counts, int C, float* __restrict__ out)
+{
+    const int c = threadIdx.x;
+    if (c == 0) out[0] = (float)counts[0] / ((float)counts[1] + 1e-10f);
+    else if (c < C) {
+        const float anb = (float)counts[2 + 3 * (c - 1)];
+        const float j = anb / ((float)counts[3 + 3 * (c - 1)] + (float)counts[4 + 3 * (c - 1)] - anb + 1e-10f);
+        out[c] = j <= 1.f ? j : 0.f;
+    }
+}
+
+// sums: [0] sum (long(pred) & label)  [1] sum label  (int64);  psum: sum pred in float64 (the reference sums the ORIGINAL tensor)
+__global__ __launch_bounds__(256) void binary_jaccard_kernel(const void* __restrict__ pred, int kind, const int64_t* __restrict__ label, long n,
+                                                             long long* __restrict__ sums, double* __restrict__ psum)
+{
+    long long anb = 0, sl = 0; double sp = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float pv = metric_load(pred, i, kind);
+        const long long pl = kind == 2 ? (long long)((const int64_t*)pred)[i] : (long long)pv;      // .long(): truncation toward zero
+        const long long y = label[i];
+        anb += pl & y; sl += y; sp += kind == 2 ? (double)pl : (double)pv;
+    }
+    for (int o = 32; o > 0; o >>= 1) { anb += __shfl_xor(anb, o); sl += __shfl_xor(sl, o); sp += __shfl_xor(sp, o); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long*)&sums[0], (unsigned long long)anb); atomicAdd((unsigned long long*)&sums[1], (unsigned long long)sl);
+        atomicAdd(psum, sp);
+    }
+}
+
+__global__ void binary_jaccard_finalize_kernel(const long long* __restrict__ sums, const double* __restrict__ psum, float* __restrict__ out)
+{
+    const float anb = (float)sums[0];
+    out[0] = anb / ((float)psum[0] + (float)sums[1] - anb);
+}
+
 }  // namespace saunet
 
 using namespace saunet;
@@ -232,6 +315,34 @@ int saunet_softmax_argmax(int dtype, const void* logits, int ldl, int64_t pixels
 #undef SMT
 #undef SM
     SAUNET_CHECK_LAUNCH("softmax_argmax");
+    return SAUNET_OK;
+}
+
+int saunet_pixel_metrics(int kind, const void* pred, int64_t stride_n, int64_t stride_c, int64_t stride_p, const int64_t* label, int64_t N, int64_t HW,
+                         int C, void* counts, float* out, void* stream)
+{
+    if (C < 1 || C > METRIC_MAXC) return set_error(SAUNET_BAD_SHAPE, "pixel_metrics: %d classes (1 .. %d)", C, METRIC_MAXC);
+    if (kind < 0 || kind > 3) return set_error(SAUNET_BAD_DTYPE, "pixel_metrics: prediction kind %d", kind);
+    if (!pred || !label || !counts || !out || N < 0 || HW < 1) return set_error(SAUNET_BAD_SHAPE, "pixel_metrics: incomplete arguments");
+    const long P = (long)N * HW;
+    long b = (P + 255) / 256; if (b > 1024) b = 1024; if (b < 1) b = 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pixel_metrics_kernel, dim3((unsigned)b), dim3(256), 0, st, pred, kind, (long)stride_n, (long)stride_c, (long)stride_p, label, (long)HW, P, C,
+                       (unsigned long long*)counts);
+    hipLaunchKernelGGL(pixel_metrics_finalize_kernel, dim3(1), dim3(64), 0, st, (const unsigned long long*)counts, C, out);
+    SAUNET_CHECK_LAUNCH("pixel_metrics");
+    return SAUNET_OK;
+}
+
+int saunet_binary_jaccard(int kind, const void* pred, const int64_t* label, int64_t n, void* sums, float* out, void* stream)
+{
+    if (kind < 0 || kind > 3) return set_error(SAUNET_BAD_DTYPE, "binary_jaccard: prediction kind %d", kind);
+    if (!pred || !label || !sums || !out || n < 0) return set_error(SAUNET_BAD_SHAPE, "binary_jaccard: incomplete arguments");
+    long b = (n + 255) / 256; if (b > 1024) b = 1024; if (b < 1) b = 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(binary_jaccard_kernel, dim3((unsigned)b), dim3(256), 0, st, pred, kind, label, (long)n, (long long*)sums, (double*)((long long*)sums + 2));
+    hipLaunchKernelGGL(binary_jaccard_finalize_kernel, dim3(1), dim3(1), 0, st, (const long long*)sums, (const double*)((const long long*)sums + 2), out);
+    SAUNET_CHECK_LAUNCH("binary_jaccard");
     return SAUNET_OK;
 }
 

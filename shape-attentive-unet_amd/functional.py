@@ -114,7 +114,11 @@ SYNCBN_ALLREDUCES = {"count": 0, "last_step": 0}      # SyncBN statistic exchang
 def begin_step():
     """Called at the start of every SAUNet forward: new scratch arenas, all weight packings refreshed in bulk."""
     SYNCBN_ALLREDUCES["last_step"], SYNCBN_ALLREDUCES["count"] = SYNCBN_ALLREDUCES["count"], 0
-    _FUSED_BLOCK_BUFS.clear(); _PENDING_AB.clear()
+    stale = len(_PENDING_AB)
+    _PENDING_AB.clear()
+    if stale:
+        # a folded transition parked its coefficient sums and no dense block consumed them: the gradients of that backward pass were wrong
+        raise RuntimeError("%d folded transition backward(s) of the previous step were never settled by a dense block" % stale)
     _DENSE_BASES.clear()          # a reserved concat buffer nobody adopted (exception, standalone stem / transition) must not outlive its step
     STATS.reset(); GRADS.reset()
     PACKS.prepack()
@@ -1412,6 +1416,48 @@ def softmax_argmax(logits, want_prob=True, want_label=True):
     return prob, label
 
 
+_METRIC_KIND = {torch.float32: 0, torch.bfloat16: 1, torch.int64: 2, torch.uint8: 3, torch.bool: 3}
+
+
+def pixel_metrics(pred, label, num_class):
+    """SegmentationModuleBase.pixel_acc (models/models.py:51-74) on the device: pred [N, C, H, W] class scores (float32 / bf16 / int64 / uint8,
+    NCHW or channels_last memory), label [N, H, W] -> float32 [C]: acc over the labelled pixels, then the Jaccard of classes 1 .. C-1."""
+    _check_dev(pred)
+    if pred.dim() != 4 or pred.shape[1] != num_class:
+        raise RuntimeError("pixel_metrics: pred must be [N, %d, H, W], got %s" % (num_class, tuple(pred.shape)))
+    if pred.dtype not in _METRIC_KIND:
+        raise RuntimeError("pixel_metrics: unsupported prediction dtype %s" % pred.dtype)
+    pred = pred.detach()
+    if not (pred.is_contiguous() or pred.is_contiguous(memory_format=_CL)):
+        pred = pred.contiguous()
+    n, c, h, w = pred.shape
+    sn, sc, sh, sw = pred.stride()
+    if sh != w * sw:                                    # one pixel stride must address the whole map
+        pred = pred.contiguous(); sn, sc, sh, sw = pred.stride()
+    lab = label.detach().to(device=pred.device, dtype=torch.int64).contiguous()
+    if tuple(lab.shape) != (n, h, w):
+        raise RuntimeError("pixel_metrics: label must be [N, H, W] = %s, got %s" % ((n, h, w), tuple(lab.shape)))
+    counts = torch.zeros(2 + 3 * (c - 1), dtype=torch.int64, device=pred.device)
+    out = torch.empty(c, dtype=torch.float32, device=pred.device)
+    L.call("saunet_pixel_metrics", _METRIC_KIND[pred.dtype], pred.data_ptr(), sn, sc, sw, lab.data_ptr(), n, h * w, c, counts.data_ptr(), out.data_ptr(), L.stream())
+    return out
+
+
+def binary_jaccard(pred, label):
+    """SegmentationModuleBase.jaccard (models/models.py:76-78) on the device -> 0-d float32 tensor."""
+    _check_dev(pred)
+    if pred.dtype not in _METRIC_KIND:
+        raise RuntimeError("binary_jaccard: unsupported prediction dtype %s" % pred.dtype)
+    p = pred.detach().contiguous()
+    lab = label.detach().to(device=p.device, dtype=torch.int64).contiguous()
+    if lab.numel() != p.numel():
+        raise RuntimeError("binary_jaccard: %d predictions for %d labels" % (p.numel(), lab.numel()))
+    sums = torch.zeros(3, dtype=torch.int64, device=p.device)
+    out = torch.empty(1, dtype=torch.float32, device=p.device)
+    L.call("saunet_binary_jaccard", _METRIC_KIND[p.dtype], p.data_ptr(), lab.data_ptr(), p.numel(), sums.data_ptr(), out.data_ptr(), L.stream())
+    return out[0]
+
+
 def canny(image, low=10, high=100, dtype=None):
     """image: float32 [N,3,H,W] (contiguous NCHW, as the loader delivers it) -> [N,1,H,W] in {0,255}."""
     _check_dev(image)
@@ -1476,8 +1522,11 @@ _DENSE_BASES = {}
 # Hand-off of a transition's share of the linear BN backward to the dense block in front of it (round 5): the block's forward registers its
 # concat buffer here when its backward will run the fused two-launch layers; the transition's backward then stores  d(buf) = scale * g  from
 # its data-gradient epilogue (no apply pass over the C-channel tensor) and leaves the coefficient sums in _PENDING_AB[buf pointer]; the block's
-# backward starts its running sums `ab` from them.  Both are keyed by the FORWARD buffer's address and dropped at the next begin_step().
-_FUSED_BLOCK_BUFS = set()
+# backward starts its running sums `ab` from them.  The registration travels ON THE OBJECT (an address can be reused): dense_block()
+# tags the statistics tensor it returns with (buffer address, norm1 eps), transition() folds only when the tag names ITS buffer and its own
+# eps equals the block's (the deferred correction uses the block's xhat rows).  _PENDING_AB is keyed by the forward buffer's address while
+# both autograd nodes hold that buffer alive; the block's backward pops its entry, begin_step() refuses left-overs.
+_LAST_FUSED_BLOCK = [None]
 _PENDING_AB = {}
 
 
@@ -1493,8 +1542,10 @@ def reserve_dense_input(n, c, h, w, ctot, dtype, device):
 
 def _dense_bwd_fused_ok(buf, training, growth, bottleneck, c0, nl):
     """the block's backward will run saunet_dense_layer_backward_conv2 / _conv1 (bf16 storage, training-mode statistics, DenseNet-121 widths)"""
+    # (the last three terms mirror dense_layer_check in csrc/dense_dgrad.hip: Cin <= 2048, pixel count below 2^31, 16-byte aligned rows)
     return bool(DENSE_BWD_FUSED and training and buf.is_cuda and buf.dtype == torch.bfloat16 and growth == 32 and bottleneck == 128 and c0 % 8 == 0
-                and ld_of(buf) == buf.shape[1] and 0 < nl <= L.DENSE_LAYERS_MAX)
+                and ld_of(buf) == buf.shape[1] and 0 < nl <= L.DENSE_LAYERS_MAX
+                and c0 + growth * (nl - 1) <= 2048 and buf.shape[0] * buf.shape[2] * buf.shape[3] < (1 << 31) and buf.data_ptr() % 16 == 0)
 
 
 class _DenseBlock(torch.autograd.Function):
@@ -1569,7 +1620,7 @@ class _DenseBlock(torch.autograd.Function):
                    None, one.data_ptr(), zero.data_ptr(),
                    float(cfgs[0][1]), 0.0, None, None, xh[0].data_ptr(), xh[1].data_ptr(), None, None, 1, L.stream())
         if _dense_bwd_fused_ok(buf, training, growth, params[2].shape[0] if nl else 0, c0, nl):
-            _FUSED_BLOCK_BUFS.add(buf.data_ptr())
+            _LAST_FUSED_BLOCK[0] = (buf.data_ptr(), float(cfgs[0][1]))
             if bnpro:
                 # the xhat rows of a concat channel are published by the first conv1 that normalises it -- nobody inside the block does that for
                 # the LAST layer's 32 channels, but a transition that folds its BatchNorm backward into this block needs them for its correction
@@ -1799,14 +1850,19 @@ def dense_block(x0, layers, training):
         bufs += [m.norm1.running_mean, m.norm1.running_var, m.norm2.running_mean, m.norm2.running_var]
         cfgs.append((m.norm1.momentum, m.norm1.eps, m.norm2.momentum, m.norm2.eps))
         _bump(m.norm1); _bump(m.norm2)
-    return _DenseBlock.apply(x0, training, tuple(cfgs), *params, *bufs)
+    _LAST_FUSED_BLOCK[0] = None
+    buf, stats = _DenseBlock.apply(x0, training, tuple(cfgs), *params, *bufs)
+    if _LAST_FUSED_BLOCK[0] is not None and stats is not None:
+        stats._saunet_fused_block = _LAST_FUSED_BLOCK[0]      # read by transition(): (address of the block's concat buffer, its norm1 eps)
+        _LAST_FUSED_BLOCK[0] = None
+    return buf, stats
 
 
 class _Transition(torch.autograd.Function):
     """BN-ReLU-conv1x1(C -> C/2)-AvgPool2 over a dense block's concat buffer (statistics already known)."""
 
     @staticmethod
-    def forward(ctx, buf, stats, gamma, beta, rmean, rvar, weight, momentum, eps, training, reserve=0):
+    def forward(ctx, buf, stats, gamma, beta, rmean, rvar, weight, momentum, eps, training, reserve=0, fold=False):
         buf = nhwc(buf)
         n, c, h, w = buf.shape
         count = n * h * w
@@ -1818,7 +1874,7 @@ class _Transition(torch.autograd.Function):
             y = new_act(n, z.shape[1], h // 2, w // 2, z.dtype, z.device)
         L.call("saunet_pool2x2_forward", L.dtype_code(z), 0, z.data_ptr(), n, h, w, z.shape[1], ld_of(z), y.data_ptr(), ld_of(y), L.stream())
         ctx.save_for_backward(buf, weight, p.buf)
-        ctx.meta = (count, training, buf.data_ptr() in _FUSED_BLOCK_BUFS)
+        ctx.meta = (count, training, bool(fold))
         return y
 
     @staticmethod
@@ -1842,17 +1898,21 @@ class _Transition(torch.autograd.Function):
             L.call("saunet_bn_backward_coeff_ab", c, sb.data_ptr(), sb.shape[0], sb.stride(0), p.scale.data_ptr(), ab.data_ptr(), c,
                    dgb[0].data_ptr(), dgb[1].data_ptr(), L.stream())
             _PENDING_AB[buf.data_ptr()] = ab
-            return da, None, dgb[0], dgb[1], None, None, dw, None, None, None, None
+            return da, None, dgb[0], dgb[1], None, None, dw, None, None, None, None, None
         da = conv_dgrad_raw(dz, weight, buf.shape, 1, 0, bn_epi=(buf, p, True, sb))
         dbuf, _, dg, db = bn_backward(da, buf, p, True, count, training, dx=da, presums=sb)
-        return dbuf, None, dg, db, None, None, dw, None, None, None, None
+        return dbuf, None, dg, db, None, None, dw, None, None, None, None, None
 
 
 def transition(buf, stats, m, training, reserve=0):
     """reserve: total channel count of the dense block that consumes the result (0: a plain tensor)"""
     _bump(m.norm)
+    # fold the BatchNorm backward into the dense block in front (section 4 of DESIGN.md) only when `stats` is the object that block's forward
+    # returned for exactly this buffer and the two normalisations agree on eps (the block's xhat rows serve the deferred correction)
+    tag = getattr(stats, "_saunet_fused_block", None)
+    fold = bool(tag is not None and tag[0] == nhwc(buf).data_ptr() and tag[1] == float(m.norm.eps))
     return _Transition.apply(buf, stats, m.norm.weight, m.norm.bias, m.norm.running_mean, m.norm.running_var, m.conv.weight,
-                             m.norm.momentum, m.norm.eps, training, int(reserve))
+                             m.norm.momentum, m.norm.eps, training, int(reserve), fold)
 
 
 def mask_to_edges(seg, num_classes=3):

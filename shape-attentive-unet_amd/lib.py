@@ -155,6 +155,8 @@ _SIGS = {
     "saunet_dual_loss_finalize": [vp, i64, vp, vp, vp],
     "saunet_dual_loss_backward": [i32, vp, i32, vp, vp, vp, i64, vp, vp, vp, i32, vp, vp],
     "saunet_softmax_argmax": [i32, vp, i32, i64, i32, vp, i32, vp, vp],
+    "saunet_pixel_metrics": [i32, vp, i64, i64, i64, vp, i64, i64, i32, vp, vp, vp],
+    "saunet_binary_jaccard": [i32, vp, vp, i64, vp, vp, vp],
     "saunet_canny": [i32, vp, i32, i32, i32, i32, i32, vp, vp, vp],
     "saunet_mask_to_edges": [vp, i32, i32, i32, i32, vp, vp],
     "saunet_labels_uncrop_resize": [vp] + [i32] * 13 + [vp, vp],
@@ -168,6 +170,7 @@ _SIGS = {
     "saunet_adam_step": [C.POINTER(TensorList), vp, vp],
     "saunet_bucket_copy": [C.POINTER(TensorList), i32, f32, vp],
 }
+ABI_VERSION = 3          # include/saunet_hip.h: SAUNET_ABI_VERSION (the struct layouts below mirror that header)
 EXPORTS = sorted(list(_SIGS) + ["saunet_last_error", "saunet_version", "saunet_launch_log"])
 
 _lib = None
@@ -185,6 +188,9 @@ def load():
     lib.saunet_last_error.restype = C.c_char_p
     lib.saunet_version.restype = C.c_int
     lib.saunet_launch_log.restype = C.c_char_p
+    if lib.saunet_version() != ABI_VERSION:
+        raise RuntimeError("%s speaks ABI version %d, this binding (include/saunet_hip.h: SAUNET_ABI_VERSION) %d: rebuild the library"
+                           % (LIB_PATH, lib.saunet_version(), ABI_VERSION))
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = sig

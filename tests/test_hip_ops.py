@@ -297,6 +297,45 @@ def test_dual_loss_against_oracle_fixture(dtype):
         close(loss, L, 1e-4, "loss"); close(ld.grad, lr.grad, 3e-2, "dlogits"); close(ed.grad, er.grad, 3e-2, "dedge")
 
 
+def test_pixel_acc_and_jaccard_with_the_reference_signatures():
+    """SegmentationModuleBase.pixel_acc(pred, label, num_class) / .jaccard(pred, label) (/root/reference/models/models.py:51-78) as thin device
+    implementations: against the reference's own values -- loss.npz (pred = round(softmax(logits)).long(), the train branch's
+    call, :92) and metrics.npz (a one-hot prediction with all-zero pixels, i.e. torch.max ties -> class 0; seeded binary masks for jaccard) --
+    in every prediction dtype / memory format the kernel takes."""
+    import saunet_amd as S
+    from tests.golden_util import load, rnd as grnd
+    base = S.modules.SegmentationModuleBase()
+    g = load("loss.npz")
+    logits = grnd((3, 4, 16, 16), int(g["meta.seed"]), "loss.logits", 2.0)
+    seg = torch.from_numpy(g["seg"]).cuda()
+    pred = torch.round(torch.softmax(logits, 1)).long()
+    for p in (pred.cuda(), pred.cuda().float(), pred.cuda().float().contiguous(memory_format=torch.channels_last), pred.cuda().to(torch.uint8),
+              pred.cuda().to(torch.bfloat16)):
+        acc, jac = base.pixel_acc(p, seg, 4)
+        assert acc.dim() == 0 and len(jac) == 3
+        close(acc, torch.tensor(g["acc"]), 1e-6, "acc"); close(torch.stack(jac), torch.from_numpy(g["jac"]), 1e-6, "jaccard")
+    # raw scores (no rounding): the class is the first maximum
+    sc = torch.softmax(logits, 1).cuda()
+    acc, jac = base.pixel_acc(sc, seg, 4)
+    am = sc.argmax(1); valid = seg >= 1
+    close(acc, ((am == seg) & valid).sum().float() / valid.sum().float(), 1e-6, "acc of raw scores")
+    m = load("metrics.npz")
+    acc, jac = base.pixel_acc(torch.from_numpy(m["pixel_acc.pred"]).cuda(), torch.from_numpy(m["pixel_acc.label"]).cuda(), 4)
+    close(acc, torch.tensor(float(m["pixel_acc.acc"])), 1e-6, "acc (ties)"); close(torch.stack(jac), torch.from_numpy(m["pixel_acc.jac"]).float(), 1e-6, "jaccard (ties)")
+    jp, jl = torch.from_numpy(m["jaccard.pred"]).cuda(), torch.from_numpy(m["jaccard.label"]).cuda()
+    for p in (jp, jp.long(), jp.bool(), jp.to(torch.bfloat16)):
+        close(base.jaccard(p, jl), torch.tensor(float(m["jaccard.value"])), 1e-6, "binary jaccard")
+    # host-side intersectionAndUnion (models/models.py:24-49): mean Jaccard of classes 1, 2 of two label maps
+    a, b = m["pixel_acc.pred"].argmax(1)[0], m["pixel_acc.label"][0]
+    j = []
+    for c in (1, 2):
+        pa, pb = (a == c) & (b >= 0), b == c
+        j.append((pa & pb).sum() / float((pa | pb).sum()))
+    assert abs(base.intersectionAndUnion(torch.from_numpy(a), torch.from_numpy(b), 4) - (j[0] + j[1]) / 2) < 1e-12
+    with pytest.raises(RuntimeError):
+        base.pixel_acc(sc[:, :3], seg, 4)
+
+
 def test_canny_bit_exact_with_oracle():
     from oracle import canny as oc, weights as Wt
     hf = HF()
