@@ -26,6 +26,10 @@ import torch  # noqa: E402
 TRAIN_GFLOP_PER_SLICE_256 = 216.1
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+# what a register-only mfma_f32_32x32x16_bf16 loop SUSTAINS on this chip under its power cap with activation-like operands (profiles/r06_mfma_ceiling.txt:
+# 1810 TFLOP/s on random normal data at 1.79 GHz / 1310 W, 1893 on relu-like x small weights, 2469 on zeros at 2.39 GHz / 877 W); matrix-bound entries
+# carry `frac_of_sustained` next to `frac` (which stays priced against the dense peak)
+MFMA_BF16_SUSTAINED_TFLOPS = 1850.0
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
@@ -339,6 +343,8 @@ def _roofline_entry(label, ms, launches, nbytes, flops, dtype, extra=None):
         e.update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), tflops=round(tfl, 1))
     else:
         e.update(bound="mfma", achieved=round(tfl, 1), peak=peak_tf, unit="TFLOP/s", frac=round(tfl / peak_tf, 4), gbs=round(gbs, 1))
+        if dtype == torch.bfloat16:
+            e["frac_of_sustained"] = round(tfl / MFMA_BF16_SUSTAINED_TFLOPS, 4)
     e["flop_per_byte"] = round(ai, 1)
     if extra:
         e.update(extra)
@@ -405,6 +411,8 @@ def census_roofline(S, step_fn, dtype, args):
                 else:
                     e["by_bound"]["mfma"] = {"launches": bn, "ms": round(bms, 4), "achieved": round(bfl / (bms * 1e-3) / 1e12, 1), "peak": peak_tf_,
                                              "unit": "TFLOP/s", "frac": round(bfl / (bms * 1e-3) / 1e12 / peak_tf_, 4)}
+                    if dtype == torch.bfloat16:
+                        e["by_bound"]["mfma"]["frac_of_sustained"] = round(bfl / (bms * 1e-3) / 1e12 / MFMA_BF16_SUSTAINED_TFLOPS, 4)
         tr = [pmc[s_]["traffic_bytes_per_step"] for s_ in symbols if s_ in pmc]
         e["traffic"] = int(sum(tr)) if tr else None
         if inc:
@@ -464,6 +472,7 @@ def weakest_family_roofline(S, dtype, batch, size):
         tf = fl / (ms * 1e-3) / 1e12
         byts = batch * h * h * (cin + cout) * esz
         return {"ms": round(ms, 4), "achieved": round(tf, 1), "frac": round(tf / peak, 4), "flops": fl,
+                "frac_of_sustained": round(tf / MFMA_BF16_SUSTAINED_TFLOPS, 4) if dtype == torch.bfloat16 else None,
                 "hbm_frac": round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     cands = [
         dict(probe(512, 128, size // 4, True), kernel="conv3x3_wgrad_mm 3x3 512->128 @%dx%d B%d (dec3.c3x3rb weight gradient, incl. its partial-gradient reduce)" % (size // 4, size // 4, batch)),

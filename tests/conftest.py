@@ -11,6 +11,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of CPU oracle work; runs only with SAUNET_SLOW=1")
 
 
 def pytest_collection_modifyitems(config, items):

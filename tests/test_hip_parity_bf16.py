@@ -74,12 +74,24 @@ def report(lines, name):
 def test_bf16_gradients_at_256_against_exact_and_bf16_emulated_oracle():
     """configs[1] geometry (256x256, bf16 storage), B=8: loss + EVERY parameter gradient (incl. the 24-deep accumulate chain of
     denseblock3) against the float32 oracle and against the oracle's bf16-storage emulation."""
+    _bf16_gradient_parity(8, "r2_parity_bf16_256.txt")
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(os.environ.get("SAUNET_SLOW") != "1", reason="B=32 oracle on the CPU (minutes): SAUNET_SLOW=1; the table of the last run is profiles/r06_parity_bf16_256_b32.txt")
+def test_bf16_gradients_at_256_b32_the_benchmarked_batch():
+    """the same comparison at the HEADLINE batch (configs[1]: B=32, 256x256, bf16) -- the geometry at which block 3 runs
+    dense_conv1_dgrad_pair_kernel (256 tiles of 128 pixels) and every small-map kernel its bench tiling."""
+    _bf16_gradient_parity(32, "r6_parity_bf16_256_b32.txt")
+
+
+def _bf16_gradient_parity(B, table_name):
     import saunet_amd as S
     torch.set_num_threads(min(os.cpu_count() or 8, 32))
     spec = R.state_dict_spec()
     sd = Wt.make_state_dict(spec, 13)
     keys = Wt.trainable_keys(spec)
-    batch = Wt.synthetic_batch(8, 256, 256, seed=113)
+    batch = Wt.synthetic_batch(B, 256, 256, seed=113)
     loss_a, ga, _ = oracle_grads(sd, keys, batch, False)
     loss_b, gb, _ = oracle_grads(sd, keys, batch, True)
     try:
@@ -99,7 +111,7 @@ def test_bf16_gradients_at_256_against_exact_and_bf16_emulated_oracle():
                 continue
             hip[group_of(k)].append(cos_rel(pd[k].grad, ga[k]) + (k,))
             emu[group_of(k)].append(cos_rel(gb[k], ga[k]) + (k,))
-        lines = ["bf16 gradient parity, B=8 256x256, seed 13: loss exact %.6f  bf16-emulated oracle %.6f  HIP bf16 %.6f" % (loss_a, loss_b, float(loss)),
+        lines = ["bf16 gradient parity, B=%d 256x256, seed 13: loss exact %.6f  bf16-emulated oracle %.6f  HIP bf16 %.6f" % (B, loss_a, loss_b, float(loss)),
                  "%-14s %4s | %-26s | %-26s" % ("group", "n", "HIP bf16 vs exact f32", "bf16-emulated oracle vs exact"),
                  "%-14s %4s | %8s %8s %8s | %8s %8s %8s" % ("", "", "med cos", "min cos", "max rel", "med cos", "min cos", "max rel")]
         bad = []
@@ -116,7 +128,7 @@ def test_bf16_gradients_at_256_against_exact_and_bf16_emulated_oracle():
                 bad.append("%s: HIP median/min cosine %.4f/%.4f below the bf16 emulation's %.4f/%.4f" % (g, hm, hmin, em, emin))
             if g in GROUPS_BENIGN and hmin < 0.99:
                 bad.append("%s: min cosine %.4f < 0.99 in a group that is benign under bf16 storage" % (g, hmin))
-        report(lines, "r2_parity_bf16_256.txt")
+        report(lines, table_name)
         assert abs(float(loss) - loss_a) < 1e-2 * loss_a, (float(loss), loss_a)
         assert not tiny_bad, "gradients that are ~0 in the oracle are not small in the HIP path: %s" % tiny_bad
         assert not bad, "\n".join(bad)
