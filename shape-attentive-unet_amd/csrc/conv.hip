@@ -32,6 +32,8 @@ int igemm_wgrad(const saunet_conv_desc* d, const void* x, const void* dy, const 
 bool tile_fwd_supported(const saunet_conv_desc* d);
 bool tile_fwd_accumulate_supported(const saunet_conv_desc* d);
 bool mm_fwd_supported(const saunet_conv_desc* d, const void* x, const void* w, const void* y, const float* ps, const saunet_bn_epilogue* epi);
+bool mm_convt_supported(const saunet_conv_desc* d, const void* x, const void* w, const void* y, const float* ps, const saunet_bn_epilogue* epi);
+int mm_convt_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* ssum, double* ssq, hipStream_t st);
 int mm_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* ssum, double* ssq, hipStream_t st);
 int64_t mm_forward_workspace(const saunet_conv_desc* d);
 bool dense_conv2_small_supported(const saunet_conv_desc* d, const void* x, const void* w, const void* y, const float* bias);
@@ -648,6 +650,7 @@ int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const voi
         }
     }
     if (mm_fwd_supported(d, x, w, y, ps, epi)) return mm_forward(d, x, w, bias, y, ssum, ssq, st);
+    if (mm_convt_supported(d, x, w, y, ps, epi)) return mm_convt_forward(d, x, w, bias, y, ssum, ssq, st);
     if (igemm_supported(d)) {
         if (epi && (((uintptr_t)epi->bn_x & 15) || epi->ld_bn_x % (d->dtype == SAUNET_BF16 ? 8 : 4)))
             return set_error(SAUNET_BAD_ALIGN, "conv: bn epilogue tensor must be 16-byte aligned");

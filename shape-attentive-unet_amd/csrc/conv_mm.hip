@@ -15,6 +15,16 @@
 //     before the barrier that ends stage s: the ds_read -> MFMA software pipeline (two named fragment sets) runs straight through barriers.
 //
 // bf16 storage only; float32 storage keeps conv3x3_tile_fwd_kernel (exact f32 MFMA).
+//
+// CONVT (round 6): ConvTranspose2d(k = 4, s = 2, p = 1) forward -- `mrf.up` of the DualAttBlocks (/root/reference/models/attention_blocks.py:179-186)
+// and DecoderBlock's transposed convolution (models/models.py:208-213) -- on the SAME stage pipeline.  Output pixel (2i + ph, 2j + pw) is a
+// 2 x 2-tap convolution over the input around (i, j): tap (th, tw) reads input pixel (i + ph - th, j + pw - tw) = halo pixel (1 + ph - th,
+// 1 + pw - tw) of the 18 x 18 halo and kernel element (1 - ph + 2 th, 1 - pw + 2 tw), i.e. row (ph, pw, co, th, tw) of the SAUNET_PACK_CONVT_FWD
+// packing.  A workgroup = (16 x 16 INPUT pixel tile, output parity, n tile): the four parities ride on the n-tile index, so they share the
+// halo on one XCD; K loop = (channel block) x (4 live taps) -- the dead taps of the "one 3 x 3 convolution with 4 Cout channels" formulation
+// (scripts/probes/convt_forward_as_3x3_rejected.patch: 2.25x the multiply-adds) are never stages; the next channel block's six halo pieces
+// per wave are requested two per stage behind taps 0 - 2 and certified at the barrier of tap 3; the epilogue scatters the tile to its
+// parity's pixels of the 2H x 2W map.
 #include "common.h"
 #include <type_traits>
 
@@ -43,8 +53,8 @@ template <bool CELL> struct MmHalo {
 constexpr int MM_RING = 4;
 
 // bias / ReLU, tile through LDS to 16-byte row stores, per-channel sums of the un-biased accumulator (BatchNorm statistics)
-template <int BN, bool CELL>
-__device__ __forceinline__ void mm_epilogue(const MmArgs& a, f32x16 (&acc)[2][BN / 64], unsigned char* smem, int n, int ty0, int tx0, int n0)
+template <int BN, bool CELL, bool CONVT = false>
+__device__ __forceinline__ void mm_epilogue(const MmArgs& a, f32x16 (&acc)[2][BN / 64], unsigned char* smem, int n, int ty0, int tx0, int n0, int par = 0)
 {
     constexpr int TJ = BN / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
@@ -80,7 +90,7 @@ __device__ __forceinline__ void mm_epilogue(const MmArgs& a, f32x16 (&acc)[2][BN
         atomicAdd(&a.stat_sumsq[ro + n0 + tid], (double)t2);
     }
     constexpr int CH = BN / 8;                                     // 16-byte chunks per row
-    u16* __restrict__ yg = a.y + (size_t)n * (CELL ? 4 : 1) * a.H * a.W * a.ldy;
+    u16* __restrict__ yg = a.y + (size_t)n * (CELL || CONVT ? 4 : 1) * a.H * a.W * a.ldy;      // CONVT: the output map is 2H x 2W
     constexpr int S_ITERS = 256 * CH / 512;
     const int colv = n0 + (tid % CH) * 8;
     if (colv < a.Cout) {
@@ -89,7 +99,8 @@ __device__ __forceinline__ void mm_epilogue(const MmArgs& a, f32x16 (&acc)[2][BN
             const int p = tid + i * 512;
             const int row = p / CH, ch = p - row * CH;
             const int py = row >> 4, px = row & 15;
-            const size_t opix = CELL ? (size_t)(2 * (py >> 3) + (px >> 3)) * 64 + (py & 7) * 8 + (px & 7) : (size_t)(ty0 + py) * a.W + tx0 + px;
+            const size_t opix = CONVT ? (size_t)(2 * (ty0 + py) + (par >> 1)) * (2 * a.W) + 2 * (tx0 + px) + (par & 1)
+                              : CELL ? (size_t)(2 * (py >> 3) + (px >> 3)) * 64 + (py & 7) * 8 + (px & 7) : (size_t)(ty0 + py) * a.W + tx0 + px;
             *(u32x4*)(yg + opix * a.ldy + colv) = *(const u32x4*)(so + row * BN + ch * 8);
         }
     }
@@ -124,9 +135,11 @@ __global__ __launch_bounds__(512) void conv3x3_mm_finish_kernel(MmArgs a)
 // loader waves (640-thread workgroups; a single wave sustains only one request per ~118 cycles, 12 per stage = 1400 cycles: slower, 55 %),
 // anti-phase halves (waves 0-3 behind the barrier, 4-7 at the end of the stage: 56 %), requests pinned a full k-step ahead and s_setprio
 // around the MFMA groups (both -2 %).
-template <int BN, bool CELL>
+template <int BN, bool CELL, bool CONVT = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
 {
+    static_assert(!(CELL && CONVT), "the transposed convolution runs on plain tiles");
+    constexpr int TAPS = CONVT ? 4 : 9;
     constexpr int MM_HP = MmHalo<CELL>::HP, MM_NPIX = MmHalo<CELL>::NPIX, MM_HALO_INSTR = MmHalo<CELL>::INSTR, MM_HALO_BYTES = MmHalo<CELL>::BYTES;
     constexpr int MM_HALO_PER_WAVE = MmHalo<CELL>::PER_WAVE;
     TSTAMP_INIT();
@@ -153,13 +166,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
     }
     const int txi = t % a.tiles_x; const int r1 = t / a.tiles_x;
     const int tyi = r1 % a.tiles_y; const int n = r1 / a.tiles_y;
+    // CONVT: nt = parity * (n tiles per parity) + n tile; (ph, pw) = output row / column parity of this workgroup
+    const int nnt_c = CONVT ? a.nnt >> 2 : a.nnt;
+    const int par = CONVT ? nt / nnt_c : 0, ph = par >> 1, pw = par & 1;
+    if constexpr (CONVT) nt -= par * nnt_c;
     const int ty0 = tyi * 16, tx0 = txi * 16, n0 = nt * BN;
     // CELL: a.tiles_x = a.tiles_y = 1 and n counts cells of four 8 x 8 images
     const u16* __restrict__ xg = a.x + (size_t)n * (CELL ? 4 : 1) * a.H * a.W * a.ldx;
     // CELL: this workgroup reduces channel blocks [cb0, cb0 + ncb) of the layer's Cin / 64
     const int ncb = CELL ? (a.Cin >> 6) / a.splits : a.Cin >> 6;
     const int cb0 = split * ncb;
-    const int nstage = ncb * 9;
+    const int nstage = ncb * TAPS;
     const unsigned char* zsrc = (const unsigned char*)g_mm_zeros;
 
     // ---- DMA source offsets of this lane (bytes; channel block / tap terms are added per issue)
@@ -188,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
         const int q = j * 8 + wave;
         const int r = q * 8 + (lane >> 3), sl = lane & 7;
         int row = n0 + r; if (row >= a.Cout) row = a.Cout - 1;
-        woff[j] = (unsigned)(((size_t)row * 9 * a.Cin + (sl ^ ((r >> 1) & 7)) * 8) * 2);
+        woff[j] = (unsigned)(((size_t)row * TAPS * a.Cin + (sl ^ ((r >> 1) & 7)) * 8) * 2);
     }
     // requests past the end of the K loop keep the per-wave request count uniform (the counted waits rely on it): they re-load the last
     // channel block / stage into a buffer nobody reads any more
@@ -200,9 +217,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
     };
     auto issue_w1 = [&](int s, int j) {              // rows j of the weight tile of stage s into ring slot s % 4
         const int sc = s < nstage ? s : nstage - 1;
-        const int cb = sc / 9, tap = sc - cb * 9;
+        const int cb = sc / TAPS, tap = sc - cb * TAPS;
         const unsigned sbase = lds0 + OFF_W + (s & (MM_RING - 1)) * WSLOT;
-        const unsigned char* wsrc = (const unsigned char*)a.w + ((size_t)tap * a.Cin + (size_t)(cb + cb0) * 64) * 2;
+        // CONVT: rows (ph, pw, co) of the phase packing, 4 taps x Cin per row
+        const unsigned char* wsrc = (const unsigned char*)a.w + ((size_t)par * a.Cout * TAPS * a.Cin + (size_t)tap * a.Cin + (size_t)(cb + cb0) * 64) * 2;
         mm_dma16(wsrc + woff[j], sbase + (j * 8 + wave) * 1024);
     };
     auto issue_w = [&](int s) {
@@ -213,10 +231,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
     // ---- fragment addresses (bytes inside smem).  A: halo pixel (py + kh, px + kw), 16-byte slot (2 ks + lh) ^ key(px + kw)
     const int py0 = wm * 4 + (lr >> 4), px = lr & 15;
     const int hy0 = CELL ? py0 + 2 * (py0 >> 3) : py0, hx0 = CELL ? px + 2 * (px >> 3) : px;      // (the wave's four rows sit in one half of the cell)
+    // (CONVT: index tw = 0, 1 -> halo column offset 1 + pw - tw; the row offset 1 + ph - th is workgroup-uniform scalar arithmetic)
     int ak[3];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-        const int hxk = hx0 + kw;
+        const int hxk = hx0 + (CONVT ? 1 + pw - kw : kw);
         const int key = ((CELL && hxk >= 10 ? hxk - 2 : hxk) >> 1) & 7;
         ak[kw] = (hy0 * MM_HP + hxk) * 128 + (((lh ^ key) & 1) << 4) + ((key & 6) << 4);
     }
@@ -243,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
 
     u32x4 fa0[2], fb0[TJ], fa1[2], fb1[TJ];
     auto load_frags = [&](u32x4* fa, u32x4* fb, int hb_off, int ws_off, int tap, int ks) {
-        const int kh = tap / 3, kw = tap - kh * 3;
+        const int kh = CONVT ? 1 + ph - (tap >> 1) : tap / 3, kw = CONVT ? (tap & 1) : tap - (tap / 3) * 3;      // kw indexes ak[]
         const int aaddr = (ak[kw] ^ (ks << 5)) + hb_off + kh * (MM_HP * 128);
         const int baddr = (bk ^ (ks << 5)) + ws_off;
 #pragma unroll
@@ -267,18 +286,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
     for (int cb = 0; cb < ncb; ++cb) {
         const int hb_off = (cb & 1) * MM_HALO_BYTES, hb_next = ((cb + 1) & 1) * MM_HALO_BYTES;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap, ++s) {
+        for (int tap = 0; tap < TAPS; ++tap, ++s) {
             // ---- stage boundary.  Outstanding (per wave, oldest first): [halo piece of stage s-2] weights(s+1) [halo piece of s-1] weights(s+2);
             // certify weights(s+1) (and with them every older halo piece): allow what stage s-1 issued to stay in flight
             TSTAMP(23);
-            if (tap >= 1 && tap <= MM_HALO_PER_WAVE) mm_wait_vm<1 + WINSTR>(); else mm_wait_vm<WINSTR>();
+            if constexpr (CONVT) {
+                // stage s - 1 issued two halo pieces (taps 0 - 2 of a channel block) in FRONT of weights(s + 2): behind taps 0 and 1 they may stay
+                // in flight, at the barrier of tap 3 they are certified with everything older than weights(s + 2) -- the first fragments of the
+                // next channel block are read at the end of this stage
+                static_assert(MM_HALO_PER_WAVE <= 6, "two halo pieces behind each of taps 0 - 2");
+                if (tap == 1 || tap == 2) mm_wait_vm<2 + WINSTR>(); else mm_wait_vm<WINSTR>();
+            } else {
+                if (tap >= 1 && tap <= MM_HALO_PER_WAVE) mm_wait_vm<1 + WINSTR>(); else mm_wait_vm<WINSTR>();
+            }
             TSTAMP(29);
             mm_barrier();
             TSTAMP(24);
             // the stage's requests of this wave as pieces 0 .. 2: [halo piece (taps 0-5)] [weight rows] [weight rows (BN = 128)]
             auto piece = [&](int k) {
-                if (k == 0) { if (tap < MM_HALO_PER_WAVE) issue_halo(tap, cb + 1); }
-                else if (k - 1 < WINSTR) issue_w1(s + 3, k - 1);
+                if constexpr (CONVT) {     // [halo piece 2 tap] [halo piece 2 tap + 1] [weight rows (both instructions with BN = 128)]
+                    if (k < 2) { if (tap < 3 && 2 * tap + k < MM_HALO_PER_WAVE) issue_halo(2 * tap + k, cb + 1); else if (tap < 3) issue_halo(MM_HALO_PER_WAVE - 1, cb + 1); }
+                    else issue_w(s + 3);
+                } else {
+                    if (k == 0) { if (tap < MM_HALO_PER_WAVE) issue_halo(tap, cb + 1); }
+                    else if (k - 1 < WINSTR) issue_w1(s + 3, k - 1);
+                }
             };
             TSTAMP(25);
             const int ws_off = (s & (MM_RING - 1)) * WSLOT, ws_next = ((s + 1) & (MM_RING - 1)) * WSLOT;
@@ -293,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
             load_frags(fa1, fb1, hb_off, ws_off, tap, 3);
             mma(fa0, fb0);
             piece(2);
-            if (tap < 8) load_frags(fa0, fb0, hb_off, ws_next, tap + 1, 0);
+            if (tap < TAPS - 1) load_frags(fa0, fb0, hb_off, ws_next, tap + 1, 0);
             else load_frags(fa0, fb0, hb_next, ws_next, 0, 0);
             mma(fa1, fb1);
         }
@@ -318,20 +350,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_mm_kernel(MmArgs a)
             return;
         }
     }
-    mm_epilogue<BN, CELL>(a, acc, smem, n, ty0, tx0, n0);
+    mm_epilogue<BN, CELL, CONVT>(a, acc, smem, n, ty0, tx0, n0, par);
     TSTAMP(28);
 }
 
 
-template <int BN, bool CELL = false> static int launch_mm(const MmArgs& a, hipStream_t st)
+template <int BN, bool CELL = false, bool CONVT = false> static int launch_mm(const MmArgs& a, hipStream_t st)
 {
     constexpr int LDS = 2 * MmHalo<CELL>::BYTES + MM_RING * BN * 128 + 1024;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_mm_kernel<BN, CELL>;
+    auto kern = conv3x3_mm_kernel<BN, CELL, CONVT>;
     static DeviceOnce attr;
     if (attr.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     hipLaunchKernelGGL(kern, dim3(a.ntiles * a.nnt * (CELL ? a.splits : 1)), dim3(512), LDS, st, a);
-    static const KName kn("conv3x3_mm_kernel", BN, CELL);
+    static const KName kn("conv3x3_mm_kernel", BN, CELL, CONVT);
     SAUNET_CHECK_LAUNCH(kn.s);
     return SAUNET_OK;
 }
@@ -411,6 +443,30 @@ int mm_forward(const saunet_conv_desc* d, const void* x, const void* w, const fl
     const int bn = mm_pick_bn(d);
     a.nnt = (d->Cout + bn - 1) / bn;
     return bn == 64 ? launch_mm<64>(a, st) : launch_mm<128>(a, st);
+}
+
+// ---- ConvTranspose2d(4, 2, 1) forward on the same pipeline (CONVT): d is the transposed-convolution descriptor (H, W = input map, Ho = 2H)
+bool mm_convt_supported(const saunet_conv_desc* d, const void* x, const void* w, const void* y, const float* ps, const saunet_bn_epilogue* epi)
+{
+    static const bool on = ab_env_on("SAUNET_CONVT_MM");            // A/B switch (variant builds only)
+    return on && d->dtype == SAUNET_BF16 && d->transposed && d->KH == 4 && d->KW == 4 && d->stride == 2 && d->pad == 1 && d->Ho == 2 * d->H && d->Wo == 2 * d->W &&
+           d->H % 16 == 0 && d->W % 16 == 0 && ps == nullptr && epi == nullptr && d->Cin % 64 == 0 && d->Cin >= 128 && d->Cin <= 2048 &&
+           d->Cout % 8 == 0 && d->Cout >= 64 && d->ldx % 8 == 0 && d->ldy % 8 == 0 &&
+           !(((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) && (long)d->N * d->H * d->W * d->ldx < (1L << 30) && (long)d->N * d->Ho * d->Wo * d->ldy < (1L << 31);
+}
+
+int mm_convt_forward(const saunet_conv_desc* d, const void* x, const void* w, const float* bias, void* y, double* ssum, double* ssq, hipStream_t st)
+{
+    MmArgs a;
+    a.x = (const u16*)x; a.w = (const u16*)w; a.y = (u16*)y; a.bias = bias; a.stat_sum = ssum; a.stat_sumsq = ssq;
+    a.stat_replicas = d->stat_replicas > 1 ? d->stat_replicas : 1; a.stat_rstride = d->stat_rstride;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.Cout = d->Cout; a.ldy = d->ldy; a.act_relu = d->epi_relu;
+    a.splits = 1; a.ws = nullptr;
+    a.tiles_y = d->H / 16; a.tiles_x = d->W / 16; a.ntiles = a.tiles_x * a.tiles_y * a.N;
+    // 128-wide output tiles unless that leaves CUs idle (four parities per pixel tile already multiply the grid by four)
+    const int bn = (d->Cout <= 64 || (long)a.ntiles * 4 * ((d->Cout + 127) / 128) < 256) ? 64 : 128;
+    a.nnt = 4 * ((d->Cout + bn - 1) / bn);
+    return bn == 64 ? launch_mm<64, false, true>(a, st) : launch_mm<128, false, true>(a, st);
 }
 
 }  // namespace saunet

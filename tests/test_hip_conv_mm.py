@@ -120,3 +120,52 @@ def test_convt_wgrad_mm_matches_float64(case):
     scale = float(wr.grad.abs().max())
     err = float((dw.double().cpu() - wr.grad).abs().max())
     assert err <= 2e-5 * scale + 1e-6 * (n * h * w) ** 0.5, (err, scale)
+
+
+CONVT_CASES = [
+    # (N, Cin, Cout, H, W, ldx_extra, ldy_extra, bias, relu)
+    (2, 128, 64, 16, 16, 0, 0, False, False),      # one tile per image: every halo pixel outside the image; BN = 64
+    (1, 256, 128, 32, 48, 0, 0, True, False),      # 2 x 3 tiles: every border / interior combination, bias
+    (2, 192, 72, 32, 32, 64, 64, True, True),      # 3 channel blocks, ragged Cout (72), channel-slice views in and out, fused ReLU
+    (9, 128, 256, 16, 16, 0, 0, False, False),     # 9 pixel tiles (plain block order), two n tiles per parity at BN = 128
+    (8, 128, 128, 64, 64, 0, 0, True, False),      # `mrf.up` of dec2 in small: 128 tiles x 4 parities, XCD-grouped order
+    (4, 512, 512, 16, 16, 0, 0, False, False),     # `mrf.up` of dec4 in small: 8 channel blocks x 4 taps = 32 stages
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_convt_mm_forward_matches_float64(case):
+    """ConvTranspose2d(k4 s2 p1) forward on the LDS-DMA stage pipeline (conv3x3_mm_kernel<.., CONVT>, round 6: `mrf.up`,
+    /root/reference/models/attention_blocks.py:179-186): all four output parities, image borders, bias / ReLU epilogue, BatchNorm statistics of
+    the un-biased accumulator over ALL parities, channel-slice views on both sides, ragged output-channel tiles -- against float64
+    conv_transpose2d on the bf16-rounded operands; and the launch log must name the kernel (no silent implicit-GEMM route)."""
+    n, cin, cout, h, w, lxe, lye, has_bias, relu = case
+    H = HF()
+    dt = torch.bfloat16
+    xw = _rnd(n, cin + lxe, h, w, seed=31).cuda().to(dt).contiguous(memory_format=torch.channels_last)
+    x = xw[:, lxe // 2: lxe // 2 + cin] if lxe else xw
+    wt = torch.nn.Parameter((_rnd(cin, cout, 4, 4, seed=32) * (1.5 / (cin * 4) ** 0.5)).cuda())
+    bias = _rnd(cout, seed=33).cuda() if has_bias else None
+    yw = torch.full((n, cout + lye, 2 * h, 2 * w), 7.0, device="cuda", dtype=dt).contiguous(memory_format=torch.channels_last)
+    y = yw[:, lye // 2: lye // 2 + cout] if lye else yw
+    st = torch.zeros(H.STAT_R, 2, cout, dtype=torch.float64, device="cuda")
+    H.PACKS.get(wt, H.L.PACK_CONVT_FWD, dt)                 # (lazy packing launches stay out of the log)
+    H.L.load().saunet_launch_log()
+    H.conv_forward_raw(x, wt, bias, 2, 1, transposed=True, out=y, stats=st, act_relu=relu)
+    launched = H.L.load().saunet_launch_log().decode()
+    assert "conv3x3_mm" in launched and "true>" in launched, launched
+    torch.cuda.synchronize()
+    ref0 = F.conv_transpose2d(x.double().cpu(), wt.detach().to(dt).double().cpu(), None, stride=2, padding=1)
+    ref = ref0 + (bias.double().cpu().view(1, -1, 1, 1) if has_bias else 0.0)
+    if relu:
+        ref = ref.clamp_min(0)
+    got = y.double().cpu()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 6e-3 * scale, "output: %g of %g" % (float((got - ref).abs().max()), scale)   # bf16 output rounding
+    s = st.sum(0).cpu()
+    cnt = n * 4 * h * w
+    r1, r2 = ref0.sum((0, 2, 3)), (ref0 * ref0).sum((0, 2, 3))
+    assert float((s[0] - r1).abs().max()) <= 2e-5 * float(ref0.abs().max()) * cnt
+    assert float(((s[1] - r2) / r2).abs().max()) <= 1e-4
+    if lye:     # the channels around the slice stay untouched
+        assert float((yw[:, :lye // 2].float() - 7).abs().max()) == 0 and float((yw[:, lye // 2 + cout:].float() - 7).abs().max()) == 0
