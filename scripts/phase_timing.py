@@ -29,6 +29,13 @@ elif case in ("conv2wgrad", "conv1wgrad", "dec3wgrad"):
     x = act(cin, h); dy = act(cout, h); w = torch.nn.Parameter(torch.randn(cout, cin, k, k, device="cuda") * 0.03)
     sc = torch.rand(cin, device="cuda") + 0.5; sh = torch.randn(cin, device="cuda") * 0.1
     run = lambda: (HF.GRADS.reset(), HF.conv_wgrad_raw(x, dy, w, 1, k // 2, pro=(sc, sh, True) if case != "dec3wgrad" else None))
+elif case in ("sc1", "sc2", "sc3"):
+    h, cnt = {"sc1": (128, 6), "sc2": (64, 12), "sc3": (32, 24)}[case]
+    probs = []
+    for i in range(cnt):
+        sc = torch.rand(128, device="cuda") + 0.5; sh = torch.randn(128, device="cuda") * 0.1
+        probs.append((act(128, h), act(32, h), torch.nn.Parameter(torch.zeros(32, 128, 3, 3, device="cuda")), (sc, sh)))
+    run = lambda: (HF.GRADS.reset(), HF.conv_wgrad_grouped(probs, 3, 1, True))
 elif case in ("dec4convtwgrad", "dec2convtwgrad"):
     ci, h = {"dec4convtwgrad": (512, 16), "dec2convtwgrad": (128, 64)}[case]
     x = act(ci, h); dy = act(ci, 2 * h); w = torch.nn.Parameter(torch.randn(ci, ci, 4, 4, device="cuda") * 0.03)

@@ -1872,6 +1872,316 @@ static int launch_tile_wgrad_grouped(GroupedWgradArgs& g, const saunet_wgrad_gro
     return SAUNET_OK;
 }
 
+// =====================================================================================================
+// conv3x3_wgrad_sc_kernel (round 6): the weight gradients of ALL DenseNet conv2 layers of a block (3x3, 128 -> 32, BatchNorm + ReLU prologue on
+// z1; torchvision _DenseLayer.conv2 as sliced at /root/reference/models/models.py:306-313) on the LDS-DMA staged, rolling-row design of
+// conv3x3_wgrad_mm_kernel -- VERDICT r5 item 2 (i).  The tiled kernel it replaces staged every pixel tile synchronously through registers
+// (global -> VGPR -> prologue -> LDS, two barriers per tile), read the dy tile once per 64 input channels and walked the tiles with a stride
+// of the group count (neighbouring halos on different XCDs): 2.0 TB/s of algorithmic bytes over the four blocks.
+//   * one 8-wave workgroup per CU = (problem, pixel group); channel tile = the whole layer (32 x 128): 4 input-channel waves x 2 K halves
+//     (tile rows 0-3 / 4-7), each wave 9 taps x one 32 x 32 accumulator; the K halves are summed through the (idle) LDS at the end;
+//   * pixel tile 8 rows x 16 columns; dy tile (8 KB) + x halo (10 rows x 20 pixel slots x 256 B: 18 real columns, the pitch of 20 makes the
+//     swizzle key  hx & 3  a function of the LANE, so a lane always handles the same 8 channels) arrive by LDS-DMA into one of two buffers
+//     while the matrix cores work on the other; one barrier per tile.  (Measured and rejected: 4-row tiles in a ring of four buffers with the
+//     activation between the MFMAs of the tile before -- no DMA wait left, but 2.1k cycles per 18 MFMAs of fragment-read latency and a third
+//     more halo: 430 us at block 1 against 384);
+//   * the BatchNorm + ReLU prologue is applied IN PLACE in the LDS by the wave that requested the piece (its 16 coefficients live in registers;
+//     pieces sourced from the zero page -- padding of the ACTIVATED tensor -- are left alone);
+//   * a group owns a CONTIGUOUS run of tiles in column-strip order (tile row fastest), so the two halo rows it shares with the tile it has
+//     just finished are L2 hits on its own XCD;
+//   * partial gradients [group][tap][co][ci] (128-byte runs), permuted into the parameter layout by wgrad_reduce_tco_multi_kernel.
+struct ScItem { const u16* x; const u16* dy; float* ws; float* dw; const float* ps; const float* psh; int ldx, lddy, blk0, pad_; };
+struct ScArgs { int N, H, W, tiles_x, tiles_y, ntiles, groups, count, pro_relu, pad_; ScItem item[SAUNET_WGRAD_GROUP_MAX]; };
+static __device__ u32x4 g_sc_zeros[4];
+
+constexpr int SC_HPW = 20;                                                   // halo pixel slots per row (18 used)
+constexpr int SC_TR = 8;                                                     // tile rows
+constexpr int SC_DYB = SC_TR * 16 * 64, SC_XB = (SC_TR + 2) * SC_HPW * 256, SC_BUF = SC_DYB + SC_XB;      // 8192 + 51200 = 59392
+constexpr int SC_DY_PIECES = SC_DYB / 1024, SC_PIECES = SC_DY_PIECES + SC_XB / 1024, SC_SLOTS = (SC_PIECES + 7) / 8;     // 8 + 50 = 58 pieces, 8 slots per wave
+constexpr int SC_NBUF = 2;
+constexpr int SC_OFF_DUMMY = SC_NBUF * SC_BUF, SC_OFF_PRO = SC_OFF_DUMMY + 1024, SC_LDS = SC_OFF_PRO + 1024;
+
+template <bool PRO>
+__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_sc_kernel(ScArgs a)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4, nhalf = lg & 1, khalf = lg >> 1;
+    const int wn0 = (wave & 3) * 32, kh2 = wave >> 2;                         // input-channel tile of the wave; its K half (tile rows 2 kh2, 2 kh2 + 1)
+    int pi = 0;
+    while (pi + 1 < a.count && (int)blockIdx.x >= a.item[pi + 1].blk0) ++pi;
+    const ScItem& it = a.item[pi];
+    const int gx = (int)blockIdx.x - it.blk0;
+    const int t0 = (int)((long)gx * a.ntiles / a.groups), t1 = (int)((long)(gx + 1) * a.ntiles / a.groups);
+    const unsigned char* zsrc = (const unsigned char*)g_sc_zeros;
+
+    // ---- DMA slots of this wave: piece id = j * 8 + wave; 0..3 = dy (16 pixels x 64 B), 4..33 = x halo (4 pixel slots x 256 B), 34..39 = dummies
+    // (zero page -> scratch KB: every wave issues the same number of requests per tile, which is what the counted waits rely on)
+    int prel[SC_SLOTS], phyx[SC_SLOTS];      // phyx = halo row << 16 | halo column (one register: the kernel sits at the 256-register limit)
+#pragma unroll
+    for (int j = 0; j < SC_SLOTS; ++j) {
+        const int id = j * 8 + wave;
+        if (id < SC_DY_PIECES) {
+            const int pix = id * 16 + (lane >> 2), sl = lane & 3, row = pix >> 4, col = pix & 15;
+            prel[j] = ((row * a.W + col) * it.lddy + sl * 8) * 2; phyx[j] = (1 << 16) | 1;
+        } else {
+            const int hp = (id - SC_DY_PIECES) * 4 + (lane >> 4), sl = lane & 15;
+            const int hy = hp / SC_HPW, hx = hp - hy * SC_HPW;
+            const int ch = sl ^ ((hx & 3) << 2);                              // (hx & 3 == lane >> 4: the lane's channel chunk never changes)
+            prel[j] = (((hy - 1) * a.W + (hx - 1)) * it.ldx + ch * 8) * 2; phyx[j] = (hy << 16) | ((hx < 18 && id < SC_PIECES) ? hx : 0x7fff);     // slots 18, 19 and dummies: never inside
+        }
+    }
+    // prologue coefficients of the lane's eight channels
+    // (they reach the registers THROUGH THE LDS: the compiler counts its own global loads in vmcnt and, at the first use inside the tile loop,
+    // waits vmcnt(0) for them on every iteration -- which also drains every LDS-DMA request of the ring, invisible to it: 5000 cycles per tile)
+    float psc[8], psh[8];
+    if constexpr (PRO) {
+        float* s_pro = (float*)(smem + SC_OFF_PRO);
+        if (tid < 128) { s_pro[tid] = it.ps[tid]; s_pro[128 + tid] = it.psh[tid]; }
+        __syncthreads();
+        const int c0 = ((lane & 15) ^ ((lane >> 4) << 2)) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { psc[e] = s_pro[c0 + e]; psh[e] = s_pro[128 + c0 + e]; }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // nothing of the compiler's own is in flight when the ring starts
+    }
+    const bool relu_on = a.pro_relu != 0;
+    // tile cursors (column strips: tile row fastest).  Two of them walk the group's run: the REQUEST cursor runs one tile in front of the
+    // MULTIPLY cursor; stepping is incremental (the two divisions of a from-scratch decode cost ~200 cycles per use)
+    struct Cur { int tyi, txi, n; };
+    auto decode = [&](int tile) { Cur c; c.tyi = tile % a.tiles_y; const int r = tile / a.tiles_y; c.txi = r % a.tiles_x; c.n = r / a.tiles_x; return c; };
+    auto step = [&](Cur& c) { if (++c.tyi == a.tiles_y) { c.tyi = 0; if (++c.txi == a.tiles_x) { c.txi = 0; ++c.n; } } };
+    auto inside = [&](int j, const Cur& c) { return (unsigned)(c.tyi * SC_TR + (phyx[j] >> 16) - 1) < (unsigned)a.H && (unsigned)(c.txi * 16 + (phyx[j] & 0xffff) - 1) < (unsigned)a.W; };
+    auto issue_slot = [&](int j, const Cur& c, int buf) {
+        const int id = j * 8 + wave;
+        const size_t pix0 = ((size_t)c.n * a.H + c.tyi * SC_TR) * a.W + c.txi * 16;       // tile origin (block-uniform)
+        const unsigned char* src;
+        if (id < SC_DY_PIECES) src = (const unsigned char*)it.dy + pix0 * it.lddy * 2 + prel[j];
+        else src = inside(j, c) ? (const unsigned char*)it.x + (long)pix0 * it.ldx * 2 + prel[j] : zsrc + (lane & 3) * 16;
+        mm_dma16(src, id < SC_PIECES ? lds0 + buf * SC_BUF + id * 1024 : lds0 + SC_OFF_DUMMY);
+    };
+    // BatchNorm + ReLU on this wave's own x pieces of a landed tile, in three steps so that the VALU work can sit BETWEEN the MFMAs of the tile
+    // before it (both waves of a SIMD transforming at once behind the barrier cost 1500 cycles per tile: 2 x 160 VALU instructions x 4 cycles):
+    // fetch (LDS -> registers), activate (a lane outside the image keeps its zeros by a select, not by a branch), put (registers -> LDS)
+    auto tf_fetch = [&](u32x4* v, int buf, int j0) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = j0 + jj;
+            const int id = j * 8 + wave;
+            if (id < SC_DY_PIECES || id >= SC_PIECES) continue;             // wave-uniform
+            v[jj] = *(const u32x4*)(smem + buf * SC_BUF + id * 1024 + lane * 16);
+        }
+    };
+    auto tf_activate = [&](u32x4& v, int j, const Cur& c) {
+        const int id = j * 8 + wave;
+        if (id < SC_DY_PIECES || id >= SC_PIECES) return;
+        // per channel pair: unpack (2), v_pk_fma_f32 (1), v_cvt_pk_bf16_f32 (1), ReLU on the PACKED pair as v_pk_max_i16 against 0 (a negative
+        // bf16 is a negative int16) (1), mask (1): 24 VALU instructions per 16 bytes instead of 40 -- the activation is what bounds this kernel
+        const unsigned okm = inside(j, c) ? 0xffffffffu : 0u;
+        typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+        typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f32x2_t q = {bf16_lo(v[e]), bf16_hi(v[e])};
+            const f32x2_t sc = {psc[2 * e], psc[2 * e + 1]}, sh = {psh[2 * e], psh[2 * e + 1]};
+            q = __builtin_elementwise_fma(q, sc, sh);
+            unsigned pk = pack_bf16x2(q[0], q[1]);
+            if (relu_on) pk = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, pk), s16x2_t{0, 0}));
+            v[e] = (pk & okm) | (v[e] & ~okm);
+        }
+    };
+    auto tf_put = [&](const u32x4* v, int buf, int j0) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = j0 + jj;
+            const int id = j * 8 + wave;
+            if (id < SC_DY_PIECES || id >= SC_PIECES) continue;
+            *(u32x4*)(smem + buf * SC_BUF + id * 1024 + lane * 16) = v[jj];
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // fragment addresses inside a buffer: dy rows of 64 B need no swizzle (four consecutive pixels x 32 B of both channel halves = 256
+    // contiguous bytes); x rows of 256 B: 64-byte segments XOR-swizzled by the halo column
+    const int prow = 8 * khalf + (li >> 2);
+    const int a_off = prow * 64 + (16 * nhalf + 4 * (li & 3)) * 2;                                       // + ty * 16 * 64
+    const int bb = (wn0 + 16 * nhalf + 4 * (li & 3)) * 2;
+    const int b0_off = SC_DYB + prow * 256 + (bb ^ ((prow & 3) << 6));                                   // + hy * SC_HPW * 256   (kw = 0)
+    const int b2_off = SC_DYB + (prow + 2) * 256 + (bb ^ (((prow + 2) & 3) << 6));                       // (kw = 2)
+
+    TSTAMP_INIT();
+    TSTAMP(90);
+    Cur cm = decode(t0), cr = cm;                // multiply / request cursors
+    if (t0 < t1) {
+#pragma unroll
+        for (int j = 0; j < SC_SLOTS; ++j) issue_slot(j, cr, 0);
+        step(cr);
+    }
+    // the two waves of a SIMD (w, w + 4) request in ANTI-PHASE: one behind tile rows 0, 2 of its K half, the other behind rows 1, 3 -- a request
+    // blocks its wave ~100 cycles and the CU accepts one per ~27, so eight waves requesting at once stall every matrix pipe for the whole burst
+    const int phase = wave >> 2;
+    int buf = 0;
+    for (int tile = t0; tile < t1; ++tile, buf ^= 1) {
+        TSTAMP(91);
+        mm_wait_vm<0>();
+        TSTAMP(92);
+        if constexpr (PRO) {
+            static_assert(SC_SLOTS % 4 == 0, "four pieces per batch");
+#pragma unroll
+            for (int j0 = 0; j0 < SC_SLOTS; j0 += 4) {
+                u32x4 v[4];
+                tf_fetch(v, buf, j0);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) tf_activate(v[jj], j0 + jj, cm);
+                tf_put(v, buf, j0);
+            }
+        }
+        TSTAMP(93);
+        mm_barrier();                  // this tile has landed and is activated; everybody is done with the other buffer
+        TSTAMP(94);
+        const bool more = tile + 1 < t1;
+        const unsigned char* sb = smem + buf * SC_BUF;
+        auto load_row = [&](int hy, u32x4* f) {
+            tr_read2(sb + b0_off + hy * (SC_HPW * 256), 4 * 256, f[0]);
+            tr_read2(sb + b2_off + hy * (SC_HPW * 256), 4 * 256, f[2]);
+            f[1][0] = __builtin_amdgcn_alignbit(f[0][1], f[0][0], 16); f[1][1] = __builtin_amdgcn_alignbit(f[0][2], f[0][1], 16);
+            f[1][2] = __builtin_amdgcn_alignbit(f[0][3], f[0][2], 16); f[1][3] = __builtin_amdgcn_alignbit(f[2][3], f[0][3], 16);
+        };
+        u32x4 rows[3][3];
+        const int r0 = 4 * kh2;
+        load_row(r0, rows[0]); load_row(r0 + 1, rows[1]);
+#pragma unroll
+        for (int tr = 0; tr < 4; ++tr) {
+            load_row(r0 + tr + 2, rows[(tr + 2) % 3]);
+            u32x4 af;
+            tr_read2(sb + a_off + (r0 + tr) * (16 * 64), 4 * 64, af);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, rows[(tr + kh) % 3][kw]),
+                                                                             acc[kh * 3 + kw], 0, 0, 0);
+            if ((tr & 1) == phase && more) {
+                const int k = tr >> 1;                                       // slots 0-3 behind the first row of this wave's phase, 4-7 behind the second
+#pragma unroll
+                for (int j = 0; j < 4; ++j) issue_slot(4 * k + j, cr, buf ^ 1);
+            }
+        }
+        if (more) step(cr);
+        step(cm);
+        TSTAMP(96);
+    }
+    TSTAMP(97);
+    mm_wait_vm<0>();
+    __syncthreads();
+    // ---- the two K halves are summed through the LDS (three taps per round: 4 waves x 3 x 16 x 64 floats = 48 KB), then the partial gradient of
+    // this pixel group goes out as ws[gx][tap][co][ci]
+    const int lr = lane & 31, lh = lane >> 5;
+    float* red = (float*)smem;
+    float* wsg = it.ws + (size_t)gx * (9 * 32 * 128);
+#pragma unroll
+    for (int round = 0; round < 3; ++round) {
+        if (kh2 == 1) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(((wave & 3) * 3 + t) * 16 + r) * 64 + lane] = acc[round * 3 + t][r];
+        }
+        __syncthreads();
+        if (kh2 == 0) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[round * 3 + t][r] + red[(((wave & 3) * 3 + t) * 16 + r) * 64 + lane];
+                    const int co = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    wsg[((size_t)(round * 3 + t) * 32 + co) * 128 + wn0 + lr] = v;       // a wave row = 128 contiguous bytes
+                }
+        }
+        __syncthreads();
+    }
+    TSTAMP(98);
+}
+
+// dw[co][ci][tap] += sum_g ws[g][tap][co][ci] for every problem of a grouped launch (blockIdx.y = problem): coalesced reads in workspace
+// order, plain adds in group order (deterministic), writes in the 9-strided parameter layout
+__global__ __launch_bounds__(256) void wgrad_reduce_tco_multi_kernel(ScArgs a, long wsize, int cc, int taps)
+{
+    const ScItem& it = a.item[blockIdx.y];
+    const float* __restrict__ ws = it.ws;
+    float* __restrict__ dw = it.dw;
+    const int groups = a.groups;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < wsize; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        int g = 0;
+        for (; g + 8 <= groups; g += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(g + u) * wsize + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; g < groups; ++g) s += ws[(size_t)g * wsize + i];
+        const long t = i / cc, r = i - t * cc;
+        dw[r * taps + t] += s;
+    }
+}
+
+// the grouped DenseNet conv2 geometry: bf16, 3x3 pad 1, every problem exactly 128 -> 32 with a prologue, maps tiling into 8 x 16 pixel tiles
+static bool wgrad_sc_supported(const saunet_wgrad_group* s)
+{
+    static const bool on = ab_env_on("SAUNET_WGRAD_SC");                // A/B switch (variant builds only)
+    if (!on || s->dtype != SAUNET_BF16 || s->KH != 3 || s->pad != 1 || s->H % SC_TR || s->W % 16 || s->count < 1) return false;
+    if ((long)s->N * s->H * s->W >= (1L << 22) * 8) return false;
+    for (int i = 0; i < s->count; ++i) {
+        const saunet_wgrad_group_item& it = s->item[i];
+        if (it.Cin != 128 || it.Cout != 32 || it.ldx % 8 || it.lddy % 8 || !it.pro_scale || !it.pro_shift) return false;
+        if ((long)s->N * s->H * s->W * (it.ldx > it.lddy ? it.ldx : it.lddy) >= (1L << 30)) return false;
+    }
+    return true;
+}
+
+static int launch_wgrad_sc(const saunet_wgrad_group* s, void* ws, size_t ws_bytes, size_t* need, hipStream_t st)
+{
+    ScArgs a;
+    a.N = s->N; a.H = s->H; a.W = s->W; a.tiles_y = s->H / SC_TR; a.tiles_x = s->W / 16; a.ntiles = s->N * a.tiles_y * a.tiles_x;
+    a.count = s->count; a.pro_relu = s->pro_relu; a.pad_ = 0;
+    // pixel groups: one workgroup per CU over all problems; at least four tiles per group (a group's prologue + epilogue cost about two)
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        (void)hipGetLastError();
+    }
+    int groups = cus / s->count; if (groups < 1) groups = 1;
+    if (groups > a.ntiles / 4) groups = a.ntiles / 4;
+    if (groups < 1) groups = 1;
+    a.groups = groups;
+    const long wsize = 9L * 32 * 128;
+    const size_t bytes = (size_t)s->count * groups * wsize * sizeof(float);
+    if (need) { *need = bytes; return SAUNET_OK; }
+    if (ws == nullptr || ws_bytes < bytes) return set_error(SAUNET_BAD_SHAPE, "grouped wgrad: workspace %zu < %zu bytes", ws_bytes, bytes);
+    for (int i = 0; i < s->count; ++i) {
+        const saunet_wgrad_group_item& it = s->item[i];
+        a.item[i] = ScItem{(const u16*)it.x, (const u16*)it.dy, (float*)ws + (size_t)i * groups * wsize, it.dw, it.pro_scale, it.pro_shift, it.ldx, it.lddy, i * groups, 0};
+    }
+    for (int i = s->count; i < SAUNET_WGRAD_GROUP_MAX; ++i) a.item[i] = ScItem{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    static DeviceOnce attr;
+    if (attr.first()) (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_sc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LDS);
+    hipLaunchKernelGGL(conv3x3_wgrad_sc_kernel<true>, dim3(s->count * groups), dim3(512), SC_LDS, st, a);
+    SAUNET_CHECK_LAUNCH("conv3x3_wgrad_sc");
+    long rb = (wsize + 255) / 256; if (rb > 36) rb = 36;
+    hipLaunchKernelGGL(wgrad_reduce_tco_multi_kernel, dim3((unsigned)rb, s->count), dim3(256), 0, st, a, wsize, 32 * 128, 9);
+    SAUNET_CHECK_LAUNCH("wgrad_reduce_tco_multi");
+    return SAUNET_OK;
+}
+
 bool tile_wgrad_grouped_supported(const saunet_wgrad_group* s)
 {
     if (s->count < 1 || s->count > SAUNET_WGRAD_GROUP_MAX) return false;
@@ -1894,6 +2204,7 @@ bool tile_wgrad_grouped_supported(const saunet_wgrad_group* s)
 int tile_wgrad_grouped(const saunet_wgrad_group* s, void* ws, size_t ws_bytes, size_t* need, hipStream_t st)
 {
     if (!tile_wgrad_grouped_supported(s)) return set_error(SAUNET_UNSUPPORTED, "grouped wgrad: geometry not on the tiled kernels");
+    if (wgrad_sc_supported(s)) return launch_wgrad_sc(s, ws, ws_bytes, need, st);
     GroupedWgradArgs g;
     g.N = s->N; g.H = s->H; g.W = s->W; g.pro_relu = s->pro_relu; g.count = s->count; g.taps = s->KH * s->KH;
     if (s->KH == 1) { g.N = (int)((long)s->N * s->H * s->W / 256); g.H = g.W = 16; }       // pixels are just rows for a 1x1 conv

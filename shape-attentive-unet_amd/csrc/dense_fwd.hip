@@ -26,7 +26,11 @@ struct DenseFwdArgs {
 };
 
 constexpr int DF_KC = 64;          // channels per stage
-constexpr int DF_RING = 4;            // requests run three stages ahead of the MFMAs (two were not enough: ~450 cycles of vmcnt wait per stage)
+#ifndef SAUNET_DF_RING
+#define SAUNET_DF_RING 4
+#endif
+constexpr int DF_RING = SAUNET_DF_RING;  // requests run DF_RING - 1 stages ahead of the MFMAs (two were not enough with ONE workgroup per CU: ~450 cycles of vmcnt wait per stage)
+constexpr int DF_AHEAD = DF_RING - 1;
 constexpr int DF_BN = 128;         // output channels (bn_size * growth)
 
 template <int BM> struct DfLayout {
@@ -127,20 +131,20 @@ __global__ __launch_bounds__(512) void dense_conv1_fwd_kernel(DenseFwdArgs a)
     TSTAMP(80);
     issue(0);
     if (a.nk > 1) issue(1);
-    if (a.nk > 2) issue(2);
+    if (DF_AHEAD > 2 && a.nk > 2) issue(2);
     bn_prologue_fill<NT>(a.bnp, a.Cin, cpad, s_pro, blockIdx.x == 0);
     __syncthreads();
     TSTAMP(81);
-    if (a.nk > 2) mm_wait_vm<2 * PER_STAGE>(); else if (a.nk > 1) mm_wait_vm<PER_STAGE>(); else mm_wait_vm<0>();
+    if (DF_AHEAD > 2 && a.nk > 2) mm_wait_vm<2 * PER_STAGE>(); else if (a.nk > 1) mm_wait_vm<PER_STAGE>(); else mm_wait_vm<0>();
     transform(0);
     mm_barrier();
     TSTAMP(82);
     for (int k = 0; k < a.nk; ++k) {
-        if (k + 3 < a.nk) issue(k + 3);
+        if (k + DF_AHEAD < a.nk) issue(k + DF_AHEAD);
         TSTAMP(83);
         if (k + 1 < a.nk) {
-            // stage k+1 was requested three stages ago; the requests of stages k+2 and k+3 may still be in flight
-            const int ahead = min(a.nk - 1, k + 3) - (k + 1);         // stages requested after k+1 (wave-uniform)
+            // stage k+1 was requested DF_AHEAD stages ago; the requests of the stages behind it may still be in flight
+            const int ahead = min(a.nk - 1, k + DF_AHEAD) - (k + 1);         // stages requested after k+1 (wave-uniform)
             if (ahead >= 2) mm_wait_vm<2 * PER_STAGE>(); else if (ahead == 1) mm_wait_vm<PER_STAGE>(); else mm_wait_vm<0>();
             TSTAMP(84);
             transform(k + 1);

@@ -84,6 +84,9 @@ def test_dense_block_fwd_bwd(dtype, tol, beta, layers, cin, shape):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("ksize,shape,chans", [(1, (4, 16, 16), [(64, 128), (96, 128), (160, 128), (288, 128)]),      # conv1 of a block: growing Cin
                                                (3, (4, 32, 32), [(128, 32)] * 5),                                      # conv2 of a block
+                                               (3, (6, 64, 48), [(128, 32)] * 3),                                      # conv3x3_wgrad_sc: 8 x 3 tiles per image, every border case, ragged tile runs per group
+                                               (3, (32, 16, 16), [(128, 32)] * 16),                                    # conv3x3_wgrad_sc at block 4's geometry: 64 tiles, 16 problems
+                                               (3, (3, 16, 16), [(128, 32)] * 2),                                      # two tiles per image, one tile column: left and right halo columns are padding
                                                (1, (8, 32, 32), [(64, 32), (32, 32)]),                                 # "small" 1x1 configuration
                                                (3, (2, 16, 48), [(64, 64), (128, 96)])])                               # larger 3x3 tiles, non-square map
 def test_grouped_weight_gradients_match_the_per_problem_launches(dtype, ksize, shape, chans):
@@ -106,8 +109,12 @@ def test_grouped_weight_gradients_match_the_per_problem_launches(dtype, ksize, s
         a = torch.relu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
         refs.append(torch.nn.grad.conv2d_weight(a, weight.shape, dy.double(), padding=pad))
     HF.GRADS.reset()
+    HF.L.load().saunet_launch_log()
     got = HF.conv_wgrad_grouped(problems, ksize, pad, True)
     assert got is not None
+    launched = HF.L.load().saunet_launch_log().decode()
+    if dtype == torch.bfloat16 and ksize == 3 and all(c == (128, 32) for c in chans) and h % 8 == 0 and w % 16 == 0:
+        assert "conv3x3_wgrad_sc" in launched and "wgrad_reduce_tco_multi" in launched, launched     # round 6: the LDS-DMA staged kernel is the one taken
     single = [HF.conv_wgrad_raw(x, dy, wt, 1, pad, pro=(p[0], p[1], True)) for (x, dy, wt, p) in problems]
     torch.cuda.synchronize()
     tol = 2e-5 if dtype == torch.float32 else 2e-3      # bf16: the prologue output is rounded to bf16 before the MFMA in both paths
