@@ -150,6 +150,15 @@ int saunet_conv2d_wgrad_deferred(const saunet_conv_desc* d, const void* x, const
                                  const float* pro_scale, const float* pro_shift, float* dw,
                                  void* workspace, int64_t workspace_bytes, saunet_wgrad_pending* pending, void* stream);
 int saunet_wgrad_reduce_multi(const saunet_wgrad_reduce_list* l, void* stream);
+/* Weight AND bias gradient of a few-output pointwise convolution in one pass (Cout <= 4: the C -> 1 side outputs c3 / c4 / c5 / phi / cw, `fuse`,
+ * `final`, /root/reference/models/models.py:286-301,324 and attention_blocks.py:150-151): dbias[co] += sum_p dy[p][co] rides as a "ones" input
+ * channel of the row-sum kernel, so the separate pass over dy (saunet_channel_sum) and its float64 -> float32 cast disappear.  dw and dbias
+ * are ACCUMULATED into (hand in zeroed buffers); workspace as for saunet_conv2d_wgrad (saunet_conv2d_wgrad_workspace(d) bytes: per-split
+ * partials + an ordered reduce, no float atomics; without it: one float atomic per value and workgroup).
+ * saunet_conv2d_wgrad_bias_supported(d) == 1 tells whether the geometry is served. */
+int saunet_conv2d_wgrad_bias_supported(const saunet_conv_desc* d);
+int saunet_conv2d_wgrad_bias(const saunet_conv_desc* d, const void* x, const void* dy, const float* pro_scale, const float* pro_shift,
+                             float* dw, float* dbias, void* workspace, int64_t workspace_bytes, void* stream);
 /* Weight gradients of up to SAUNET_WGRAD_GROUP_MAX stride-1 convolutions of ONE geometry (same N x H x W map, same kernel size 1x1 pad 0 or
  * 3x3 pad 1, same dtype; per-problem channel counts, operands, prologue vectors and gradient buffers) in ONE launch (+ one reduction launch
  * when the pixel tiles are split over several workgroups).  A DenseNet block's backward (torchvision _DenseBlock as used at

@@ -350,7 +350,8 @@ template <typename T> __global__ __launch_bounds__(256) void pointwise_cin1_kern
 struct PwWgradArgs {
     const void* x; const void* dy; float* dw; const float* ps; const float* psh;
     long P; int Cin, Cout, ldx, lddy, pro_relu; long pix_per_block; long sM, sN; int rows;
-    float* part;      // narrow kernel: per-split partial gradients [splits][Cout][Cin] (nullptr: float atomics into dw)
+    float* part;      // narrow kernel: per-split partial gradients [splits][Cout][Cin + 1] (nullptr: float atomics into dw / dbias)
+    float* dbias;     // narrow kernel: optional bias gradient sum_p dy[p][co] -- the "ones" input channel, index Cin of a partial row
 };
 template <typename T, int WPT> __global__ __launch_bounds__(256) void pointwise_wgrad_kernel(PwWgradArgs a)
 {
@@ -457,6 +458,7 @@ template <typename T, int V> __global__ __launch_bounds__(256) void pointwise_wg
     for (int j = 0; j < V; ++j) { sc[j] = a.ps ? a.ps[ci + j] : 1.f; sh[j] = a.ps ? a.psh[ci + j] : 0.f; }
     const float relu_lo = (a.ps && a.pro_relu) ? 0.f : -__builtin_inff();
     float acc[4][V];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};              // bias gradient: the threads of chunk 0 own it
 #pragma unroll
     for (int co = 0; co < 4; ++co)
 #pragma unroll
@@ -477,13 +479,16 @@ template <typename T, int V> __global__ __launch_bounds__(256) void pointwise_wg
                 for (int co = 0; co < 4; ++co) dv[u][co] = Elem<T>::load(dy + (p + (long)u * RL) * a.lddy + cco[co]);      // unconditional (clamped) loads: a load under a branch waits vmcnt(0)
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u) {
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
                     const float v = fmaxf(fmaf(xv[u][j], sc[j], sh[j]), relu_lo);
 #pragma unroll
                     for (int co = 0; co < 4; ++co) acc[co][j] = fmaf(dv[u][co], v, acc[co][j]);
                 }
+#pragma unroll
+                for (int co = 0; co < 4; ++co) bsum[co] += dv[u][co];
+            }
         }
         for (; p < p1; p += RL) {
             float xv[V];
@@ -491,6 +496,7 @@ template <typename T, int V> __global__ __launch_bounds__(256) void pointwise_wg
 #pragma unroll
             for (int co = 0; co < 4; ++co) {
                 const float d = Elem<T>::load(dy + p * a.lddy + cco[co]);
+                bsum[co] += d;
 #pragma unroll
                 for (int j = 0; j < V; ++j) acc[co][j] = fmaf(d, fmaxf(fmaf(xv[j], sc[j], sh[j]), relu_lo), acc[co][j]);
             }
@@ -508,20 +514,38 @@ template <typename T, int V> __global__ __launch_bounds__(256) void pointwise_wg
         float s = 0.f;
         for (int rr = 0; rr < RL; ++rr) s += s_part[((rr * CHB + cc) * 4 + co) * V + j];
         const int ci_o = (c0 + cc) * V + j;
-        if (a.part) a.part[((size_t)blockIdx.y * a.Cout + co) * a.Cin + ci_o] = s;      // ordered second stage: pointwise_wgrad_narrow_reduce_kernel
+        if (a.part) a.part[((size_t)blockIdx.y * a.Cout + co) * (a.Cin + 1) + ci_o] = s;      // ordered second stage: pointwise_wgrad_narrow_reduce_kernel
         else atomicAdd(a.dw + co * a.sM + (long)ci_o * a.sN, s);
+    }
+    if (a.dbias != nullptr && blockIdx.x == 0) {        // bias gradient: the RL row-threads of chunk 0, folded in row order through the (now free) LDS
+        __syncthreads();
+        if (live && c == 0) {
+#pragma unroll
+            for (int co = 0; co < 4; ++co) s_part[r * 4 + co] = bsum[co];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < a.Cout) {
+            float s = 0.f;
+            for (int rr = 0; rr < RL; ++rr) s += s_part[rr * 4 + threadIdx.x];
+            if (a.part) a.part[((size_t)blockIdx.y * a.Cout + threadIdx.x) * (a.Cin + 1) + a.Cin] = s;
+            else atomicAdd(a.dbias + threadIdx.x, s);
+        }
     }
 }
 
 // dw[co][ci] += sum over the pixel splits of part[split][co][ci]: one wave per weight, lanes stride the splits, fixed-shape fold (deterministic)
-__global__ __launch_bounds__(256) void pointwise_wgrad_narrow_reduce_kernel(const float* __restrict__ part, int splits, int nW, int Cin, float* __restrict__ dw, long sM, long sN)
+// (a partial row has Cin + 1 entries: the last one is the bias gradient, written to dbias when the caller asked for it)
+__global__ __launch_bounds__(256) void pointwise_wgrad_narrow_reduce_kernel(const float* __restrict__ part, int splits, int nW, int Cin, float* __restrict__ dw, long sM, long sN,
+                                                                            float* __restrict__ dbias)
 {
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (w >= nW) return;
+    const int co = w / (Cin + 1), ci = w - co * (Cin + 1);
+    if (ci == Cin && dbias == nullptr) return;
     float s = 0.f;
     for (int k = lane; k < splits; k += 64) s += part[(size_t)k * nW + w];
     s = wave_sum(s);
-    if (lane == 0) { const int co = w / Cin, ci = w - co * Cin; dw[co * sM + ci * sN] += s; }
+    if (lane == 0) { if (ci < Cin) dw[co * sM + ci * sN] += s; else dbias[co] += s; }
 }
 
 // Small channel counts at full resolution (d2/d3/fuse/final of the shape stream and head: Cin <= 32*CIT, Cout <= 32, bf16):
@@ -876,7 +900,7 @@ int64_t saunet_conv2d_wgrad_workspace(const saunet_conv_desc* d)
     if (narrow_wgrad_applies(d)) {           // (the query sees no pointer: it assumes 16-byte aligned operands, the widest chunk = the most splits)
         int V, ctiles; long splits, ppb;
         narrow_wgrad_plan(d, nullptr, &V, &ctiles, &splits, &ppb);
-        return splits > 1 ? (int64_t)splits * d->Cin * d->Cout * (int64_t)sizeof(float) : 0;
+        return (int64_t)splits * (d->Cin + 1) * d->Cout * (int64_t)sizeof(float);
     }
     if (convt_direct(d)) {
         size_t need = 0;
@@ -925,8 +949,32 @@ int saunet_wgrad_reduce_multi(const saunet_wgrad_reduce_list* l, void* stream)
     return wgrad_reduce_multi(l, (hipStream_t)stream);
 }
 
+static int conv2d_wgrad_impl(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw, float* dbias,
+                             void* workspace, int64_t workspace_bytes, saunet_wgrad_pending* pending, void* stream);
+
 int saunet_conv2d_wgrad_deferred(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw,
                                  void* workspace, int64_t workspace_bytes, saunet_wgrad_pending* pending, void* stream)
+{
+    return conv2d_wgrad_impl(d, x, dy, ps, psh, dw, nullptr, workspace, workspace_bytes, pending, stream);
+}
+
+int saunet_conv2d_wgrad_bias_supported(const saunet_conv_desc* d)
+{
+    saunet_conv_desc flat;
+    if (is_pointwise(d) && dense_pointwise_rows(d, &flat)) d = &flat;
+    return narrow_wgrad_applies(d) ? 1 : 0;
+}
+
+int saunet_conv2d_wgrad_bias(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw, float* dbias,
+                             void* workspace, int64_t workspace_bytes, void* stream)
+{
+    if (!dbias) return set_error(SAUNET_BAD_SHAPE, "wgrad_bias: no bias gradient buffer");
+    if (!saunet_conv2d_wgrad_bias_supported(d)) return set_error(SAUNET_UNSUPPORTED, "wgrad_bias: geometry not served (saunet_conv2d_wgrad_bias_supported)");
+    return conv2d_wgrad_impl(d, x, dy, ps, psh, dw, dbias, workspace, workspace_bytes, nullptr, stream);
+}
+
+static int conv2d_wgrad_impl(const saunet_conv_desc* d, const void* x, const void* dy, const float* ps, const float* psh, float* dw, float* dbias,
+                             void* workspace, int64_t workspace_bytes, saunet_wgrad_pending* pending, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (pending) { pending->ws = nullptr; pending->dw = nullptr; pending->wsize = 0; pending->groups = 0; pending->reserved = 0; }
@@ -944,13 +992,15 @@ int saunet_conv2d_wgrad_deferred(const saunet_conv_desc* d, const void* x, const
         return tile_wgrad(d, x, dy, ps, psh, dw, workspace, (size_t)workspace_bytes, nullptr, false, st, pending);
     if (!is_pointwise(d)) return set_error(SAUNET_UNSUPPORTED, "wgrad: %dx%d Cin=%d Cout=%d has no kernel", d->KH, d->KW, d->Cin, d->Cout);
     const int nW = d->Cin * d->Cout;
-    PwWgradArgs a{x, dy, dw, ps, psh, (long)d->N * d->H * d->W, d->Cin, d->Cout, d->ldx, d->ldy, d->pro_relu, 0, (long)d->Cin, 1, 32, nullptr};
+    PwWgradArgs a{x, dy, dw, ps, psh, (long)d->N * d->H * d->W, d->Cin, d->Cout, d->ldx, d->ldy, d->pro_relu, 0, (long)d->Cin, 1, 32, nullptr, nullptr};
     if (narrow_wgrad_applies(d)) {
         int V, ctiles; long splits;
         narrow_wgrad_plan(d, x, &V, &ctiles, &splits, &a.pix_per_block);
-        const size_t need = (size_t)splits * nW * sizeof(float);
+        const int nWp = d->Cout * (d->Cin + 1);                // a partial row carries the bias gradient as input channel Cin
+        const size_t need = (size_t)splits * nWp * sizeof(float);
+        a.dbias = dbias;
         // with caller scratch: per-split partials + an ordered reduce (deterministic, no contended atomics); without: one float atomic per weight and block
-        a.part = (workspace != nullptr && (size_t)workspace_bytes >= need && splits > 1) ? (float*)workspace : nullptr;
+        a.part = (workspace != nullptr && (size_t)workspace_bytes >= need && (splits > 1 || dbias != nullptr)) ? (float*)workspace : nullptr;
         const size_t lds = sizeof(float) * 256 * 4 * V;
 #define PW_NARROW(TT, VV) hipLaunchKernelGGL((pointwise_wgrad_narrow_kernel<TT, VV>), dim3(ctiles, (unsigned)splits), dim3(256), lds, st, a)
         if (d->dtype == SAUNET_F32) { if (V == 4) PW_NARROW(float, 4); else if (V == 2) PW_NARROW(float, 2); else PW_NARROW(float, 1); }
@@ -958,7 +1008,7 @@ int saunet_conv2d_wgrad_deferred(const saunet_conv_desc* d, const void* x, const
 #undef PW_NARROW
         SAUNET_CHECK_LAUNCH("pointwise_wgrad_narrow");
         if (a.part) {
-            hipLaunchKernelGGL(pointwise_wgrad_narrow_reduce_kernel, dim3((nW + 3) / 4), dim3(256), 0, st, a.part, (int)splits, nW, d->Cin, dw, a.sM, a.sN);
+            hipLaunchKernelGGL(pointwise_wgrad_narrow_reduce_kernel, dim3((nWp + 3) / 4), dim3(256), 0, st, a.part, (int)splits, nWp, d->Cin, dw, a.sM, a.sN, dbias);
             SAUNET_CHECK_LAUNCH("pointwise_wgrad_narrow_reduce");
         }
         return SAUNET_OK;

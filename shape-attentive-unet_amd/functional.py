@@ -459,6 +459,30 @@ def conv_wgrad_raw(x, dy, weight, stride, pad, transposed=False, pro=None, pendi
     return _conv_wgrad_impl(x, dy, weight, stride, pad, transposed, pro, pending)
 
 
+WGRAD_BIAS_FUSED = os.environ.get("SAUNET_WGRAD_BIAS_FUSED", "1") != "0"      # bias gradient of the few-output 1x1 layers inside their weight-gradient pass (A/B, tests)
+
+
+def conv_wgrad_bias_raw(x, dy, weight, stride, pad):
+    """(dw, dbias) of a plain convolution in ONE pass where the library has a kernel for it (saunet_conv2d_wgrad_bias_supported: pointwise,
+    Cout <= 4), else None -- the caller then runs conv_wgrad_raw + channel_sum."""
+    if not WGRAD_BIAS_FUSED:
+        return None
+    x = nhwc(x); dy = nhwc(dy)
+    cout, _, kh, kw = weight.shape
+    d = _desc(x, cout, ld_of(dy), dy.shape[2], dy.shape[3], kh, kw, stride, pad, False, False)
+    lib = L.load()
+    if lib.saunet_conv2d_wgrad_bias_supported(C.byref(d)) != 1:
+        return None
+    need = lib.saunet_conv2d_wgrad_workspace(C.byref(d))
+    if need < 0:
+        return None
+    dw = GRADS.take(weight.numel(), x.device).view(weight.shape)         # zeroed arena: both gradients are accumulated into
+    db = GRADS.take(cout, x.device)
+    ws = torch.empty(max(need, 4) // 4, dtype=torch.float32, device=x.device)
+    L.call("saunet_conv2d_wgrad_bias", C.byref(d), x.data_ptr(), dy.data_ptr(), None, None, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), need, L.stream())
+    return dw, db
+
+
 def flush_wgrad_reductions(pending):
     """dw += sum over groups of the partial gradients, for every entry collected by conv_wgrad_raw(..., pending=list): ONE launch per 64."""
     for i in range(0, len(pending), L.WGRAD_REDUCE_MAX):
@@ -724,6 +748,10 @@ class _Conv(torch.autograd.Function):
         stride, pad, transposed, has_bias = ctx.cfg
         dy = nhwc(dy)
         dx = conv_dgrad_raw(dy, weight, x.shape, stride, pad, transposed) if ctx.needs_input_grad[0] else None
+        if has_bias and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and not transposed and x.is_cuda:
+            both = conv_wgrad_bias_raw(x, dy, weight, stride, pad)       # few-output 1x1 layers: the bias gradient rides in the weight-gradient pass
+            if both is not None:
+                return dx, both[0], both[1], None, None, None
         dw = conv_wgrad_raw(x, dy, weight, stride, pad, transposed) if ctx.needs_input_grad[1] else None
         db = channel_sum(dy) if has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None, None, None

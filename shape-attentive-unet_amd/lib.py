@@ -98,6 +98,8 @@ _SIGS = {
     "saunet_conv2d_forward_bnpro": [C.POINTER(ConvDesc), vp, vp, vp, C.POINTER(BnPrologue), vp, vp, vp, vp],
     "saunet_bn_xhat": [i32, vp, vp, i32, i32, f64, f32, vp, i32, vp],
     "saunet_conv2d_wgrad": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i64, vp],
+    "saunet_conv2d_wgrad_bias": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, i64, vp],
+    "saunet_conv2d_wgrad_bias_supported": [C.POINTER(ConvDesc)],
     "saunet_conv2d_wgrad_workspace": [C.POINTER(ConvDesc)],
     "saunet_conv2d_wgrad_deferred": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i64, C.POINTER(WgradPending), vp],
     "saunet_wgrad_reduce_multi": [C.POINTER(WgradReduceList), vp],

@@ -336,6 +336,35 @@ def test_pixel_acc_and_jaccard_with_the_reference_signatures():
         base.pixel_acc(sc[:, :3], seg, 4)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 1, 32, 32), (3, 32, 4, 24, 40), (2, 2, 1, 64, 64), (1, 1024, 1, 16, 16), (2, 24, 3, 8, 8)])
+def test_few_output_weight_and_bias_gradient_in_one_pass(dtype, n, cin, cout, h, w):
+    """saunet_conv2d_wgrad_bias (round 6): dW and dbias of the few-output 1x1 layers (c3 / c4 / c5 / phi / cw / fuse / final,
+    /root/reference/models/models.py:286-301,324) from ONE pass -- per-split partials with the bias as a ones-channel, ordered reduce -- against
+    float64 autograd, and bit-identical from run to run (no float atomics on this path)."""
+    hf = HF()
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = to_dev(torch.randn(n, cin, h, w, generator=g), dtype)
+    dy = to_dev(torch.randn(n, cout, h, w, generator=g), dtype)
+    wt = torch.nn.Parameter(torch.zeros(cout, cin, 1, 1, device="cuda"))
+    entries, orig = [], hf.L.call
+    hf.L.call = lambda name, *a: (entries.append(name), orig(name, *a))[1]
+    try:
+        hf.GRADS.reset()
+        dw, db = hf.conv_wgrad_bias_raw(x, dy, wt, 1, 0)
+        dw1, db1 = dw.clone(), db.clone()
+        hf.GRADS.reset()
+        dw2, db2 = hf.conv_wgrad_bias_raw(x, dy, wt, 1, 0)
+    finally:
+        hf.L.call = orig
+    assert entries.count("saunet_conv2d_wgrad_bias") == 2
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2)                   # deterministic
+    xr, dyr = x.double().cpu(), dy.double().cpu()
+    ref_w = torch.einsum("nohw,nihw->oi", dyr, xr).view(cout, cin, 1, 1)
+    ref_b = dyr.sum((0, 2, 3))
+    close(dw1, ref_w, 1e-5, "dW"); close(db1, ref_b, 1e-5, "dbias")
+
+
 def test_canny_bit_exact_with_oracle():
     from oracle import canny as oc, weights as Wt
     hf = HF()
