@@ -144,7 +144,7 @@ int saunet_conv2d_wgrad(const saunet_conv_desc* d, const void* x, const void* dy
  * saunet_wgrad_reduce_multi performs up to SAUNET_WGRAD_REDUCE_MAX pending reductions in ONE launch (dw[i] += sum over groups, no atomics)
  * -- a DenseNet block's backward issues two weight gradients per layer, i.e. 116 tiny reduce launches per step otherwise. */
 #define SAUNET_WGRAD_REDUCE_MAX 64
-typedef struct saunet_wgrad_pending { const float* ws; float* dw; int64_t wsize; int32_t groups, reserved; } saunet_wgrad_pending;
+typedef struct saunet_wgrad_pending { const float* ws; float* dw; int64_t wsize; int32_t groups, taps; } saunet_wgrad_pending;   /* taps = 9 / 16: partials are [tap][wsize / taps], dw is [wsize / taps][tap]; 0: same layout (filled in by the library) */
 typedef struct saunet_wgrad_reduce_list { int32_t count, reserved; saunet_wgrad_pending item[SAUNET_WGRAD_REDUCE_MAX]; } saunet_wgrad_reduce_list;
 int saunet_conv2d_wgrad_deferred(const saunet_conv_desc* d, const void* x, const void* dy,
                                  const float* pro_scale, const float* pro_shift, float* dw,

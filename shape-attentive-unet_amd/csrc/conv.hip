@@ -944,8 +944,9 @@ int saunet_wgrad_reduce_multi(const saunet_wgrad_reduce_list* l, void* stream)
 {
     if (l->count < 1 || l->count > SAUNET_WGRAD_REDUCE_MAX) return set_error(SAUNET_BAD_SHAPE, "wgrad_reduce_multi: %d entries", l->count);
     for (int e = 0; e < l->count; ++e)
-        if (!l->item[e].ws || !l->item[e].dw || l->item[e].wsize < 1 || l->item[e].groups < 1)
-            return set_error(SAUNET_BAD_SHAPE, "wgrad_reduce_multi: entry %d is empty", e);
+        if (!l->item[e].ws || !l->item[e].dw || l->item[e].wsize < 1 || l->item[e].groups < 1 || (l->item[e].taps != 0 && l->item[e].taps != 9 && l->item[e].taps != 16) ||
+            (l->item[e].taps > 0 && l->item[e].wsize % l->item[e].taps))
+            return set_error(SAUNET_BAD_SHAPE, "wgrad_reduce_multi: entry %d is empty or malformed", e);
     return wgrad_reduce_multi(l, (hipStream_t)stream);
 }
 
@@ -977,7 +978,7 @@ static int conv2d_wgrad_impl(const saunet_conv_desc* d, const void* x, const voi
                              void* workspace, int64_t workspace_bytes, saunet_wgrad_pending* pending, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (pending) { pending->ws = nullptr; pending->dw = nullptr; pending->wsize = 0; pending->groups = 0; pending->reserved = 0; }
+    if (pending) { pending->ws = nullptr; pending->dw = nullptr; pending->wsize = 0; pending->groups = 0; pending->taps = 0; }
     // (operands that are not 16-byte aligned -- an odd channel slice handed in through the C API -- take the generic path below; the workspace
     // query cannot see pointers and sizes for the direct kernel, which is the larger of the two)
     if (ps == nullptr && convt_direct(d) && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0)

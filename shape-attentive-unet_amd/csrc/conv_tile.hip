@@ -1329,7 +1329,7 @@ template <typename T, int KS, int TR, int CO_T, int CI_T, int WM, int WN, int KS
     static const KName kn("conv_tile_wgrad_kernel", type_name<T>(), KS, TR, CO_T, CI_T, WM, WN, KSPLIT, ALIGNED);
     SAUNET_CHECK_LAUNCH(kn.s);
     if (a.pend) {
-        a.pend->ws = a.ws; a.pend->dw = a.dw; a.pend->wsize = a.wsize; a.pend->groups = groups; a.pend->reserved = 0;
+        a.pend->ws = a.ws; a.pend->dw = a.dw; a.pend->wsize = a.wsize; a.pend->groups = groups; a.pend->taps = 0;
         return SAUNET_OK;
     }
     long rb = (a.wsize + 255) / 256; if (rb > 2048) rb = 2048;
@@ -1525,29 +1525,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_mm_kernel(WgradMmArgs a)
     TSTAMP(86);
 }
 
-// dw[co][ci][tap] += sum_g ws[g][tap][co][ci]: reads in workspace order (coalesced, the bulk), writes the 9-strided parameter layout
-__global__ __launch_bounds__(256) void wgrad_reduce_tco_kernel(const float* __restrict__ ws, long wsize, int groups, int cc, int taps, float* __restrict__ dw)
+int wgrad_reduce_multi(const saunet_wgrad_reduce_list* l, hipStream_t st);
+// dw[co][ci][tap] += sum_g ws[g][tap][co][ci] of ONE problem: a one-entry list for wgrad_reduce_multi_kernel (LDS-transposed, contiguous writes)
+static int wgrad_reduce_tco_one(const float* ws, float* dw, long wsize, int groups, int taps, hipStream_t st)
 {
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < wsize; i += (long)gridDim.x * 256) {
-        float s = 0.f;
-        int g = 0;
-        for (; g + 8 <= groups; g += 8) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(g + u) * wsize + i];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
-        }
-        for (; g < groups; ++g) s += ws[(size_t)g * wsize + i];
-        const long t = i / cc, r = i - t * cc;          // cc = channel pairs of the parameter (its first two dimensions)
-        dw[r * taps + t] += s;
-    }
+    saunet_wgrad_reduce_list l; l.count = 1; l.reserved = 0;
+    l.item[0].ws = ws; l.item[0].dw = dw; l.item[0].wsize = wsize; l.item[0].groups = groups; l.item[0].taps = taps;
+    return wgrad_reduce_multi(&l, st);
 }
 
 bool wgrad_mm_supported(const TileWgradArgs& a, int ks, int dtype, bool aligned)
 {
     static const bool on = ab_env_on("SAUNET_WGRAD_MM");                // A/B switch (variant builds only)
-    return on && aligned && dtype == SAUNET_BF16 && ks == 3 && a.pro_scale == nullptr && a.pend == nullptr && a.Cout % 64 == 0 && a.Cin % 128 == 0 && a.H % 8 == 0 && a.W % 16 == 0 &&
+    return on && aligned && dtype == SAUNET_BF16 && ks == 3 && a.pro_scale == nullptr && a.Cout % 64 == 0 && a.Cin % 128 == 0 && a.H % 8 == 0 && a.W % 16 == 0 &&
            a.ldx % 8 == 0 && a.lddy % 8 == 0 && (long)a.N * a.H * a.W * (a.ldx > a.lddy ? a.ldx : a.lddy) < (1L << 30);
 }
 
@@ -1569,10 +1559,11 @@ int launch_wgrad_mm(TileWgradArgs& t, size_t ws_bytes, size_t* need, hipStream_t
     if (attr.first()) (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_mm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     hipLaunchKernelGGL(conv3x3_wgrad_mm_kernel, dim3(groups, chan_tiles), dim3(512), LDS, st, a);
     SAUNET_CHECK_LAUNCH("conv3x3_wgrad_mm");
-    long rb = (a.wsize + 255) / 256; if (rb > 4096) rb = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_tco_kernel, dim3((unsigned)rb), dim3(256), 0, st, t.ws, a.wsize, groups, t.Cout * t.Cin, 9, t.dw);
-    SAUNET_CHECK_LAUNCH("wgrad_reduce_tco");
-    return SAUNET_OK;
+    if (t.pend) {        // deferred: the permuting reduction ([tap][co][ci] partials -> parameter layout) runs in saunet_wgrad_reduce_multi
+        t.pend->ws = t.ws; t.pend->dw = t.dw; t.pend->wsize = a.wsize; t.pend->groups = groups; t.pend->taps = 9;
+        return SAUNET_OK;
+    }
+    return wgrad_reduce_tco_one(t.ws, t.dw, a.wsize, groups, 9, st);
 }
 
 
@@ -1584,7 +1575,7 @@ int launch_wgrad_mm(TileWgradArgs& t, size_t ws_bytes, size_t* need, hipStream_t
 //   * channel tile 128 (Cin) x 128 (Cout), 8 waves = 4 x 2 tiles of 32 x 64 channels x 4 taps (8 accumulators);
 //   * pixel tile 8 x 16 of x; LDS per buffer: x tile 32 KB + 9 x 18 pixels of D (read IN PLACE from dy with stride-2 pixel addresses) 41 KB, two
 //     buffers; one D row serves two consecutive tile rows (th = 1, 0), the tw = 1 fragment is the register shift of the tw = 0 one;
-//   * blockIdx.y = parity x channel tile; partial gradients [tap][ci][co] per pixel group, permuted by wgrad_reduce_tco_kernel.
+//   * blockIdx.y = parity x channel tile; partial gradients [tap][ci][co] per pixel group, permuted by wgrad_reduce_multi_kernel.
 struct ConvtWgradMmArgs {
     const u16* x; const u16* dy; float* ws;
     int N, H, W, Cin, ldx, Cout, lddy, tiles_x, tiles_y, ntiles, nbt, nct;
@@ -1731,14 +1722,15 @@ __global__ __launch_bounds__(512, 2) void convt_wgrad_mm_kernel(ConvtWgradMmArgs
         }
 }
 
-bool convt_wgrad_mm_supported(const saunet_conv_desc* d, const saunet_wgrad_pending* pend)
+bool convt_wgrad_mm_supported(const saunet_conv_desc* d)
 {
     static const bool on = ab_env_on("SAUNET_WGRAD_MM");                // A/B switch (variant builds only)
-    return on && pend == nullptr && d->Cin % 128 == 0 && d->Cout % 128 == 0 && d->H % 8 == 0 && d->W % 16 == 0 &&
+    return on && d->Cin % 128 == 0 && d->Cout % 128 == 0 && d->H % 8 == 0 && d->W % 16 == 0 &&
            (long)d->N * d->Ho * d->Wo * d->ldy < (1L << 30) && (long)d->N * d->H * d->W * d->ldx < (1L << 30);
 }
 
-int launch_convt_wgrad_mm(const saunet_conv_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, size_t* need, hipStream_t st)
+int launch_convt_wgrad_mm(const saunet_conv_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, size_t* need, hipStream_t st,
+                          saunet_wgrad_pending* pend = nullptr)
 {
     ConvtWgradMmArgs a;
     a.x = (const u16*)x; a.dy = (const u16*)dy; a.ws = (float*)ws;
@@ -1756,10 +1748,8 @@ int launch_convt_wgrad_mm(const saunet_conv_desc* d, const void* x, const void* 
     if (attr.first()) (void)hipFuncSetAttribute((const void*)convt_wgrad_mm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     hipLaunchKernelGGL(convt_wgrad_mm_kernel, dim3(groups, a.nct * 4), dim3(512), LDS, st, a);
     SAUNET_CHECK_LAUNCH("convt_wgrad_mm");
-    long rb = (a.wsize + 255) / 256; if (rb > 4096) rb = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_tco_kernel, dim3((unsigned)rb), dim3(256), 0, st, (const float*)ws, a.wsize, groups, d->Cin * d->Cout, 16, dw);
-    SAUNET_CHECK_LAUNCH("wgrad_reduce_tco");
-    return SAUNET_OK;
+    if (pend) { pend->ws = (const float*)ws; pend->dw = dw; pend->wsize = a.wsize; pend->groups = groups; pend->taps = 16; return SAUNET_OK; }
+    return wgrad_reduce_tco_one((const float*)ws, dw, a.wsize, groups, 16, st);
 }
 
 bool tile_wgrad_unaligned_supported(const saunet_conv_desc* d)
@@ -1774,34 +1764,121 @@ bool tile_wgrad_supported(const saunet_conv_desc* d)
     return !d->transposed && (k3 || k1) && d->stride == 1 && d->H % TILE == 0 && d->W % TILE == 0 && d->Ho == d->H && d->Wo == d->W;
 }
 
-// all pending reductions of a list in ONE launch: blockIdx.y = entry, dw[i] += sum over the groups of ws[g][i] (no atomics: deterministic)
+// all pending reductions of a list in ONE launch: blockIdx.y = entry, dw[i] += sum over the groups of ws[g][i] (no atomics, fixed order:
+// deterministic).  Entries with many groups and few weights (res3: 512 partial copies of 2304 values) would be a chain of dependent load batches
+// on a handful of threads, so a block deals its 256 threads as (lanes x group slices): 16 slices from 128 groups, 4 from 32; slice sums are
+// folded through the LDS in slice order.
+// taps > 0: the partials are [tap][co * ci] (LDS-DMA kernels) and the parameter is [co * ci][tap].  Writing dw[r * taps + t] straight from the
+// thread that summed (t, r) is a 4-byte read-modify-write at a 36 / 64-byte stride whose neighbours are handled by far-away blocks: a whole
+// 64-byte sector in and out of HBM per value (rocprofv3, round 6: 15.7 M such values per step = 2 GB of traffic, 300 us).  So a block takes a
+// run of `lanes` channel pairs through ALL taps, transposes through the LDS and writes lanes * taps consecutive floats.
+static __host__ __device__ inline int wgrad_reduce_slices(int groups) { return groups >= 128 ? 16 : groups >= 32 ? 4 : 1; }
+
+template <int TAPS> static __device__ __forceinline__ void wgrad_reduce_tco_entry(const saunet_wgrad_pending& e, float* s_part, float* s_out)
+{
+    constexpr int PITCH = TAPS | 1;
+    const float* __restrict__ ws = e.ws;
+    float* __restrict__ dw = e.dw;
+    const long wsize = e.wsize, cc = wsize / TAPS;
+    const int groups = e.groups;
+    const int slices = wgrad_reduce_slices(groups), lanes = 256 / slices;
+    const int tid = (int)threadIdx.x, sl = tid / lanes, ln = tid - sl * lanes;
+    const int gper = (groups + slices - 1) / slices, g0 = sl * gper, g1 = min(g0 + gper, groups);
+    for (long r0 = (long)blockIdx.x * lanes; r0 < cc; r0 += (long)gridDim.x * lanes) {       // (block-uniform trip count)
+        const long r = r0 + ln;
+        if (slices == 1) {
+            float s[TAPS];
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) s[t] = 0.f;
+            if (r < cc)
+                for (int g = 0; g < groups; ++g) {
+                    const float* src = ws + (size_t)g * wsize + r;
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t) s[t] += src[(size_t)t * cc];          // TAPS independent loads in flight
+                }
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) s_out[ln * PITCH + t] = s[t];
+        } else {
+            for (int t = 0; t < TAPS; ++t) {
+                float s = 0.f;
+                if (r < cc) {
+                    const float* src = ws + (size_t)t * cc + r;
+                    int g = g0;
+                    for (; g + 8 <= g1; g += 8) {
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(g + u) * wsize];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) s += v[u];
+                    }
+                    for (; g < g1; ++g) s += src[(size_t)g * wsize];
+                }
+                s_part[(t & 1) * 256 + tid] = s;
+                __syncthreads();                                                           // (two slot sets: one barrier per tap)
+                if (sl == 0) {
+                    for (int q = 1; q < slices; ++q) s += s_part[(t & 1) * 256 + q * lanes + ln];
+                    s_out[ln * PITCH + t] = s;
+                }
+            }
+        }
+        __syncthreads();
+        const long rem = cc - r0;
+        const int nv = (int)(rem < lanes ? rem : lanes) * TAPS;
+        float* dst = dw + r0 * TAPS;
+        for (int j = tid; j < nv; j += 256) { const int q = j / TAPS; dst[j] += s_out[q * PITCH + (j - q * TAPS)]; }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(saunet_wgrad_reduce_list l)
 {
+    __shared__ float s_part[512];
+    __shared__ float s_out[256 * 17];
     const saunet_wgrad_pending& e = l.item[blockIdx.y];
+    if (e.taps == 9) { wgrad_reduce_tco_entry<9>(e, s_part, s_out); return; }
+    if (e.taps == 16) { wgrad_reduce_tco_entry<16>(e, s_part, s_out); return; }
     const float* __restrict__ ws = e.ws;
     float* __restrict__ dw = e.dw;
     const long wsize = e.wsize;
     const int groups = e.groups;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < wsize; i += (long)gridDim.x * 256) {
+    const int slices = wgrad_reduce_slices(groups), lanes = 256 / slices;
+    const int sl = (int)threadIdx.x / lanes, ln = (int)threadIdx.x - sl * lanes;
+    const int gper = (groups + slices - 1) / slices, g0 = sl * gper, g1 = min(g0 + gper, groups);
+    for (long base = (long)blockIdx.x * lanes; base < wsize; base += (long)gridDim.x * lanes) {       // (block-uniform trip count)
+        const long i = base + ln;
         float s = 0.f;
-        int g = 0;
-        for (; g + 8 <= groups; g += 8) {
-            float v[8];
+        if (i < wsize) {
+            int g = g0;
+            for (; g + 8 <= g1; g += 8) {
+                float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(g + u) * wsize + i];
+                for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(g + u) * wsize + i];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; g < g1; ++g) s += ws[(size_t)g * wsize + i];
         }
-        for (; g < groups; ++g) s += ws[(size_t)g * wsize + i];
-        dw[i] += s;
+        if (slices > 1) {
+            s_part[threadIdx.x] = s;
+            __syncthreads();
+            if (sl == 0) for (int q = 1; q < slices; ++q) s += s_part[q * lanes + ln];
+            __syncthreads();
+        }
+        if (sl == 0 && i < wsize) dw[i] += s;
     }
 }
 
 int wgrad_reduce_multi(const saunet_wgrad_reduce_list* l, hipStream_t st)
 {
-    long biggest = 1;
-    for (int e = 0; e < l->count; ++e) if (l->item[e].wsize > biggest) biggest = l->item[e].wsize;
-    long bx = (biggest + 1023) / 1024; if (bx > 256) bx = 256; if (bx < 1) bx = 1;
+    long bx = 1;
+    for (int e = 0; e < l->count; ++e) {
+        const saunet_wgrad_pending& it = l->item[e];
+        const long lanes = 256 / wgrad_reduce_slices(it.groups);
+        const long nb = it.taps > 0 ? (it.wsize / it.taps + lanes - 1) / lanes             // one run of `lanes` channel pairs (all taps) per block
+                                    : (it.wsize + 4 * lanes - 1) / (4 * lanes);             // about four chunks per block
+        if (nb > bx) bx = nb;
+    }
+    if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)bx, l->count), dim3(256), 0, st, *l);
     SAUNET_CHECK_LAUNCH("wgrad_reduce_multi");
     return SAUNET_OK;
@@ -1864,7 +1941,7 @@ static int launch_tile_wgrad_grouped(GroupedWgradArgs& g, const saunet_wgrad_gro
             l.count = g.count - i0 < SAUNET_WGRAD_REDUCE_MAX ? g.count - i0 : SAUNET_WGRAD_REDUCE_MAX;
             for (int i = 0; i < l.count; ++i) {
                 const GWItem& it = g.item[i0 + i];
-                l.item[i].ws = it.ws; l.item[i].dw = it.dw; l.item[i].wsize = (long)it.Cout * it.Cin * g.taps; l.item[i].groups = groups; l.item[i].reserved = 0;
+                l.item[i].ws = it.ws; l.item[i].dw = it.dw; l.item[i].wsize = (long)it.Cout * it.Cin * g.taps; l.item[i].groups = groups; l.item[i].taps = 0;
             }
             if (int rc = wgrad_reduce_multi(&l, st)) return rc;
         }
@@ -1889,7 +1966,7 @@ static int launch_tile_wgrad_grouped(GroupedWgradArgs& g, const saunet_wgrad_gro
 //     pieces sourced from the zero page -- padding of the ACTIVATED tensor -- are left alone);
 //   * a group owns a CONTIGUOUS run of tiles in column-strip order (tile row fastest), so the two halo rows it shares with the tile it has
 //     just finished are L2 hits on its own XCD;
-//   * partial gradients [group][tap][co][ci] (128-byte runs), permuted into the parameter layout by wgrad_reduce_tco_multi_kernel.
+//   * partial gradients [group][tap][co][ci] (128-byte runs), permuted into the parameter layout by wgrad_reduce_multi_kernel.
 struct ScItem { const u16* x; const u16* dy; float* ws; float* dw; const float* ps; const float* psh; int ldx, lddy, blk0, pad_; };
 struct ScArgs { int N, H, W, tiles_x, tiles_y, ntiles, groups, count, pro_relu, pad_; ScItem item[SAUNET_WGRAD_GROUP_MAX]; };
 static __device__ u32x4 g_sc_zeros[4];
@@ -2109,30 +2186,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_sc_kernel(ScArgs a)
     TSTAMP(98);
 }
 
-// dw[co][ci][tap] += sum_g ws[g][tap][co][ci] for every problem of a grouped launch (blockIdx.y = problem): coalesced reads in workspace
-// order, plain adds in group order (deterministic), writes in the 9-strided parameter layout
-__global__ __launch_bounds__(256) void wgrad_reduce_tco_multi_kernel(ScArgs a, long wsize, int cc, int taps)
-{
-    const ScItem& it = a.item[blockIdx.y];
-    const float* __restrict__ ws = it.ws;
-    float* __restrict__ dw = it.dw;
-    const int groups = a.groups;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < wsize; i += (long)gridDim.x * 256) {
-        float s = 0.f;
-        int g = 0;
-        for (; g + 8 <= groups; g += 8) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(g + u) * wsize + i];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
-        }
-        for (; g < groups; ++g) s += ws[(size_t)g * wsize + i];
-        const long t = i / cc, r = i - t * cc;
-        dw[r * taps + t] += s;
-    }
-}
-
 // the grouped DenseNet conv2 geometry: bf16, 3x3 pad 1, every problem exactly 128 -> 32 with a prologue, maps tiling into 8 x 16 pixel tiles
 static bool wgrad_sc_supported(const saunet_wgrad_group* s)
 {
@@ -2176,10 +2229,11 @@ static int launch_wgrad_sc(const saunet_wgrad_group* s, void* ws, size_t ws_byte
     if (attr.first()) (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_sc_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LDS);
     hipLaunchKernelGGL(conv3x3_wgrad_sc_kernel<true>, dim3(s->count * groups), dim3(512), SC_LDS, st, a);
     SAUNET_CHECK_LAUNCH("conv3x3_wgrad_sc");
-    long rb = (wsize + 255) / 256; if (rb > 36) rb = 36;
-    hipLaunchKernelGGL(wgrad_reduce_tco_multi_kernel, dim3((unsigned)rb, s->count), dim3(256), 0, st, a, wsize, 32 * 128, 9);
-    SAUNET_CHECK_LAUNCH("wgrad_reduce_tco_multi");
-    return SAUNET_OK;
+    // dw[co][ci][tap] += sum_g ws[g][tap][co][ci] for every problem of the launch: one multi-entry reduction
+    static_assert(SAUNET_WGRAD_GROUP_MAX <= SAUNET_WGRAD_REDUCE_MAX, "one reduce list per grouped launch");
+    saunet_wgrad_reduce_list l; l.count = s->count; l.reserved = 0;
+    for (int i = 0; i < s->count; ++i) { l.item[i].ws = a.item[i].ws; l.item[i].dw = a.item[i].dw; l.item[i].wsize = wsize; l.item[i].groups = groups; l.item[i].taps = 9; }
+    return wgrad_reduce_multi(&l, st);
 }
 
 bool tile_wgrad_grouped_supported(const saunet_wgrad_group* s)
@@ -2292,15 +2346,15 @@ int tile_wgrad_convt(const saunet_conv_desc* d, const void* x, const void* dy, f
     a.xs_p = 2L * d->ldy; a.xs_r = 2L * d->Wo * d->ldy; a.xs_n = (long)d->Ho * d->Wo * d->ldy; a.Wo = d->Wo; a.ncot = 0;
     a.sM = (long)d->Cout * 16; a.sN = 16;     // dw[ci][co][kh][kw]
     if (!need && (((uintptr_t)x | (uintptr_t)dy) & 15)) return set_error(SAUNET_BAD_ALIGN, "conv-transpose wgrad: pointers must be 16-byte aligned");
-    if (convt_wgrad_mm_supported(d, pend)) {
-        if (need) {      // (a deferred call -- pend -- takes the tiled kernel: size for both)
+    if (convt_wgrad_mm_supported(d)) {
+        if (need) {      // (the query sees no operands: size for both kernels)
             size_t n1 = 0, n2 = 0;
             if (int rc = launch_convt_wgrad_mm(d, x, dy, dw, ws, 0, &n1, st)) return rc;
             if (int rc = launch_tile_wgrad<u16, 2, 8, 64, 64, 32, 32, 1>(a, 0, &n2, st)) return rc;
             *need = n1 > n2 ? n1 : n2;
             return SAUNET_OK;
         }
-        return launch_convt_wgrad_mm(d, x, dy, dw, ws, ws_bytes, nullptr, st);
+        return launch_convt_wgrad_mm(d, x, dy, dw, ws, ws_bytes, nullptr, st, pend);
     }
     // (measured at dec4, 189 us: a 128 x 64 channel tile with 64 x 32 per wave -- each haloed-operand fragment feeding two MFMAs -- 264 us; the register
     // prefetch of the next tile, which fits here without spills, 194 us: the tile loop is bound by the transposing LDS fragment reads, not by load latency)

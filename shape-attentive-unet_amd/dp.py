@@ -18,6 +18,7 @@ import torch
 import torch.distributed as dist
 
 from . import lib as L
+from . import functional as HF
 
 
 def init_from_env(backend=None):
@@ -148,6 +149,7 @@ class GradientBuckets:
         return [g for g, _ in pairs], [v for _, v in pairs]
 
     def _launch(self, b):
+        HF.flush_deferred_wgrads()    # weight gradients whose cross-workgroup reduction was deferred to the end of backward must be complete now
         grads, views = self._present(b)
         if len(grads) != len(self.buckets[b]):
             self.flat[b].zero_()      # first step only: slots of gradient-less parameters travel as zeros (every rank agrees)

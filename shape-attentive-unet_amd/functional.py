@@ -119,6 +119,7 @@ def begin_step():
     if stale:
         # a folded transition parked its coefficient sums and no dense block consumed them: the gradients of that backward pass were wrong
         raise RuntimeError("%d folded transition backward(s) of the previous step were never settled by a dense block" % stale)
+    del _DEFERRED[:]              # (a backward pass that died mid-way: its partial gradients are gone with the arenas)
     _DENSE_BASES.clear()          # a reserved concat buffer nobody adopted (exception, standalone stem / transition) must not outlive its step
     STATS.reset(); GRADS.reset()
     PACKS.prepack()
@@ -483,14 +484,37 @@ def conv_wgrad_bias_raw(x, dy, weight, stride, pad):
     return dw, db
 
 
+# Deferred weight-gradient reductions (round 6): every layer that goes through _conv_wgrad_impl with a leaf parameter leaves its per-group partial
+# gradients in its workspace and the reductions of the WHOLE backward pass run as one saunet_wgrad_reduce_multi launch from an autograd final
+# callback (30 small launches per step otherwise).  Not taken outside a backward pass, for derived weights (their gradient is consumed at once by
+# the ops that derive them) or when the parameter already holds a gradient (AccumulateGrad would add the incomplete tensor immediately).
+# SAUNET_WGRAD_DEFER=0 restores the per-layer reductions (A/B, tests).  dp.GradBuckets flushes before it packs a bucket.
+WGRAD_DEFER = os.environ.get("SAUNET_WGRAD_DEFER", "1") != "0"
+_DEFERRED = []       # (saunet_wgrad_pending, workspace tensor) of the backward pass in flight
+
+
+def _defer_ok(weight):
+    return (WGRAD_DEFER and isinstance(weight, torch.Tensor) and weight.is_leaf and weight.grad is None
+            and torch._C._current_graph_task_id() >= 0)
+
+
+def flush_deferred_wgrads():
+    """Run the reductions collected so far (no-op when there are none).  Called by the autograd engine at the end of the backward pass, on the
+    stream that surrounds the user's backward() call (which the engine has synchronised with the streams the gradients were produced on)."""
+    if _DEFERRED:
+        items = list(_DEFERRED)
+        del _DEFERRED[:]
+        flush_wgrad_reductions(items)
+
+
 def flush_wgrad_reductions(pending):
     """dw += sum over groups of the partial gradients, for every entry collected by conv_wgrad_raw(..., pending=list): ONE launch per 64."""
     for i in range(0, len(pending), L.WGRAD_REDUCE_MAX):
         chunk = pending[i:i + L.WGRAD_REDUCE_MAX]
         lst = L.WgradReduceList()
         lst.count = len(chunk)
-        for j, (p, _ws, _dw) in enumerate(chunk):
-            lst.item[j] = p
+        for j, entry in enumerate(chunk):
+            lst.item[j] = entry[0]
         L.call("saunet_wgrad_reduce_multi", C.byref(lst), L.stream())
     del pending[:]
 
@@ -572,6 +596,18 @@ def _conv_wgrad_impl(x, dy, weight, stride, pad, transposed=False, pro=None, pen
     if need < 0:
         raise RuntimeError("saunet_conv2d_wgrad_workspace failed (%d)" % need)
     ws = torch.empty(need // 4, dtype=torch.float32, device=x.device) if need > 0 else None
+    if pending is None and ws is not None and _defer_ok(weight):
+        # the cross-workgroup reduction of this layer joins ONE launch at the end of the backward pass (flush_deferred_wgrads).  Only the raw
+        # pointers are kept: a second reference to dw would make AccumulateGrad clone the (still incomplete) gradient instead of adopting it;
+        # the GRADS arena owns the memory until the next begin_step()
+        pd = L.WgradPending()
+        L.call("saunet_conv2d_wgrad_deferred", C.byref(d), x.data_ptr(), dy.data_ptr(), L.ptr(pro[0]) if pro else None,
+               L.ptr(pro[1]) if pro else None, dw.data_ptr(), L.ptr(ws), need, C.byref(pd), L.stream())
+        if pd.groups > 0:
+            if not _DEFERRED:
+                torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_wgrads)
+            _DEFERRED.append((pd, ws))
+        return dw
     if pending is not None and ws is not None:
         pd = L.WgradPending()
         L.call("saunet_conv2d_wgrad_deferred", C.byref(d), x.data_ptr(), dy.data_ptr(), L.ptr(pro[0]) if pro else None,

@@ -42,7 +42,7 @@ WGRAD_REDUCE_MAX = 64
 
 
 class WgradPending(C.Structure):
-    _fields_ = [("ws", C.c_void_p), ("dw", C.c_void_p), ("wsize", C.c_int64), ("groups", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("ws", C.c_void_p), ("dw", C.c_void_p), ("wsize", C.c_int64), ("groups", C.c_int32), ("taps", C.c_int32)]
 
 
 class WgradReduceList(C.Structure):

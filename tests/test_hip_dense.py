@@ -114,7 +114,7 @@ def test_grouped_weight_gradients_match_the_per_problem_launches(dtype, ksize, s
     assert got is not None
     launched = HF.L.load().saunet_launch_log().decode()
     if dtype == torch.bfloat16 and ksize == 3 and all(c == (128, 32) for c in chans) and h % 8 == 0 and w % 16 == 0:
-        assert "conv3x3_wgrad_sc" in launched and "wgrad_reduce_tco_multi" in launched, launched     # round 6: the LDS-DMA staged kernel is the one taken
+        assert "conv3x3_wgrad_sc" in launched and "wgrad_reduce_multi" in launched, launched     # round 6: the LDS-DMA staged kernel is the one taken
     single = [HF.conv_wgrad_raw(x, dy, wt, 1, pad, pro=(p[0], p[1], True)) for (x, dy, wt, p) in problems]
     torch.cuda.synchronize()
     tol = 2e-5 if dtype == torch.float32 else 2e-3      # bf16: the prologue output is rounded to bf16 before the MFMA in both paths

@@ -449,7 +449,9 @@ def test_deferred_wgrad_reduction_matches_the_immediate_one(dtype):
     import saunet_amd as S
     HF = S.functional
     torch.manual_seed(3)
-    cases = [(2, 64, 32, 32, 32, 3), (2, 96, 32, 32, 128, 1), (1, 128, 16, 48, 32, 3)]
+    # (the last three: many pixel groups over a tiny weight tensor -- the sliced fold of the multi kernel; the LDS-DMA kernel of the decoder's
+    # c3x3rb geometry, whose [tap][co][ci] partials the multi kernel permutes; few groups)
+    cases = [(2, 64, 32, 32, 32, 3), (2, 96, 32, 32, 128, 1), (1, 128, 16, 48, 32, 3), (4, 16, 64, 64, 16, 3), (2, 128, 32, 32, 64, 3), (1, 256, 16, 16, 128, 3)]
     pend, deferred, immediate = [], [], []
     for (n, cin, h, w, cout, k) in cases:
         x = torch.randn(n, cin, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
@@ -463,6 +465,80 @@ def test_deferred_wgrad_reduction_matches_the_immediate_one(dtype):
     assert not pend
     for a, b in zip(deferred, immediate):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+def test_deferred_conv_transpose_wgrad_reduction():
+    """ConvTranspose2d(4, 2, 1) weight gradient on the LDS-DMA kernel with its permuting reduction deferred (taps = 16) against the immediate one"""
+    import saunet_amd as S
+    HF = S.functional
+    torch.manual_seed(5)
+    x = torch.randn(2, 128, 16, 16, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(2, 128, 32, 32, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = torch.nn.Parameter(torch.randn(128, 128, 4, 4, device="cuda") * 0.05)
+    want = HF.conv_wgrad_raw(x, dy, wt, 2, 1, transposed=True).clone()
+    pend = []
+    got = HF.conv_wgrad_raw(x, dy, wt, 2, 1, transposed=True, pending=pend)
+    assert len(pend) == 1 and pend[0][0].taps == 16
+    HF.flush_wgrad_reductions(pend)
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_backward_pass_defers_every_reduction_to_one_launch():
+    """Inside a backward pass the per-layer reductions are collected and run by ONE saunet_wgrad_reduce_multi launch from the autograd engine's
+    final callback (functional._DEFERRED); the gradients equal those of the per-layer reductions (SAUNET_WGRAD_DEFER=0) and a parameter that
+    already holds a gradient is not deferred (AccumulateGrad would add the incomplete tensor)."""
+    import saunet_amd as S
+    from saunet_amd import lib as L
+    HF = S.functional
+    S.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(11)
+        ws = [torch.nn.Parameter(torch.randn(co, ci, k, k, device="cuda") * 0.05) for (co, ci, k) in ((64, 16, 3), (128, 64, 3), (32, 128, 1))]
+        x = torch.randn(2, 16, 32, 32, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+
+        def run():
+            for w in ws:
+                w.grad = None
+            y = x
+            for w in ws:
+                y = HF.conv2d(y, w, None, 1, w.shape[2] // 2)
+            names, orig, handle = [], L.call, L.load()
+
+            def traced(name, *args):          # (the launch log is per thread: read it on the thread that made the call -- autograd's worker)
+                handle.saunet_launch_log()
+                orig(name, *args)
+                names.extend(n for n in (handle.saunet_launch_log() or b"").decode().split("+") if n)
+            L.call = traced
+            try:
+                y.float().square().sum().backward()
+            finally:
+                L.call = orig
+            torch.cuda.synchronize()
+            return [w.grad.clone() for w in ws], names
+        was = HF.WGRAD_DEFER
+        try:
+            HF.WGRAD_DEFER = False
+            want, names0 = run()
+            HF.WGRAD_DEFER = True
+            got, names1 = run()
+            assert not HF._DEFERRED
+            n0 = sum(1 for n in names0 if "reduce" in n)
+            n1 = sum(1 for n in names1 if "reduce" in n)
+            assert n0 == 3 and n1 == 1, (names0, names1)
+            for a, b in zip(got, want):
+                assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+            # second backward on top of existing gradients: accumulation must see complete tensors
+            y = x
+            for w in ws:
+                y = HF.conv2d(y, w, None, 1, w.shape[2] // 2)
+            y.float().square().sum().backward()
+            torch.cuda.synchronize()
+            for w, b in zip(ws, want):
+                assert float((w.grad - 2 * b).abs().max()) <= 2e-5 * float(b.abs().max())
+        finally:
+            HF.WGRAD_DEFER = was
+    finally:
+        S.set_compute_dtype(torch.float32)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
