@@ -142,7 +142,7 @@ def kernel_roofline(S, dtype, batch, size, launch_mix=True):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # Live per-kernel census of one real training step: which kernels dominate is READ from the committed rocprofv3
 # summary of this round, and each of them is timed here over its real launch mix -- not one favourable geometry of one kernel.
-STATS_FILE = os.path.join("profiles", "r05_f_step_kernel_stats.txt")
+STATS_FILE = os.path.join("profiles", "r06_f_step_kernel_stats.txt")
 
 
 def _norm_symbol(name):
@@ -352,7 +352,7 @@ def _roofline_entry(label, ms, launches, nbytes, flops, dtype, extra=None):
 
 
 def census_roofline(S, step_fn, dtype, args):
-    """`roofline` of the bench line.  The kernel ranking is read from the committed rocprofv3 summary of this round (profiles/r05_*): its
+    """`roofline` of the bench line.  The kernel ranking is read from the committed rocprofv3 summary of this round (profiles/r06_*): its
     top three SYMBOLS are reported one by one, its largest FAMILY (all template instances of one kernel) gives the headline `frac` -- each
     timed live over its real launch mix of one step (live_kernel_census), algorithmic bytes per SURVEY 8(d), HBM traffic from the committed
     whole-step PMC passes (profiles/step_pmc.json `per_kernel`, FETCH_SIZE x 2 + WRITE_SIZE per the guide's gfx950 correction)."""

@@ -283,6 +283,21 @@ int saunet_bn_backward_apply(int dtype, const void* dy, int lddy, const void* x,
                              int relu, const double* sums, int sums_replicas, int sums_rstride, double count, int training, int accumulate,
                              void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta,
                              int64_t pixels, int C, void* stream);
+/* Residual blocks (y = relu(x*scale+shift + residual), /root/reference/models/resnet.py:54-59): the backward pass needs the ReLU decision of
+ * every element, and recomputing it means re-reading the skip tensor in both the reduce and the apply pass.  saunet_affine_act_mask also
+ * writes the decisions as bits -- relu_mask[pixel * C/8 + c/8] bit (c % 8), dense, pixels * C / 8 bytes -- and the _masked backward entries
+ * read those instead of the residual (one full-resolution tensor read less per pass).  bf16, C and strides multiples of 8, 16-byte aligned
+ * views (SAUNET_UNSUPPORTED otherwise); same sums / outputs as the unmasked entries with relu = 1. */
+int saunet_affine_act_mask(int dtype, const void* x, int ldx, const float* scale, const float* shift,
+                           const void* residual, int ldr, void* y, int ldy, int64_t pixels, int C, uint8_t* relu_mask, void* stream);
+int saunet_bn_backward_reduce_masked(int dtype, const void* dy, int lddy, const void* x, int ldx, const uint8_t* relu_mask,
+                                     const float* scale, const float* shift, const float* mean, const float* invstd,
+                                     double* sums, int replicas, int rstride, int64_t pixels, int C, void* stream);
+int saunet_bn_backward_apply_masked(int dtype, const void* dy, int lddy, const void* x, int ldx, const uint8_t* relu_mask,
+                                    const float* scale, const float* shift, const float* mean, const float* invstd,
+                                    const double* sums, int sums_replicas, int sums_rstride, double count, int training, int accumulate,
+                                    void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta,
+                                    int64_t pixels, int C, void* stream);
 
 /* "Linear" form of the BatchNorm backward used inside DenseNet, where one concat channel feeds many BatchNorms:
  *   dx_c = sum_k s_kc*g_k  -  (A_c + B_c*xhat_c),   A_c = sum_k s_kc*mean(g_k),  B_c = sum_k s_kc*mean(g_k*xhat)

@@ -166,8 +166,10 @@ __global__ void syncbn_finalize_kernel(int C, const double* __restrict__ sum, co
 template <typename T, int V>
 __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const T* __restrict__ res, int ldr, int relu,
-                                                         T* __restrict__ y, int ldy, long P, int C, long rpb)
+                                                         T* __restrict__ y, int ldy, long P, int C, long rpb, unsigned char* __restrict__ mask)
 {
+    // mask (V == 8 only): one byte per 8-channel chunk, bit j = the ReLU let channel j through -- what the backward pass of a residual block
+    // needs instead of re-reading the skip tensor (saunet_bn_backward_*_masked)
     const long p0 = blockIdx.x * rpb, p1 = min(p0 + rpb, P);
     const int CH = C / V;
     for (int cb = 0; cb < CH; cb += 256) {
@@ -181,13 +183,16 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x
             float f[V], r[V];
             ChunkIO<T, V>::load(x + p * ldx + ch * V, f);
             if (res) ChunkIO<T, V>::load(res + p * ldr + ch * V, r);
+            unsigned bits = 0;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 float v = fmaf(f[j], s[j], t[j]);
                 if (res) v += r[j];
+                bits |= (v > 0.f ? 1u : 0u) << j;
                 f[j] = relu ? fmaxf(v, 0.f) : v;
             }
             ChunkIO<T, V>::store(y + p * ldy + ch * V, f);
+            if constexpr (V == 8) { if (mask) mask[p * CH + ch] = (unsigned char)bits; }
         }
     }
 }
@@ -250,6 +255,7 @@ struct BnBwdArgs {
     double* sums; int sreps, srstride; double count; int training, accumulate;
     void* dx; int lddx; void* dres; int lddres; float* dgamma; float* dbeta;
     long P; int C; long rpb;
+    const unsigned char* mask;      // non-null (V == 8): the ReLU decisions as bits (affine_act's mask output); the pre-activation is not recomputed
 };
 
 template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a)
@@ -278,10 +284,13 @@ template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_reduc
             ChunkIO<T, V>::load(dy + p * a.lddy + ch * V, g);
             ChunkIO<T, V>::load(x + p * a.ldx + ch * V, xv);
             if (res) ChunkIO<T, V>::load(res + p * a.ldr + ch * V, r);
+            unsigned bits = 0xffu;
+            if constexpr (V == 8) { if (a.mask) bits = a.mask[p * CH + ch]; }
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 float gv = g[j];
-                if (a.relu) {
+                if (V == 8 && a.mask) { if (!((bits >> j) & 1u)) gv = 0.f; }
+                else if (a.relu) {
                     float o = fmaf(xv[j], s[j], t[j]);
                     if (res) o += r[j];
                     if (!(o > 0.f)) gv = 0.f;
@@ -337,10 +346,13 @@ template <typename T, int V> __global__ __launch_bounds__(256) void bn_bwd_apply
             ChunkIO<T, V>::load(x + p * a.ldx + ch * V, xv);
             if (res) ChunkIO<T, V>::load(res + p * a.ldr + ch * V, r);
             if (a.accumulate) ChunkIO<T, V>::load(dx + p * a.lddx + ch * V, o);
+            unsigned bits = 0xffu;
+            if constexpr (V == 8) { if (a.mask) bits = a.mask[p * CH + ch]; }
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 float gv = g[j];
-                if (a.relu) {
+                if (V == 8 && a.mask) { if (!((bits >> j) & 1u)) gv = 0.f; }
+                else if (a.relu) {
                     float ov = fmaf(xv[j], s[j], t[j]);
                     if (res) ov += r[j];
                     if (!(ov > 0.f)) gv = 0.f;
@@ -626,18 +638,33 @@ int saunet_syncbn_finalize(int C, const double* sum, const double* sumsq, int re
     return SAUNET_OK;
 }
 
-int saunet_affine_act(int dtype, const void* x, int ldx, const float* scale, const float* shift,
-                      const void* residual, int ldr, int relu, void* y, int ldy, int64_t pixels, int C, void* stream)
+static int affine_act_impl(int dtype, const void* x, int ldx, const float* scale, const float* shift, const void* residual, int ldr, int relu,
+                           void* y, int ldy, int64_t pixels, int C, unsigned char* mask, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
     const bool vec = residual ? vec_ok(dtype, C, {ldx, ldy, ldr}, {x, y, residual}) : vec_ok(dtype, C, {ldx, ldy}, {x, y});
+    if (mask && !(vec && dtype == SAUNET_BF16))
+        return set_error(SAUNET_UNSUPPORTED, "affine_act_mask: bf16, C and strides multiples of 8, 16-byte aligned views");
     int blocks; const int V = vec ? (dtype == SAUNET_BF16 ? 8 : 4) : 1;
     long rpb = rows_per_block(pixels, C, V, &blocks);
-#define CALL(TT, VV) hipLaunchKernelGGL((affine_act_kernel<TT, VV>), dim3(blocks), dim3(256), 0, st, (const TT*)x, ldx, scale, shift, (const TT*)residual, ldr, relu, (TT*)y, ldy, (long)pixels, C, rpb)
+#define CALL(TT, VV) hipLaunchKernelGGL((affine_act_kernel<TT, VV>), dim3(blocks), dim3(256), 0, st, (const TT*)x, ldx, scale, shift, (const TT*)residual, ldr, relu, (TT*)y, ldy, (long)pixels, C, rpb, mask)
     DISPATCH_TV(dtype, vec, CALL);
 #undef CALL
     CHECK_LAUNCH_TV("affine_act", dtype, vec);
     return SAUNET_OK;
+}
+
+int saunet_affine_act(int dtype, const void* x, int ldx, const float* scale, const float* shift,
+                      const void* residual, int ldr, int relu, void* y, int ldy, int64_t pixels, int C, void* stream)
+{
+    return affine_act_impl(dtype, x, ldx, scale, shift, residual, ldr, relu, y, ldy, pixels, C, nullptr, stream);
+}
+
+int saunet_affine_act_mask(int dtype, const void* x, int ldx, const float* scale, const float* shift,
+                           const void* residual, int ldr, void* y, int ldy, int64_t pixels, int C, uint8_t* relu_mask, void* stream)
+{
+    if (!relu_mask) return set_error(SAUNET_BAD_SHAPE, "affine_act_mask: no mask buffer");
+    return affine_act_impl(dtype, x, ldx, scale, shift, residual, ldr, 1, y, ldy, pixels, C, relu_mask, stream);
 }
 
 int saunet_affine_act_pool(int dtype, const void* x, int ldx, const float* scale, const float* shift, int relu, void* y, int ldy,
@@ -660,13 +687,15 @@ int saunet_affine_act_pool(int dtype, const void* x, int ldx, const float* scale
     return SAUNET_OK;
 }
 
-int saunet_bn_backward_reduce(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,
+static int bn_backward_reduce_impl(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,
                               const float* scale, const float* shift, const float* mean, const float* invstd,
-                              int relu, double* sums, int replicas, int rstride, int64_t pixels, int C, void* stream)
+                              int relu, double* sums, int replicas, int rstride, int64_t pixels, int C, const unsigned char* mask, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
     const bool vec = residual ? vec_ok(dtype, C, {lddy, ldx, ldr}, {dy, x, residual}) : vec_ok(dtype, C, {lddy, ldx}, {dy, x});
-    BnBwdArgs a{}; a.dy = dy; a.lddy = lddy; a.x = x; a.ldx = ldx; a.res = residual; a.ldr = ldr; a.scale = scale; a.shift = shift;
+    if (mask && !(vec && dtype == SAUNET_BF16))
+        return set_error(SAUNET_UNSUPPORTED, "bn_backward_reduce_masked: bf16, C and strides multiples of 8, 16-byte aligned views");
+    BnBwdArgs a{}; a.mask = mask; a.dy = dy; a.lddy = lddy; a.x = x; a.ldx = ldx; a.res = residual; a.ldr = ldr; a.scale = scale; a.shift = shift;
     a.mean = mean; a.invstd = invstd; a.relu = relu; a.sums = sums; a.sreps = replicas < 1 ? 1 : replicas; a.srstride = rstride; a.P = pixels; a.C = C;
     int blocks; const int V = vec ? (dtype == SAUNET_BF16 ? 8 : 4) : 1;
     a.rpb = rows_per_block(pixels, C, V, &blocks);
@@ -675,6 +704,21 @@ int saunet_bn_backward_reduce(int dtype, const void* dy, int lddy, const void* x
 #undef CALL
     CHECK_LAUNCH_TV("bn_bwd_reduce", dtype, vec);
     return SAUNET_OK;
+}
+
+int saunet_bn_backward_reduce(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,
+                              const float* scale, const float* shift, const float* mean, const float* invstd,
+                              int relu, double* sums, int replicas, int rstride, int64_t pixels, int C, void* stream)
+{
+    return bn_backward_reduce_impl(dtype, dy, lddy, x, ldx, residual, ldr, scale, shift, mean, invstd, relu, sums, replicas, rstride, pixels, C, nullptr, stream);
+}
+
+int saunet_bn_backward_reduce_masked(int dtype, const void* dy, int lddy, const void* x, int ldx, const uint8_t* relu_mask,
+                                     const float* scale, const float* shift, const float* mean, const float* invstd,
+                                     double* sums, int replicas, int rstride, int64_t pixels, int C, void* stream)
+{
+    if (!relu_mask) return set_error(SAUNET_BAD_SHAPE, "bn_backward_reduce_masked: no mask");
+    return bn_backward_reduce_impl(dtype, dy, lddy, x, ldx, nullptr, 0, scale, shift, mean, invstd, 1, sums, replicas, rstride, pixels, C, relu_mask, stream);
 }
 
 int saunet_bn_backward_coeff(int C, const double* sums, int sums_replicas, int sums_rstride, double count, const float* scale, float* A, float* B,
@@ -752,17 +796,19 @@ int saunet_bn_backward_correct(int dtype, void* dx, int lddx, const void* x, int
     return SAUNET_OK;
 }
 
-int saunet_bn_backward_apply(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,
+static int bn_backward_apply_impl(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,
                              const float* scale, const float* shift, const float* mean, const float* invstd,
                              int relu, const double* sums, int sums_replicas, int sums_rstride, double count, int training, int accumulate,
                              void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta,
-                             int64_t pixels, int C, void* stream)
+                             int64_t pixels, int C, const unsigned char* mask, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
     bool vec = vec_ok(dtype, C, {lddy, ldx, lddx}, {dy, x, dx});
     if (residual) vec = vec && vec_ok(dtype, C, {ldr}, {residual});
     if (dres) vec = vec && vec_ok(dtype, C, {lddres}, {dres});
-    BnBwdArgs a{}; a.dy = dy; a.lddy = lddy; a.x = x; a.ldx = ldx; a.res = residual; a.ldr = ldr; a.scale = scale; a.shift = shift;
+    if (mask && !(vec && dtype == SAUNET_BF16))
+        return set_error(SAUNET_UNSUPPORTED, "bn_backward_apply_masked: bf16, C and strides multiples of 8, 16-byte aligned views");
+    BnBwdArgs a{}; a.mask = mask; a.dy = dy; a.lddy = lddy; a.x = x; a.ldx = ldx; a.res = residual; a.ldr = ldr; a.scale = scale; a.shift = shift;
     a.mean = mean; a.invstd = invstd; a.relu = relu; a.sums = (double*)sums; a.sreps = sums_replicas < 1 ? 1 : sums_replicas; a.srstride = sums_rstride;
     a.count = count; a.training = training;
     a.accumulate = accumulate; a.dx = dx; a.lddx = lddx; a.dres = dres; a.lddres = lddres; a.dgamma = dgamma; a.dbeta = dbeta;
@@ -774,6 +820,27 @@ int saunet_bn_backward_apply(int dtype, const void* dy, int lddy, const void* x,
 #undef CALL
     CHECK_LAUNCH_TV("bn_bwd_apply", dtype, vec);
     return SAUNET_OK;
+}
+
+int saunet_bn_backward_apply(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,
+                             const float* scale, const float* shift, const float* mean, const float* invstd,
+                             int relu, const double* sums, int sums_replicas, int sums_rstride, double count, int training, int accumulate,
+                             void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta,
+                             int64_t pixels, int C, void* stream)
+{
+    return bn_backward_apply_impl(dtype, dy, lddy, x, ldx, residual, ldr, scale, shift, mean, invstd, relu, sums, sums_replicas, sums_rstride, count, training,
+                                  accumulate, dx, lddx, dres, lddres, dgamma, dbeta, pixels, C, nullptr, stream);
+}
+
+int saunet_bn_backward_apply_masked(int dtype, const void* dy, int lddy, const void* x, int ldx, const uint8_t* relu_mask,
+                                    const float* scale, const float* shift, const float* mean, const float* invstd,
+                                    const double* sums, int sums_replicas, int sums_rstride, double count, int training, int accumulate,
+                                    void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta,
+                                    int64_t pixels, int C, void* stream)
+{
+    if (!relu_mask) return set_error(SAUNET_BAD_SHAPE, "bn_backward_apply_masked: no mask");
+    return bn_backward_apply_impl(dtype, dy, lddy, x, ldx, nullptr, 0, scale, shift, mean, invstd, 1, sums, sums_replicas, sums_rstride, count, training,
+                                  accumulate, dx, lddx, dres, lddres, dgamma, dbeta, pixels, C, relu_mask, stream);
 }
 
 }  // extern "C"

@@ -693,12 +693,30 @@ def bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum, eps, training,
     return p
 
 
-def affine_act(x, scale, shift, relu, residual=None, out=None, pool=None):
-    """pool: optional float32 [N, C] tensor that receives the global average pool of the OUTPUT (SE squeeze fused into this pass)"""
+def relu_mask_ok(x, residual=None):
+    """the bit-mask forms (saunet_affine_act_mask / saunet_bn_backward_*_masked) serve bf16 tensors with 8-channel chunks"""
+    ts = [x] + ([residual] if residual is not None else [])
+    return RELU_MASK and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 and all(ld_of(t) % 8 == 0 and t.data_ptr() % 16 == 0 for t in ts)
+
+
+RELU_MASK = os.environ.get("SAUNET_RELU_MASK", "1") != "0"      # residual blocks keep their ReLU decisions as bits for the backward pass (A/B, tests)
+
+
+def affine_act(x, scale, shift, relu, residual=None, out=None, pool=None, mask=None):
+    """pool: optional float32 [N, C] tensor that receives the global average pool of the OUTPUT (SE squeeze fused into this pass)
+    mask: optional uint8 [N*H*W*C/8] tensor that receives the ReLU decisions as bits (relu_mask_ok(x, residual) must hold)"""
     x = nhwc(x)
     n, c, h, w = x.shape
     if out is None:
         out = new_act(n, c, h, w, x.dtype, x.device)
+    if mask is not None:
+        if not relu or pool is not None:
+            raise ValueError("affine_act: the ReLU bit mask needs relu=True and no pool")
+        if residual is not None:
+            residual = nhwc(residual)
+        L.call("saunet_affine_act_mask", L.dtype_code(x), x.data_ptr(), ld_of(x), L.ptr(scale), L.ptr(shift), L.ptr(residual),
+               ld_of(residual) if residual is not None else 0, out.data_ptr(), ld_of(out), n * h * w, c, mask.data_ptr(), L.stream())
+        return out
     if pool is not None:
         epc = 8 if x.dtype == torch.bfloat16 else 4
         if residual is None and c % epc == 0 and ld_of(x) % epc == 0 and ld_of(out) % epc == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0:
@@ -716,7 +734,7 @@ def affine_act(x, scale, shift, relu, residual=None, out=None, pool=None):
 
 
 def bn_backward(dy, x, p, relu, count, training, residual=None, dx=None, accumulate=False, want_dres=False, sync_group=None,
-                presums=None):
+                presums=None, mask=None):
     """Returns (dx, dres, dgamma, dbeta).  x is the tensor BN normalised (pre-affine).
     sync_group: all-reduce the two per-channel sums over that process group between the reduce and the
     apply kernel (SynchronizedBatchNorm semantics, lib/nn/modules/batchnorm.py:98-139); `count` must then
@@ -732,6 +750,11 @@ def bn_backward(dy, x, p, relu, count, training, residual=None, dx=None, accumul
     if presums is not None:
         # dy is already g = dy*[relu mask] and the two sums were taken in the producing dgrad kernel's epilogue
         st, relu = presums, False
+    elif mask is not None:
+        # the ReLU decisions of the forward pass as bits (affine_act(mask=...)): the residual is not read again
+        st = new_stats(c, dev)
+        L.call("saunet_bn_backward_reduce_masked", dt, dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), mask.data_ptr(), p.scale.data_ptr(),
+               p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), st.data_ptr(), st.shape[0], st.stride(0), P, c, L.stream())
     else:
         st = new_stats(c, dev)
         L.call("saunet_bn_backward_reduce", dt, dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), rp, rl, p.scale.data_ptr(),
@@ -750,6 +773,14 @@ def bn_backward(dy, x, p, relu, count, training, residual=None, dx=None, accumul
         dx = new_act(n, c, h, w, x.dtype, dev)
     dres = new_act(n, c, h, w, x.dtype, dev) if want_dres else None
     dgb = torch.empty(2, c, dtype=torch.float32, device=dev)
+    if mask is not None and presums is None:
+        L.call("saunet_bn_backward_apply_masked", dt, dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), mask.data_ptr(), p.scale.data_ptr(),
+               p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), sums.data_ptr(), sreps, srstr, float(count),
+               1 if training else 0, 1 if accumulate else 0, dx.data_ptr(), ld_of(dx), L.ptr(dres),
+               ld_of(dres) if dres is not None else 0, dgb[0].data_ptr(), dgb[1].data_ptr(), P, c, L.stream())
+        if local is not None:
+            return dx, dres, local[c:].float(), local[:c].float()
+        return dx, dres, dgb[0], dgb[1]
     L.call("saunet_bn_backward_apply", dt, dy.data_ptr(), ld_of(dy), x.data_ptr(), ld_of(x), rp, rl, p.scale.data_ptr(),
            p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), 1 if relu else 0, sums.data_ptr(), sreps, srstr, float(count),
            1 if training else 0, 1 if accumulate else 0, dx.data_ptr(), ld_of(dx), L.ptr(dres),
@@ -909,18 +940,23 @@ class _BasicBlock(torch.autograd.Function):
         st2 = new_stats(c, x.device) if training else None
         z2 = conv_forward_raw(z1, w2, None, 1, 1, pro=(p1.scale, p1.shift, True), stats=st2)
         p2 = bn_finalize(st2, count, g2, b2, rm2, rv2, mom2, eps2, training)
-        y = affine_act(z2, p2.scale, p2.shift, True, x)
-        ctx.save_for_backward(x, w1, w2, z1, z2, p1.buf, p2.buf)
-        ctx.cfg = (training, count)
+        # the ReLU decisions of the block's output as bits (1/16 of the tensor): bn2's backward passes then read them instead of the skip tensor
+        mask = torch.empty(z2.numel() // 8, dtype=torch.uint8, device=x.device) if relu_mask_ok(z2, x) else None
+        y = affine_act(z2, p2.scale, p2.shift, True, x, mask=mask)
+        ctx.save_for_backward(x, w1, w2, z1, z2, p1.buf, p2.buf, mask if mask is not None else z2.new_empty(0))
+        ctx.cfg = (training, count, mask is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w1, w2, z1, z2, p1b, p2b = ctx.saved_tensors
-        training, count = ctx.cfg
+        x, w1, w2, z1, z2, p1b, p2b, mask = ctx.saved_tensors
+        training, count, masked = ctx.cfg
         p1 = BNParams.__new__(BNParams); p1.buf = p1b
         p2 = BNParams.__new__(BNParams); p2.buf = p2b
-        dz2, dres, dg2, db2 = bn_backward(dy, z2, p2, True, count, training, x, want_dres=True)
+        if masked and nhwc(dy).data_ptr() % 16 == 0 and ld_of(nhwc(dy)) % 8 == 0:
+            dz2, dres, dg2, db2 = bn_backward(dy, z2, p2, True, count, training, None, want_dres=True, mask=mask)
+        else:
+            dz2, dres, dg2, db2 = bn_backward(dy, z2, p2, True, count, training, x, want_dres=True)
         dw2 = conv_wgrad_raw(z1, dz2, w2, 1, 1, pro=(p1.scale, p1.shift, True))
         s1 = new_stats(z1.shape[1], z1.device)
         da1 = conv_dgrad_raw(dz2, w2, z1.shape, 1, 1, bn_epi=(z1, p1, True, s1))

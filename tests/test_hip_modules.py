@@ -108,3 +108,65 @@ def test_fused_basic_block_matches_the_unfused_path():
         assert rel(ga[k], gb[k]) < 2e-4, k
     for k in ra:
         assert rel(ra[k], rb[k]) < 1e-5, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ch,shape", [(16, (2, 32, 48)), (64, (1, 16, 16)), (32, (3, 16, 32))])
+def test_basic_block_relu_bit_mask_is_bit_identical(ch, shape):
+    """bf16 BasicBlock with the ReLU decisions of its output kept as bits (saunet_affine_act_mask + saunet_bn_backward_*_masked, round 6)
+    against the same block re-reading the skip tensor in bn2's backward (SAUNET_RELU_MASK=0 path): the arithmetic is the same, so output,
+    input gradient and every parameter gradient must be IDENTICAL; the mask bytes themselves are checked against out > 0."""
+    import saunet_amd as S
+    HF = S.functional
+    S.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(ch)
+        blk = S.BasicBlock(ch, ch).cuda().train()
+        with torch.no_grad():
+            for m in blk.modules():
+                if hasattr(m, "running_mean") and m.weight is not None and m.weight.dim() == 1:
+                    m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+        state0 = {k: v.clone() for k, v in blk.state_dict().items()}
+        n, h, w = shape
+        x0 = torch.randn(n, ch, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        cot = torch.randn(n, ch, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        res, saved, calls = {}, HF.RELU_MASK, []
+        orig = S.lib.call
+
+        def traced(name, *a):
+            calls.append(name); return orig(name, *a)
+        try:
+            for mode in (True, False):
+                HF.RELU_MASK = mode
+                blk.load_state_dict(state0); HF.notify_params_changed(); blk.zero_grad(set_to_none=True)
+                x = x0.clone().requires_grad_(True)
+                del calls[:]
+                S.lib.call = traced
+                try:
+                    y = blk(x)
+                    (y * cot).sum().backward()
+                finally:
+                    S.lib.call = orig
+                torch.cuda.synchronize()
+                assert ("saunet_bn_backward_apply_masked" in calls) == mode and ("saunet_affine_act_mask" in calls) == mode, calls
+                res[mode] = (y.detach().clone(), x.grad.clone(), {k: v.grad.clone() for k, v in blk.named_parameters()})
+        finally:
+            HF.RELU_MASK = saved
+        (ya, dxa, ga), (yb, dxb, gb) = res[True], res[False]
+        assert torch.equal(ya, yb) and torch.equal(dxa, dxb)
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
+        # the mask itself: bit (c % 8) of byte [pixel][c / 8] is out > 0
+        z = torch.randn(n, ch, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        r = torch.randn(n, ch, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        sc = torch.rand(ch, device="cuda") + 0.5; sh = torch.randn(ch, device="cuda") * 0.2
+        mask = torch.zeros(z.numel() // 8, dtype=torch.uint8, device="cuda")
+        out = HF.affine_act(z, sc, sh, True, r, mask=mask)
+        pre = torch.addcmul(sh.view(1, -1, 1, 1), z.float(), sc.view(1, -1, 1, 1)) + r.float()      # (fmaf vs mul+add: equal sign except within an ulp of zero)
+        want = (pre > 0).permute(0, 2, 3, 1).reshape(-1, ch // 8, 8)
+        got = ((mask.view(-1, ch // 8, 1).int() >> torch.arange(8, device="cuda").view(1, 1, 8)) & 1).bool()
+        differ = (got != want)
+        assert int(differ.sum()) <= 2 and float(pre.permute(0, 2, 3, 1).reshape(-1, ch // 8, 8)[differ].abs().max() if differ.any() else 0.0) < 1e-5
+        assert torch.equal(out > 0, (got.reshape(n, h, w, ch).permute(0, 3, 1, 2)) & (out > 0))
+    finally:
+        S.set_compute_dtype(torch.float32)
