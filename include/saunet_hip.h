@@ -283,6 +283,16 @@ int saunet_bn_backward_apply(int dtype, const void* dy, int lddy, const void* x,
                              int relu, const double* sums, int sums_replicas, int sums_rstride, double count, int training, int accumulate,
                              void* dx, int lddx, void* dres, int lddres, float* dgamma, float* dbeta,
                              int64_t pixels, int C, void* stream);
+/* Consumer-side BatchNorm finalize for the conv -> BN -> act layers (models/models.py:118-123, attention_blocks.py:215-220, resnet.py:54-59):
+ * y = act(BN(x) (+residual)) with scale / shift derived INSIDE the pass from the raw batch statistics of x's producer, exactly as
+ * saunet_bn_finalize computes them (conv_bias: that entry's `conv_bias`, may be NULL; c_lo must be 0; xhat may be NULL).  One workgroup writes pro->params ([4][C]: scale, shift,
+ * mean, invstd -- what the backward entries take) and updates the running statistics.  Training mode, vector path only (SAUNET_UNSUPPORTED
+ * otherwise: run saunet_bn_finalize + saunet_affine_act).  relu_mask: optional, see saunet_affine_act_mask.  _pool_bn: the same for
+ * saunet_affine_act_pool. */
+int saunet_affine_act_bn(int dtype, const void* x, int ldx, const saunet_bn_prologue* pro, const float* conv_bias, const void* residual, int ldr, int relu,
+                         void* y, int ldy, int64_t pixels, int C, uint8_t* relu_mask, void* stream);
+int saunet_affine_act_pool_bn(int dtype, const void* x, int ldx, const saunet_bn_prologue* pro, const float* conv_bias, int relu, void* y, int ldy,
+                              int64_t pixels, int C, float* pooled, int HW, void* stream);
 /* Residual blocks (y = relu(x*scale+shift + residual), /root/reference/models/resnet.py:54-59): the backward pass needs the ReLU decision of
  * every element, and recomputing it means re-reading the skip tensor in both the reduce and the apply pass.  saunet_affine_act_mask also
  * writes the decisions as bits -- relu_mask[pixel * C/8 + c/8] bit (c % 8), dense, pixels * C / 8 bytes -- and the _masked backward entries

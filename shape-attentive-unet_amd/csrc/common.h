@@ -346,7 +346,9 @@ __device__ __forceinline__ float row_transpose_sum(const float (&e1)[8], const f
 // Consumer-side BatchNorm finalize (saunet_bn_prologue): fills s_pro[0 .. cpad) = scale and s_pro[cpad .. 2*cpad) = shift of the input
 // channels (zero beyond Cin) with the arithmetic of bn_finalize_kernel; `writer` (one workgroup of the launch) also publishes the xhat rows
 // of the channels finalised here, the [4][Cin] parameter block the backward pass reads and the running statistics.
-template <int NT> __device__ __forceinline__ void bn_prologue_fill(const saunet_bn_prologue& p, int Cin, int cpad, float* s_pro, bool writer)
+// cbias: bias of the convolution that produced the tensor (its statistics were taken before the bias was added; bn_finalize_kernel's `cbias`).
+template <int NT> __device__ __forceinline__ void bn_prologue_fill(const saunet_bn_prologue& p, int Cin, int cpad, float* s_pro, bool writer,
+                                                                   const float* __restrict__ cbias = nullptr)
 {
     for (int c = threadIdx.x; c < cpad; c += NT) {
         float sc = 0.f, sh = 0.f;
@@ -355,9 +357,10 @@ template <int NT> __device__ __forceinline__ void bn_prologue_fill(const saunet_
             if (c >= p.c_lo) {
                 double s1, s2;
                 rep_sum2(p.sum, p.sumsq, p.replicas, p.rstride, c, s1, s2);
-                const double m = s1 / p.count;
+                double m = s1 / p.count;
                 double v = s2 / p.count - m * m;
                 if (v < 0.0) v = 0.0;
+                if (cbias) m += (double)cbias[c];
                 mean = (float)m; is = (float)(1.0 / sqrt(v + (double)p.eps)); var = (float)v;
                 if (writer && p.xhat) {
                     p.xhat[c] = is; p.xhat[p.ld_xhat + c] = -mean * is; p.xhat[2 * p.ld_xhat + c] = mean; p.xhat[3 * p.ld_xhat + c] = is;

@@ -163,11 +163,22 @@ __global__ void syncbn_finalize_kernel(int C, const double* __restrict__ sum, co
     if (iter && threadIdx.x == 0) iter[0] = it_new;
 }
 
-template <typename T, int V>
+// PRO: consumer-side BatchNorm finalize (round 6): scale / shift are derived in the kernel's prologue from the raw batch statistics the
+// producing convolution accumulated (bn_prologue_fill: the arithmetic of bn_finalize_kernel, cooperatively into the LDS); workgroup 0 publishes the
+// [4][C] parameter block the backward pass reads and updates the running statistics -- the saunet_bn_finalize launch in front of every
+// conv -> BN -> act layer (33 single-workgroup launches per step) disappears.
+template <typename T, int V, bool PRO = false>
 __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const T* __restrict__ res, int ldr, int relu,
-                                                         T* __restrict__ y, int ldy, long P, int C, long rpb, unsigned char* __restrict__ mask)
+                                                         T* __restrict__ y, int ldy, long P, int C, long rpb, unsigned char* __restrict__ mask,
+                                                         saunet_bn_prologue pro, const float* __restrict__ cbias)
 {
+    extern __shared__ float s_aff[];      // PRO: [2][C]
+    if constexpr (PRO) {
+        bn_prologue_fill<256>(pro, C, C, s_aff, blockIdx.x == 0, cbias);
+        __syncthreads();
+        scale = s_aff; shift = s_aff + C;
+    }
     // mask (V == 8 only): one byte per 8-channel chunk, bit j = the ReLU let channel j through -- what the backward pass of a residual block
     // needs instead of re-reading the skip tensor (saunet_bn_backward_*_masked)
     const long p0 = blockIdx.x * rpb, p1 = min(p0 + rpb, P);
@@ -201,12 +212,16 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x
 // average pool over H x W (nn.AdaptiveAvgPool2d(1) of SEModule, /root/reference/models/attention_blocks.py:32,50) is accumulated:
 // per-thread sums -> LDS (two images at most per block: rpb <= HW) -> one float atomic per (image, channel) per block into the zeroed
 // pooled[N][C], already scaled by 1/HW.  F is never re-read for the pool.
-template <typename T, int V>
+template <typename T, int V, bool PRO = false>
 __global__ __launch_bounds__(256) void affine_act_pool_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, int relu, T* __restrict__ y, int ldy, long P, int C,
-                                                              long rpb, float* __restrict__ pooled, int HW)
+                                                              long rpb, float* __restrict__ pooled, int HW, saunet_bn_prologue pro, const float* __restrict__ cbias)
 {
-    extern __shared__ float s_pool[];   // [2][C]
+    extern __shared__ float s_pool[];   // [2][C]  (PRO: + [2][C] coefficients)
+    if constexpr (PRO) {
+        bn_prologue_fill<256>(pro, C, C, s_pool + 2 * C, blockIdx.x == 0, cbias);
+        scale = s_pool + 2 * C; shift = s_pool + 3 * C;
+    }
     for (int i = threadIdx.x; i < 2 * C; i += 256) s_pool[i] = 0.f;
     __syncthreads();
     const long p0 = blockIdx.x * rpb, p1 = min(p0 + rpb, P);
@@ -639,7 +654,8 @@ int saunet_syncbn_finalize(int C, const double* sum, const double* sumsq, int re
 }
 
 static int affine_act_impl(int dtype, const void* x, int ldx, const float* scale, const float* shift, const void* residual, int ldr, int relu,
-                           void* y, int ldy, int64_t pixels, int C, unsigned char* mask, void* stream)
+                           void* y, int ldy, int64_t pixels, int C, unsigned char* mask, void* stream, const saunet_bn_prologue* pro = nullptr,
+                           const float* cbias = nullptr)
 {
     hipStream_t st = (hipStream_t)stream;
     const bool vec = residual ? vec_ok(dtype, C, {ldx, ldy, ldr}, {x, y, residual}) : vec_ok(dtype, C, {ldx, ldy}, {x, y});
@@ -647,11 +663,41 @@ static int affine_act_impl(int dtype, const void* x, int ldx, const float* scale
         return set_error(SAUNET_UNSUPPORTED, "affine_act_mask: bf16, C and strides multiples of 8, 16-byte aligned views");
     int blocks; const int V = vec ? (dtype == SAUNET_BF16 ? 8 : 4) : 1;
     long rpb = rows_per_block(pixels, C, V, &blocks);
-#define CALL(TT, VV) hipLaunchKernelGGL((affine_act_kernel<TT, VV>), dim3(blocks), dim3(256), 0, st, (const TT*)x, ldx, scale, shift, (const TT*)residual, ldr, relu, (TT*)y, ldy, (long)pixels, C, rpb, mask)
+    if (pro) {
+        if (!vec) return set_error(SAUNET_UNSUPPORTED, "affine_act_bn: vector path only (C, strides multiples of 8 bf16 / 4 f32 elements, 16-byte aligned views)");
+        const size_t lds = sizeof(float) * 2 * C;
+        if (dtype == SAUNET_BF16)
+            hipLaunchKernelGGL((affine_act_kernel<u16, 8, true>), dim3(blocks), dim3(256), lds, st, (const u16*)x, ldx, nullptr, nullptr, (const u16*)residual, ldr, relu, (u16*)y, ldy, (long)pixels, C, rpb, mask, *pro, cbias);
+        else if (dtype == SAUNET_F32)
+            hipLaunchKernelGGL((affine_act_kernel<float, 4, true>), dim3(blocks), dim3(256), lds, st, (const float*)x, ldx, nullptr, nullptr, (const float*)residual, ldr, relu, (float*)y, ldy, (long)pixels, C, rpb, mask, *pro, cbias);
+        else return set_error(SAUNET_BAD_DTYPE, "dtype %d", dtype);
+        CHECK_LAUNCH_TV("affine_act", dtype, vec);
+        return SAUNET_OK;
+    }
+    const saunet_bn_prologue none{};
+#define CALL(TT, VV) hipLaunchKernelGGL((affine_act_kernel<TT, VV>), dim3(blocks), dim3(256), 0, st, (const TT*)x, ldx, scale, shift, (const TT*)residual, ldr, relu, (TT*)y, ldy, (long)pixels, C, rpb, mask, none, nullptr)
     DISPATCH_TV(dtype, vec, CALL);
 #undef CALL
     CHECK_LAUNCH_TV("affine_act", dtype, vec);
     return SAUNET_OK;
+}
+
+static int check_bn_prologue(const saunet_bn_prologue* pro, int C, const char* who)
+{
+    if (!pro || !pro->gamma || !pro->beta || !pro->params || !pro->sum || !pro->sumsq || pro->count < 1.0 || pro->c_lo != 0 || C > 4096 ||
+        (pro->running_mean == nullptr) != (pro->running_var == nullptr))
+        return set_error(SAUNET_BAD_SHAPE, "%s: incomplete BatchNorm prologue descriptor (c_lo must be 0, C <= 4096)", who);
+    return SAUNET_OK;
+}
+
+int saunet_affine_act_bn(int dtype, const void* x, int ldx, const saunet_bn_prologue* pro, const float* conv_bias, const void* residual, int ldr, int relu,
+                         void* y, int ldy, int64_t pixels, int C, uint8_t* relu_mask, void* stream)
+{
+    if (int rc = check_bn_prologue(pro, C, "affine_act_bn")) return rc;
+    if (relu_mask && !relu) return set_error(SAUNET_BAD_SHAPE, "affine_act_bn: a ReLU mask needs relu = 1");
+    saunet_bn_prologue p = *pro;
+    if (p.replicas < 1) p.replicas = 1;
+    return affine_act_impl(dtype, x, ldx, nullptr, nullptr, residual, ldr, relu, y, ldy, pixels, C, relu_mask, stream, &p, conv_bias);
 }
 
 int saunet_affine_act(int dtype, const void* x, int ldx, const float* scale, const float* shift,
@@ -667,11 +713,11 @@ int saunet_affine_act_mask(int dtype, const void* x, int ldx, const float* scale
     return affine_act_impl(dtype, x, ldx, scale, shift, residual, ldr, 1, y, ldy, pixels, C, relu_mask, stream);
 }
 
-int saunet_affine_act_pool(int dtype, const void* x, int ldx, const float* scale, const float* shift, int relu, void* y, int ldy,
-                           int64_t pixels, int C, float* pooled, int HW, void* stream)
+static int affine_act_pool_impl(int dtype, const void* x, int ldx, const float* scale, const float* shift, int relu, void* y, int ldy,
+                                int64_t pixels, int C, float* pooled, int HW, void* stream, const saunet_bn_prologue* pro, const float* cbias = nullptr)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (!scale || !shift || !pooled || HW <= 0 || pixels % HW) return set_error(SAUNET_BAD_SHAPE, "affine_act_pool: needs scale/shift/pooled and pixels %% HW == 0");
+    if ((!pro && (!scale || !shift)) || !pooled || HW <= 0 || pixels % HW) return set_error(SAUNET_BAD_SHAPE, "affine_act_pool: needs scale/shift/pooled and pixels %% HW == 0");
     const int epc = dtype == SAUNET_BF16 ? 8 : 4;
     if (!vec_ok(dtype, C, {ldx, ldy}, {x, y})) return set_error(SAUNET_BAD_ALIGN, "affine_act_pool: C, strides multiples of %d and 16-byte aligned views", epc);
     int blocks;
@@ -679,12 +725,35 @@ int saunet_affine_act_pool(int dtype, const void* x, int ldx, const float* scale
     if (rpb > HW) rpb = HW;                       // a block touches two images at most
     blocks = (int)((pixels + rpb - 1) / rpb);
     if (hipMemsetAsync(pooled, 0, sizeof(float) * (size_t)(pixels / HW) * C, st) != hipSuccess) return set_error(SAUNET_LAUNCH_FAILED, "affine_act_pool memset");
-    const size_t lds = sizeof(float) * 2 * C;
-    if (dtype == SAUNET_BF16) hipLaunchKernelGGL((affine_act_pool_kernel<u16, 8>), dim3(blocks), dim3(256), lds, st, (const u16*)x, ldx, scale, shift, relu, (u16*)y, ldy, (long)pixels, C, rpb, pooled, HW);
-    else if (dtype == SAUNET_F32) hipLaunchKernelGGL((affine_act_pool_kernel<float, 4>), dim3(blocks), dim3(256), lds, st, (const float*)x, ldx, scale, shift, relu, (float*)y, ldy, (long)pixels, C, rpb, pooled, HW);
-    else return set_error(SAUNET_BAD_DTYPE, "dtype %d", dtype);
+    const saunet_bn_prologue none{};
+    if (pro) {
+        const size_t lds = sizeof(float) * 4 * C;
+        if (dtype == SAUNET_BF16) hipLaunchKernelGGL((affine_act_pool_kernel<u16, 8, true>), dim3(blocks), dim3(256), lds, st, (const u16*)x, ldx, nullptr, nullptr, relu, (u16*)y, ldy, (long)pixels, C, rpb, pooled, HW, *pro, cbias);
+        else if (dtype == SAUNET_F32) hipLaunchKernelGGL((affine_act_pool_kernel<float, 4, true>), dim3(blocks), dim3(256), lds, st, (const float*)x, ldx, nullptr, nullptr, relu, (float*)y, ldy, (long)pixels, C, rpb, pooled, HW, *pro, cbias);
+        else return set_error(SAUNET_BAD_DTYPE, "dtype %d", dtype);
+    } else {
+        const size_t lds = sizeof(float) * 2 * C;
+        if (dtype == SAUNET_BF16) hipLaunchKernelGGL((affine_act_pool_kernel<u16, 8>), dim3(blocks), dim3(256), lds, st, (const u16*)x, ldx, scale, shift, relu, (u16*)y, ldy, (long)pixels, C, rpb, pooled, HW, none, nullptr);
+        else if (dtype == SAUNET_F32) hipLaunchKernelGGL((affine_act_pool_kernel<float, 4>), dim3(blocks), dim3(256), lds, st, (const float*)x, ldx, scale, shift, relu, (float*)y, ldy, (long)pixels, C, rpb, pooled, HW, none, nullptr);
+        else return set_error(SAUNET_BAD_DTYPE, "dtype %d", dtype);
+    }
     SAUNET_CHECK_LAUNCH("affine_act_pool");
     return SAUNET_OK;
+}
+
+int saunet_affine_act_pool(int dtype, const void* x, int ldx, const float* scale, const float* shift, int relu, void* y, int ldy,
+                           int64_t pixels, int C, float* pooled, int HW, void* stream)
+{
+    return affine_act_pool_impl(dtype, x, ldx, scale, shift, relu, y, ldy, pixels, C, pooled, HW, stream, nullptr);
+}
+
+int saunet_affine_act_pool_bn(int dtype, const void* x, int ldx, const saunet_bn_prologue* pro, const float* conv_bias, int relu, void* y, int ldy,
+                              int64_t pixels, int C, float* pooled, int HW, void* stream)
+{
+    if (int rc = check_bn_prologue(pro, C, "affine_act_pool_bn")) return rc;
+    saunet_bn_prologue p = *pro;
+    if (p.replicas < 1) p.replicas = 1;
+    return affine_act_pool_impl(dtype, x, ldx, nullptr, nullptr, relu, y, ldy, pixels, C, pooled, HW, stream, &p, conv_bias);
 }
 
 static int bn_backward_reduce_impl(int dtype, const void* dy, int lddy, const void* x, int ldx, const void* residual, int ldr,

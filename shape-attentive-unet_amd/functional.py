@@ -733,6 +733,42 @@ def affine_act(x, scale, shift, relu, residual=None, out=None, pool=None, mask=N
     return out
 
 
+BN_FINALIZE_FUSED = os.environ.get("SAUNET_BN_FINALIZE_FUSED", "1") != "0"     # consumer-side finalize in the BN-apply pass (A/B, tests)
+
+
+def bn_affine_act(z, stats, count, gamma, beta, rmean, rvar, momentum, eps, relu, residual=None, out=None, pool=None, mask=None, conv_bias=None):
+    """y = act(BN(z) (+residual)) in training mode from the raw statistics `stats` of z, returns (y, BNParams).  One launch where the library
+    serves the geometry (saunet_affine_act_bn / _pool_bn: the finalize happens in the pass's prologue), else bn_finalize + affine_act."""
+    z = nhwc(z)
+    n, c, h, w = z.shape
+    epc = 8 if z.dtype == torch.bfloat16 else 4
+    if residual is not None:
+        residual = nhwc(residual)
+    views = [z] + ([residual] if residual is not None else []) + ([out] if out is not None else [])
+    ok = (BN_FINALIZE_FUSED and z.is_cuda and stats is not None and z.dtype in (torch.bfloat16, torch.float32) and c % epc == 0 and c <= 4096
+          and all(ld_of(t) % epc == 0 and t.data_ptr() % 16 == 0 for t in views) and not (pool is not None and (residual is not None or mask is not None)))
+    if not ok:
+        p = bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum, eps, True, conv_bias=conv_bias)
+        return affine_act(z, p.scale, p.shift, relu, residual, out=out, pool=pool, mask=mask), p
+    if rmean is not None:
+        PACKS.generation += 1                  # running statistics are about to change through a raw pointer
+    p = BNParams(c, z.device)
+    if out is None:
+        out = new_act(n, c, h, w, z.dtype, z.device)
+    pro = L.BnPrologue()
+    pro.sum, pro.sumsq = stats[0, 0].data_ptr(), stats[0, 1].data_ptr()
+    pro.replicas, pro.rstride, pro.count, pro.eps, pro.momentum = stats.shape[0], stats.stride(0), float(count), float(eps), float(momentum)
+    pro.c_lo, pro.ld_xhat, pro.xhat = 0, 0, None
+    pro.gamma, pro.beta, pro.params, pro.running_mean, pro.running_var = gamma.data_ptr(), beta.data_ptr(), p.buf.data_ptr(), L.ptr(rmean), L.ptr(rvar)
+    if pool is not None:
+        L.call("saunet_affine_act_pool_bn", L.dtype_code(z), z.data_ptr(), ld_of(z), C.byref(pro), L.ptr(conv_bias), 1 if relu else 0, out.data_ptr(), ld_of(out),
+               n * h * w, c, pool.data_ptr(), h * w, L.stream())
+    else:
+        L.call("saunet_affine_act_bn", L.dtype_code(z), z.data_ptr(), ld_of(z), C.byref(pro), L.ptr(conv_bias), L.ptr(residual),
+               ld_of(residual) if residual is not None else 0, 1 if relu else 0, out.data_ptr(), ld_of(out), n * h * w, c, L.ptr(mask), L.stream())
+    return out, p
+
+
 def bn_backward(dy, x, p, relu, count, training, residual=None, dx=None, accumulate=False, want_dres=False, sync_group=None,
                 presums=None, mask=None):
     """Returns (dx, dres, dgamma, dbeta).  x is the tensor BN normalised (pre-affine).
@@ -849,6 +885,7 @@ class _ConvBNAct(torch.autograd.Function):
         stats = new_stats(cout, x.device) if training else None
         z = conv_forward_raw(x, weight, bias, stride, pad, transposed, stats=stats)
         count = z.shape[0] * z.shape[2] * z.shape[3]
+        y = None
         if group is not None and training:
             # SynchronizedBatchNorm across replicas (lib/nn/modules/batchnorm.py:98-139): global batch statistics = all-reduce of
             # (sum, sumsq), count scales with the world, inv_std = clamp(var, eps)^-1/2, running statistics through the reference's
@@ -865,9 +902,12 @@ class _ConvBNAct(torch.autograd.Function):
             L.call("saunet_syncbn_finalize", cout, flat[:cout].data_ptr(), flat[cout:].data_ptr(), 1, 0, float(count), gamma.data_ptr(),
                    beta.data_ptr(), float(eps), float(momentum), L.ptr(tm), L.ptr(tv), L.ptr(it), L.ptr(rmean), L.ptr(rvar),
                    p.scale.data_ptr(), p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), L.stream())
+        elif training:
+            y, p = bn_affine_act(z, stats, count, gamma, beta, rmean, rvar, momentum, eps, relu, residual, out=out, pool=pool, conv_bias=bias)
         else:
             p = bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum, eps, training, conv_bias=bias)
-        y = affine_act(z, p.scale, p.shift, relu, residual, out=out, pool=pool)
+        if y is None:
+            y = affine_act(z, p.scale, p.shift, relu, residual, out=out, pool=pool)
         ctx.save_for_backward(x, weight, z, p.buf, residual if residual is not None else z.new_empty(0))
         ctx.cfg = (stride, pad, transposed, relu, training, count, bias is not None, residual is not None, group)
         return y
@@ -936,13 +976,18 @@ class _BasicBlock(torch.autograd.Function):
         st1 = new_stats(c, x.device) if training else None
         z1 = conv_forward_raw(x, w1, None, 1, 1, stats=st1)
         count = z1.shape[0] * z1.shape[2] * z1.shape[3]
-        p1 = bn_finalize(st1, count, g1, b1, rm1, rv1, mom1, eps1, training)
         st2 = new_stats(c, x.device) if training else None
+        # (measured and rejected, round 6: bn1's finalize in conv2's operand-load prologue -- saunet_conv2d_forward_bnpro -- and the same for the
+        # transitions' 1x1: step +0.05 ms same-box; thousands of full-resolution workgroups each repeat the replica sums before their first load)
+        p1 = bn_finalize(st1, count, g1, b1, rm1, rv1, mom1, eps1, training)
         z2 = conv_forward_raw(z1, w2, None, 1, 1, pro=(p1.scale, p1.shift, True), stats=st2)
-        p2 = bn_finalize(st2, count, g2, b2, rm2, rv2, mom2, eps2, training)
         # the ReLU decisions of the block's output as bits (1/16 of the tensor): bn2's backward passes then read them instead of the skip tensor
         mask = torch.empty(z2.numel() // 8, dtype=torch.uint8, device=x.device) if relu_mask_ok(z2, x) else None
-        y = affine_act(z2, p2.scale, p2.shift, True, x, mask=mask)
+        if training:
+            y, p2 = bn_affine_act(z2, st2, count, g2, b2, rm2, rv2, mom2, eps2, True, x, mask=mask)
+        else:
+            p2 = bn_finalize(st2, count, g2, b2, rm2, rv2, mom2, eps2, training)
+            y = affine_act(z2, p2.scale, p2.shift, True, x, mask=mask)
         ctx.save_for_backward(x, w1, w2, z1, z2, p1.buf, p2.buf, mask if mask is not None else z2.new_empty(0))
         ctx.cfg = (training, count, mask is not None)
         return y
@@ -996,8 +1041,11 @@ class _BNAct(torch.autograd.Function):
         count = n * h * w
         if training and stats is None:
             stats = bn_stats(x)
-        p = bn_finalize(stats if training else None, count, gamma, beta, rmean, rvar, momentum, eps, training)
-        y = affine_act(x, p.scale, p.shift, relu, out=out)
+        if training:
+            y, p = bn_affine_act(x, stats, count, gamma, beta, rmean, rvar, momentum, eps, relu, out=out)
+        else:
+            p = bn_finalize(None, count, gamma, beta, rmean, rvar, momentum, eps, training)
+            y = affine_act(x, p.scale, p.shift, relu, out=out)
         ctx.save_for_backward(x, p.buf)
         ctx.cfg = (relu, training, count)
         return y

@@ -148,7 +148,8 @@ def test_basic_block_relu_bit_mask_is_bit_identical(ch, shape):
                 finally:
                     S.lib.call = orig
                 torch.cuda.synchronize()
-                assert ("saunet_bn_backward_apply_masked" in calls) == mode and ("saunet_affine_act_mask" in calls) == mode, calls
+                assert ("saunet_bn_backward_apply_masked" in calls) == mode, calls
+                assert ("saunet_affine_act_mask" in calls or "saunet_affine_act_bn" in calls) == (mode or HF.BN_FINALIZE_FUSED), calls
                 res[mode] = (y.detach().clone(), x.grad.clone(), {k: v.grad.clone() for k, v in blk.named_parameters()})
         finally:
             HF.RELU_MASK = saved
@@ -168,5 +169,64 @@ def test_basic_block_relu_bit_mask_is_bit_identical(ch, shape):
         differ = (got != want)
         assert int(differ.sum()) <= 2 and float(pre.permute(0, 2, 3, 1).reshape(-1, ch // 8, 8)[differ].abs().max() if differ.any() else 0.0) < 1e-5
         assert torch.equal(out > 0, (got.reshape(n, h, w, ch).permute(0, 3, 1, 2)) & (out > 0))
+    finally:
+        S.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_consumer_side_bn_finalize_matches_the_separate_launch(dtype):
+    """round 6: saunet_affine_act_bn / _pool_bn derive the BatchNorm coefficients in the prologue of the pass that applies them.  Against the saunet_bn_finalize launch they replace (SAUNET_BN_FINALIZE_FUSED=0 path): outputs and
+    gradients identical (same arithmetic), running statistics to float rounding, and no bn_finalize call left on the fused path."""
+    import saunet_amd as S
+    HF = S.functional
+    S.set_compute_dtype(dtype)
+    try:
+        torch.manual_seed(21)
+        blk = S.BasicBlock(32, 32).cuda().train()
+        cbr = S.conv3x3_bn_relu(32, 64).cuda().train()
+        with torch.no_grad():
+            for mod in (blk, cbr):
+                for m in mod.modules():
+                    if hasattr(m, "running_mean") and m.weight is not None and m.weight.dim() == 1:
+                        m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+        st_b = {k: v.clone() for k, v in blk.state_dict().items()}; st_c = {k: v.clone() for k, v in cbr.state_dict().items()}
+        x0 = torch.randn(2, 32, 32, 48, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+        bn = [m for m in cbr.modules() if hasattr(m, "running_mean")][0]
+        conv = [m for m in cbr.modules() if isinstance(m, torch.nn.Conv2d)][0]
+        res, saved, calls, orig = {}, HF.BN_FINALIZE_FUSED, [], S.lib.call
+
+        def traced(name, *a):
+            calls.append(name); return orig(name, *a)
+        try:
+            for mode in (True, False):
+                HF.BN_FINALIZE_FUSED = mode
+                blk.load_state_dict(st_b); cbr.load_state_dict(st_c); HF.notify_params_changed()
+                blk.zero_grad(set_to_none=True); cbr.zero_grad(set_to_none=True)
+                x = x0.clone().requires_grad_(True)
+                del calls[:]
+                S.lib.call = traced
+                try:
+                    y = cbr(blk(x))
+                    pool = torch.empty(2, 64, dtype=torch.float32, device="cuda")
+                    y2 = HF.conv_bn_act(y, conv.weight.new_tensor(conv.weight.detach()[:, :, :1, :1].repeat(1, 2, 1, 1) * 0.1), None, bn, relu=True, pool=pool)
+                    (y.float().square().sum() + y2.float().sum()).backward()
+                finally:
+                    S.lib.call = orig
+                torch.cuda.synchronize()
+                assert calls.count("saunet_bn_finalize") == (1 if mode else 4), calls          # (fused: BasicBlock.bn1 feeds conv2's operand prologue, kept; the ConvBNReLU's conv has a bias)
+                assert ("saunet_affine_act_bn" in calls) == mode and ("saunet_affine_act_pool_bn" in calls) == mode
+                res[mode] = (y.detach().clone(), y2.detach().clone(), pool.clone(), x.grad.clone(),
+                             {k: v.grad.clone() for mod in (blk, cbr) for k, v in mod.named_parameters()},
+                             {k: v.clone() for mod in (blk, cbr) for k, v in mod.state_dict().items() if "running" in k})
+        finally:
+            HF.BN_FINALIZE_FUSED = saved
+        a, b = res[True], res[False]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+        assert float((a[2] - b[2]).abs().max()) <= 1e-6 * float(b[2].abs().max())            # (float atomics into the pool: order)
+        for k in a[4]:
+            assert float((a[4][k] - b[4][k]).abs().max()) <= 1e-6 * float(b[4][k].abs().max()) + 1e-12, k
+        for k in a[5]:
+            assert float((a[5][k] - b[5][k]).abs().max()) <= 1e-6 * float(b[5][k].abs().max()) + 1e-9, k
     finally:
         S.set_compute_dtype(torch.float32)
