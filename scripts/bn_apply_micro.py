@@ -41,6 +41,13 @@ for (n, c, h) in ((32, 128, 128), (32, 128, 64), (32, 32, 256), (32, 64, 128), (
         g, x, o = nxt(); g.add_(x)
     def f7():
         g, x, o = nxt(); o.copy_(x)
+    from saunet_amd import lib as L
+    def f0():
+        g, x, o = nxt()
+        L.call("saunet_bn_backward_reduce", L.dtype_code(x), g.data_ptr(), HF.ld_of(g), x.data_ptr(), HF.ld_of(x), None, 0, p.scale.data_ptr(), p.shift.data_ptr(),
+               p.mean.data_ptr(), p.invstd.data_ptr(), 1, st.data_ptr(), st.shape[0], st.stride(0), P, c, L.stream())
+    ms = t(f0)
+    print("%-22s reduce          %7.1f us  %.2f TB/s" % ((n, c, h), ms * 1e3, 2 * by / ms / 1e9))
     ms = t(f1)
     print("%-22s apply in place  %7.1f us  %.2f TB/s" % ((n, c, h), ms * 1e3, 3 * by / ms / 1e9))
     ms = t(f2)
