@@ -40,3 +40,8 @@ case(B, 64, 256, 64, 3, "res1 wgrad 3x3 64->64 @256", pro=False)
 case(B, 1024, 32, 256, 3, "dec4 wgrad 3x3 1024->256 @32", pro=False)
 case(B, 512, 64, 128, 3, "dec3 wgrad 3x3 512->128 @64", pro=False)
 case(B, 256, 128, 64, 3, "dec2 wgrad 3x3 256->64 @128", pro=False)
+case(B, 64, 256, 64, 3, "res1.conv2 wgrad 3x3 64->64 @256 (prologue)", pro=True)
+case(B, 32, 256, 32, 3, "res2 wgrad 3x3 32->32 @256", pro=False)
+case(B, 16, 256, 16, 3, "res3 wgrad 3x3 16->16 @256", pro=False)
+case(B, 64, 256, 32, 3, "dec0 wgrad 3x3 64->32 @256", pro=False)
+case(B, 64, 128, 48, 3, "dec1 wgrad 3x3 64->48 @128", pro=False)
