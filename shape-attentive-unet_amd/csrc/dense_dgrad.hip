@@ -353,12 +353,16 @@ static __device__ u32x4 g_dg_zeros[4];
 template <bool HALO, bool CORR = false>
 __global__ __launch_bounds__((HALO ? 8 : DG_WAVES) * 64, HALO ? 1 : 2) void dense_dgrad3_kernel(DenseDgrad3Args a)
 {
-    static_assert(!(HALO && CORR), "the correction is folded into the per-wave variant only");
     extern __shared__ __attribute__((aligned(1024))) unsigned char d_smem[];
     TSTAMP_INIT();
     TSTAMP(50);
     constexpr int WAVES = HALO ? 8 : DG_WAVES;
-    constexpr int OFF_W = HALO ? 2 * D3_HALO_BYTES : 0;              // the halo buffers first: their DMA destinations are 1 KB aligned
+    // HALO && CORR (round 6): the deferred BN1 correction g' = g - (A + B * xhat(x)) is applied IN PLACE in the landed halo buffer by the wave that
+    // requested the piece (its lane always holds the same 8 channels: the coefficients live in 16 registers), with the chunk's activations
+    // staged by a second DMA stream into ONE extra buffer (it is only read between the landing and the barrier of its tile); the corrected
+    // centre pixels go to gc.  The separate bn_bwd_correct_ab pass (read chunk + x, write dz2) and the re-read of dz2 disappear.
+    constexpr int OFF_X = 2 * D3_HALO_BYTES;
+    constexpr int OFF_W = HALO ? (CORR ? 3 : 2) * D3_HALO_BYTES : 0;  // the halo buffers first: their DMA destinations are 1 KB aligned
     u16* s_w = (u16*)(d_smem + OFF_W);                               // [128][D3_WPITCH]
     float* s_par = (float*)(d_smem + OFF_W + (size_t)128 * D3_WPITCH * 2);  // [4][128]
     constexpr int NT = WAVES * 64;
@@ -379,6 +383,11 @@ __global__ __launch_bounds__((HALO ? 8 : DG_WAVES) * 64, HALO ? 1 : 2) void dens
                 const int ch = sl ^ ((hp >> 2) & 3);
                 const unsigned char* src = ok ? img + ((size_t)(iy * a.W + ix) * a.ldg + ch * 8) * 2 : (const unsigned char*)g_dg_zeros + sl * 16;
                 mm_dma16(src, lds0 + buf * D3_HALO_BYTES + piece * 1024);
+                if constexpr (HALO && CORR) {
+                    const unsigned char* ximg = (const unsigned char*)(a.xc + (size_t)n * a.H * a.W * a.ldxc);
+                    const unsigned char* sx = ok ? ximg + ((size_t)(iy * a.W + ix) * a.ldxc + ch * 8) * 2 : (const unsigned char*)g_dg_zeros + sl * 16;
+                    mm_dma16(sx, lds0 + OFF_X + piece * 1024);
+                }
             }
         }
     };
@@ -412,7 +421,7 @@ __global__ __launch_bounds__((HALO ? 8 : DG_WAVES) * 64, HALO ? 1 : 2) void dens
     }
     __syncthreads();
     float cA[CORR ? 16 : 1], cB[CORR ? 16 : 1];     // this lane's channels 16*h + 8*lh + j
-    if constexpr (CORR) {
+    if constexpr (CORR && !HALO) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -452,6 +461,41 @@ __global__ __launch_bounds__((HALO ? 8 : DG_WAVES) * 64, HALO ? 1 : 2) void dens
             p = unit_pixel(tp);
             live = true;
             mm_wait_vm<0>();
+            if constexpr (CORR) {
+                const unsigned txi = tp % tilesX, r1 = tp / tilesX, tyi = r1 % tilesY, n = r1 / tilesY;
+                // the 8 channels of the lane's 16-byte slot are the same in every piece it requests: chunk = sl ^ ((hp >> 2) & 3) and
+                // (hp >> 2) & 3 == (lane >> 4) & 3.  Their coefficients are re-read from the LDS per tile (the kernel sits at the register limit)
+                const int chl = (lane & 3) ^ ((lane >> 4) & 3);
+                float hA[8], hB[8];
+                {
+                    const f32x4 a0 = *(const f32x4*)(s_cc + chl * 8), a1 = *(const f32x4*)(s_cc + chl * 8 + 4);
+                    const f32x4 b0 = *(const f32x4*)(s_cc + 32 + chl * 8), b1 = *(const f32x4*)(s_cc + 32 + chl * 8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { hA[e] = a0[e]; hA[4 + e] = a1[e]; hB[e] = b0[e]; hB[4 + e] = b1[e]; }
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int piece = wave + 8 * j;
+                    if (piece < D3_HALO_PIECES) {
+                        const int hp = piece * 16 + (lane >> 2);
+                        const int hy = hp / 18, hx = hp - hy * 18;
+                        const int iy = (int)tyi * 16 + hy - 1, ix = (int)txi * 16 + hx - 1;
+                        const bool ok = hp < 324 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                        unsigned char* gp = d_smem + kbuf * D3_HALO_BYTES + piece * 1024 + lane * 16;
+                        const u32x4 g4 = *(const u32x4*)gp, x4 = *(const u32x4*)(d_smem + OFF_X + piece * 1024 + lane * 16);
+                        float gv[8], xv[8];
+                        Vec16<u16>::unpack(g4, gv); Vec16<u16>::unpack(x4, xv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gv[e] -= fmaf(hB[e], xv[e], hA[e]);
+                        const u32x4 c4 = Vec16<u16>::pack(gv);
+                        if (ok) {                       // (padding pixels came from the zero page and stay zero: the CORRECTED gradient is what is padded)
+                            *(u32x4*)gp = c4;
+                            if (hy >= 1 && hy <= 16 && hx >= 1 && hx <= 16)       // the tile's own pixels: what the conv2 weight gradient reads later
+                                *(u32x4*)(a.gc + ((size_t)(n * a.H + iy) * a.W + ix) * a.ldgc + chl * 8) = c4;
+                        }
+                    }
+                }
+            }
             mm_barrier();
             TSTAMP(51);
             const unsigned char* hb = d_smem + kbuf * D3_HALO_BYTES;
@@ -771,10 +815,11 @@ static int launch_dense_dgrad3(DenseDgrad3Args& a, bool corr, hipStream_t st)
         (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
+        (void)hipFuncSetAttribute((const void*)dense_dgrad3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024);
     }
     static const bool cw_on = ab_env_on("SAUNET_DGRAD3_CW");     // A/B (variant builds only)
     const long runs = ((long)a.P + 31) / 32;
-    if (cw_on && runs <= 2048 && !(!corr && dense_dgrad3_halo(a.N, a.H, a.W))) {
+    if (cw_on && runs <= 2048 && !dense_dgrad3_halo(a.N, a.H, a.W)) {
         // low-resolution maps: one 32-pixel run per workgroup at a time, its waves = the four 32-channel tiles
         static const long cw_blocks = ab_env_int("SAUNET_DGRAD3_CW_BLOCKS", 512);
         const long bx = runs < cw_blocks ? runs : cw_blocks;
@@ -783,18 +828,21 @@ static int launch_dense_dgrad3(DenseDgrad3Args& a, bool corr, hipStream_t st)
         SAUNET_CHECK_LAUNCH(corr ? "dense_dgrad3_cw_kernel<true>" : "dense_dgrad3_cw_kernel<false>");
         return SAUNET_OK;
     }
-    if (!corr && dense_dgrad3_halo(a.N, a.H, a.W)) {
+    if (dense_dgrad3_halo(a.N, a.H, a.W)) {
         // one 8-wave workgroup per CU, 16 x 16 tiles: only for maps with at least one tile per CU
         const long ntile = (long)a.N * (a.H >> 4) * (a.W >> 4);
         const long bx = ntile < 256 ? ntile : 256;
-        hipLaunchKernelGGL(dense_dgrad3_kernel<true>, dim3((unsigned)bx), dim3(512), lds + 2 * D3_HALO_BYTES, st, a);
+        if (corr) hipLaunchKernelGGL((dense_dgrad3_kernel<true, true>), dim3((unsigned)bx), dim3(512), lds + 3 * D3_HALO_BYTES, st, a);
+        else hipLaunchKernelGGL(dense_dgrad3_kernel<true>, dim3((unsigned)bx), dim3(512), lds + 2 * D3_HALO_BYTES, st, a);
+        SAUNET_CHECK_LAUNCH(corr ? "dense_dgrad3_kernel<true, true>" : "dense_dgrad3_kernel<true, false>");
+        return SAUNET_OK;
     } else {
         long bx = 512; const long maxbx = ((long)a.P + 32 * DG_WAVES - 1) / (32 * DG_WAVES);
         if (bx > maxbx) bx = maxbx; if (bx < 1) bx = 1;
         if (corr) hipLaunchKernelGGL((dense_dgrad3_kernel<false, true>), dim3((unsigned)bx), dim3(DG_WAVES * 64), lds, st, a);
         else hipLaunchKernelGGL(dense_dgrad3_kernel<false>, dim3((unsigned)bx), dim3(DG_WAVES * 64), lds, st, a);
     }
-    SAUNET_CHECK_LAUNCH(corr ? "dense_dgrad3_kernel<false, true>" : (dense_dgrad3_halo(a.N, a.H, a.W) ? "dense_dgrad3_kernel<true, false>" : "dense_dgrad3_kernel<false, false>"));
+    SAUNET_CHECK_LAUNCH(corr ? "dense_dgrad3_kernel<false, true>" : "dense_dgrad3_kernel<false, false>");
     return SAUNET_OK;
 }
 
@@ -1464,7 +1512,8 @@ int saunet_dense_layer_backward_conv2(const saunet_dense_layer_bwd* l, void* str
         return launch_dense_dgrad3(a, false, st);
     }
     const double* ab = l->ab + l->Cin;
-    if (dense_dgrad3_halo(l->N, l->H, l->W)) {     // large maps: a streaming correction pass into dz2, then the LDS-DMA staged kernel over dz2
+    static const bool halo_corr = ab_env_on("SAUNET_DGRAD3_HALO_CORR");     // A/B (variant builds only): 0 = the separate correction pass of round 5
+    if (!halo_corr && dense_dgrad3_halo(l->N, l->H, l->W)) {     // large maps: a streaming correction pass into dz2, then the LDS-DMA staged kernel over dz2
         // (the correction folded into the halo buffer of a non-transposed form of that kernel was built and measured slower: registers --
         // scripts/probes/dense_dgrad3_halo2_rejected.hip)
         if (int rc = bn_backward_correct_ab(SAUNET_BF16, chunk, l->Ctot, (const u16*)l->buf + l->Cin, l->Ctot, l->dz2, 32, ab, l->ab_replicas, l->ab_rstride,
