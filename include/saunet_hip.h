@@ -293,6 +293,20 @@ int saunet_affine_act_bn(int dtype, const void* x, int ldx, const saunet_bn_prol
                          void* y, int ldy, int64_t pixels, int C, uint8_t* relu_mask, void* stream);
 int saunet_affine_act_pool_bn(int dtype, const void* x, int ldx, const saunet_bn_prologue* pro, const float* conv_bias, int relu, void* y, int ldy,
                               int64_t pixels, int C, float* pooled, int HW, void* stream);
+/* DenseNet transition with the average pool IN FRONT of its 1x1 convolution (torchvision _Transition: norm -> relu -> conv1x1 -> AvgPool2d(2, 2),
+ * /root/reference/models/models.py:271 as sliced at :306-313).  A pointwise convolution and an average pool commute, so
+ *   y = conv1x1(saunet_bn_relu_avgpool2(x))
+ * equals pool(conv1x1(relu(bn(x)))) up to rounding, with the convolution, its data gradient and its weight gradient on a quarter of the pixels.
+ *   forward : y[n, oy, ox, c] = 1/4 * sum over the 2x2 window of relu(x*scale+shift)          x [N,H,W,C] -> y [N,H/2,W/2,C]
+ *   backward: g = [x*scale+shift > 0] * 1/4 * da[n, h/2, w/2, c];  sums[0:C] += sum g, sums[C:2C] += sum g*xhat (float64, zeroed by the caller:
+ *             what saunet_bn_backward_reduce would have produced);  dx = g (scaled = 0: continue with saunet_bn_backward_apply on pre-masked
+ *             sums) or scale*g (scaled = 1: the dense block's linear form, saunet_bn_backward_coeff_ab).
+ * Even H and W, C <= 2048, vector path only (SAUNET_UNSUPPORTED otherwise). */
+int saunet_bn_relu_avgpool2(int dtype, const void* x, int ldx, const float* scale, const float* shift, void* y, int ldy,
+                            int N, int H, int W, int C, void* stream);
+int saunet_bn_relu_avgpool2_backward(int dtype, const void* da, int ldda, const void* x, int ldx, const float* scale, const float* shift,
+                                     const float* mean, const float* invstd, int scaled, void* dx, int lddx,
+                                     double* sums, int replicas, int rstride, int N, int H, int W, int C, void* stream);
 /* Residual blocks (y = relu(x*scale+shift + residual), /root/reference/models/resnet.py:54-59): the backward pass needs the ReLU decision of
  * every element, and recomputing it means re-reading the skip tensor in both the reduce and the apply pass.  saunet_affine_act_mask also
  * writes the decisions as bits -- relu_mask[pixel * C/8 + c/8] bit (c % 8), dense, pixels * C / 8 bytes -- and the _masked backward entries

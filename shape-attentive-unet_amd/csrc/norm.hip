@@ -518,6 +518,107 @@ __global__ void bn_bwd_coeff_ab_kernel(int C, const double* __restrict__ sums, i
     ab[c] += sc * s1; ab[half + c] += sc * s2;
 }
 
+// ---- DenseNet transition with the pooling IN FRONT of the 1x1 convolution (round 6).  torchvision's _Transition is norm -> relu -> conv1x1 ->
+// AvgPool2d(2, 2) (/root/reference/models/models.py:271 as sliced at :306-313); a pointwise convolution and an average pool are both linear and
+// act on different axes, so they commute: pool(conv(a)) == conv(pool(a)).  Pooling the ACTIVATION first runs the convolution, its data gradient
+// and its weight gradient on a quarter of the pixels and never materialises the full-resolution C/2-channel tensor in either direction.
+//   forward :  a'[n, oy, ox, c] = 1/4 * sum_{2x2} relu(x * scale + shift)                       (one pass: read C full-res, write C quarter-res)
+//   backward:  g[p, c] = [x * scale + shift > 0] * 1/4 * da'[p / 2, c];  sums[c] += g, sums[C + c] += g * xhat;  dx[p, c] = (scaled ? scale : 1) * g
+//              (the reduce pass of the BatchNorm backward and the pool / ReLU backward in ONE pass; `scaled` = the dense block's linear form)
+struct PoolBnArgs {
+    const void* x; int ldx; const float* scale; const float* shift; const float* mean; const float* invstd;
+    void* y; int ldy; const void* da; int ldda; void* dx; int lddx; int scaled;
+    double* sums; int sreps, srstride;
+    int Wo, W, C; long Po, rpb;
+};
+
+template <typename T, int V> __global__ __launch_bounds__(256) void bn_relu_avgpool2_fwd_kernel(PoolBnArgs a)
+{
+    const long p0 = blockIdx.x * a.rpb, p1 = min(p0 + a.rpb, a.Po);
+    const int CH = a.C / V;
+    const T* x = (const T*)a.x; T* y = (T*)a.y;
+    for (int cb = 0; cb < CH; cb += 256) {
+        const int cw = min(256, CH - cb), rl = 256 / cw;
+        const int ch = cb + threadIdx.x % cw, r0 = threadIdx.x / cw;
+        if (r0 >= rl) continue;
+        float s[V], t[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { s[j] = a.scale[ch * V + j]; t[j] = a.shift[ch * V + j]; }
+        for (long op = p0 + r0; op < p1; op += rl) {
+            const long r = op / a.Wo; const int ox = (int)(op - r * a.Wo);
+            const T* xb = x + ((2 * r) * a.W + 2 * ox) * (long)a.ldx + ch * V;
+            float f[4][V], o[V];
+            ChunkIO<T, V>::load(xb, f[0]); ChunkIO<T, V>::load(xb + a.ldx, f[1]);
+            ChunkIO<T, V>::load(xb + (long)a.W * a.ldx, f[2]); ChunkIO<T, V>::load(xb + (long)(a.W + 1) * a.ldx, f[3]);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float v0 = fmaxf(fmaf(f[0][j], s[j], t[j]), 0.f), v1 = fmaxf(fmaf(f[1][j], s[j], t[j]), 0.f);
+                const float v2 = fmaxf(fmaf(f[2][j], s[j], t[j]), 0.f), v3 = fmaxf(fmaf(f[3][j], s[j], t[j]), 0.f);
+                o[j] = 0.25f * ((v0 + v1) + (v2 + v3));
+            }
+            ChunkIO<T, V>::store(y + op * a.ldy + ch * V, o);
+        }
+    }
+}
+
+template <typename T, int V> __global__ __launch_bounds__(256) void bn_relu_avgpool2_bwd_kernel(PoolBnArgs a)
+{
+    extern __shared__ double s_red[];  // [2][C]
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) s_red[i] = 0.0;
+    __syncthreads();
+    const long p0 = blockIdx.x * a.rpb, p1 = min(p0 + a.rpb, a.Po);
+    const int CH = a.C / V;
+    const T* x = (const T*)a.x; const T* da = (const T*)a.da; T* dx = (T*)a.dx;
+    for (int cb = 0; cb < CH; cb += 256) {
+        const int cw = min(256, CH - cb), rl = 256 / cw;
+        const int ch = cb + threadIdx.x % cw, r0 = threadIdx.x / cw;
+        if (r0 >= rl) continue;
+        float s[V], t[V], mu[V], is[V], os[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            s[j] = a.scale[ch * V + j]; t[j] = a.shift[ch * V + j]; mu[j] = a.mean[ch * V + j]; is[j] = a.invstd[ch * V + j];
+            os[j] = a.scaled ? s[j] : 1.f;
+        }
+        double d1[V], d2[V]; float f1[V], f2[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { d1[j] = d2[j] = 0.0; f1[j] = f2[j] = 0.f; }
+        int cnt = 0;
+        for (long op = p0 + r0; op < p1; op += rl) {
+            const long r = op / a.Wo; const int ox = (int)(op - r * a.Wo);
+            const long pb = (2 * r) * a.W + 2 * ox;
+            float g[V], xv[4][V];
+            ChunkIO<T, V>::load(da + op * a.ldda + ch * V, g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ChunkIO<T, V>::load(x + (pb + (q >> 1) * (long)a.W + (q & 1)) * a.ldx + ch * V, xv[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float o[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float gv = fmaf(xv[q][j], s[j], t[j]) > 0.f ? 0.25f * g[j] : 0.f;
+                    f1[j] += gv;
+                    f2[j] = fmaf(gv, (xv[q][j] - mu[j]) * is[j], f2[j]);
+                    o[j] = os[j] * gv;
+                }
+                ChunkIO<T, V>::store(dx + (pb + (q >> 1) * (long)a.W + (q & 1)) * a.lddx + ch * V, o);
+            }
+            if ((cnt += 4) >= 128) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) { d1[j] += f1[j]; d2[j] += f2[j]; f1[j] = f2[j] = 0.f; }
+                cnt = 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            atomicAdd(&s_red[ch * V + j], d1[j] + (double)f1[j]);
+            atomicAdd(&s_red[a.C + ch * V + j], d2[j] + (double)f2[j]);
+        }
+    }
+    __syncthreads();
+    const size_t ro = (size_t)(blockIdx.x % a.sreps) * a.srstride;
+    for (int c = threadIdx.x; c < 2 * a.C; c += 256) atomicAdd(&a.sums[ro + c], s_red[c]);
+}
+
 // dgamma / dbeta of all norm1 layers of a dense block: blockIdx.y = layer
 __global__ __launch_bounds__(256) void dense_bn1_grads_kernel(saunet_dense_bn1_list l)
 {
@@ -910,6 +1011,48 @@ int saunet_bn_backward_apply_masked(int dtype, const void* dy, int lddy, const v
     if (!relu_mask) return set_error(SAUNET_BAD_SHAPE, "bn_backward_apply_masked: no mask");
     return bn_backward_apply_impl(dtype, dy, lddy, x, ldx, nullptr, 0, scale, shift, mean, invstd, 1, sums, sums_replicas, sums_rstride, count, training,
                                   accumulate, dx, lddx, dres, lddres, dgamma, dbeta, pixels, C, relu_mask, stream);
+}
+
+static int pool_bn_check(const char* who, int dtype, int N, int H, int W, int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs)
+{
+    if (N < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 1 || C > 2048) return set_error(SAUNET_BAD_SHAPE, "%s: N=%d H=%d W=%d C=%d (even maps, C <= 2048)", who, N, H, W, C);
+    if (dtype != SAUNET_BF16 && dtype != SAUNET_F32) return set_error(SAUNET_BAD_DTYPE, "%s: dtype %d", who, dtype);
+    if (!vec_ok(dtype, C, lds, ptrs)) return set_error(SAUNET_UNSUPPORTED, "%s: vector path only (C, strides multiples of 8 bf16 / 4 f32 elements, 16-byte aligned views)", who);
+    for (const void* p : ptrs) if (!p) return set_error(SAUNET_BAD_SHAPE, "%s: null operand", who);
+    return SAUNET_OK;
+}
+
+int saunet_bn_relu_avgpool2(int dtype, const void* x, int ldx, const float* scale, const float* shift, void* y, int ldy,
+                            int N, int H, int W, int C, void* stream)
+{
+    if (int rc = pool_bn_check("bn_relu_avgpool2", dtype, N, H, W, C, {ldx, ldy}, {x, y})) return rc;
+    if (!scale || !shift) return set_error(SAUNET_BAD_SHAPE, "bn_relu_avgpool2: no coefficients");
+    PoolBnArgs a{}; a.x = x; a.ldx = ldx; a.scale = scale; a.shift = shift; a.y = y; a.ldy = ldy; a.Wo = W / 2; a.W = W; a.C = C;
+    a.Po = (long)N * (H / 2) * (W / 2);
+    int blocks; const int V = dtype == SAUNET_BF16 ? 8 : 4;
+    a.rpb = rows_per_block(a.Po * 4, C, V, &blocks); a.rpb = (a.rpb + 3) / 4; blocks = (int)((a.Po + a.rpb - 1) / a.rpb);
+    if (dtype == SAUNET_BF16) hipLaunchKernelGGL((bn_relu_avgpool2_fwd_kernel<u16, 8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((bn_relu_avgpool2_fwd_kernel<float, 4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    CHECK_LAUNCH_TV("bn_relu_avgpool2_fwd", dtype, true);
+    return SAUNET_OK;
+}
+
+int saunet_bn_relu_avgpool2_backward(int dtype, const void* da, int ldda, const void* x, int ldx, const float* scale, const float* shift,
+                                     const float* mean, const float* invstd, int scaled, void* dx, int lddx,
+                                     double* sums, int replicas, int rstride, int N, int H, int W, int C, void* stream)
+{
+    if (int rc = pool_bn_check("bn_relu_avgpool2_backward", dtype, N, H, W, C, {ldda, ldx, lddx}, {da, x, dx})) return rc;
+    if (!scale || !shift || !mean || !invstd || !sums) return set_error(SAUNET_BAD_SHAPE, "bn_relu_avgpool2_backward: incomplete arguments");
+    PoolBnArgs a{}; a.x = x; a.ldx = ldx; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.da = da; a.ldda = ldda;
+    a.dx = dx; a.lddx = lddx; a.scaled = scaled; a.sums = sums; a.sreps = replicas < 1 ? 1 : replicas; a.srstride = rstride;
+    a.Wo = W / 2; a.W = W; a.C = C; a.Po = (long)N * (H / 2) * (W / 2);
+    int blocks; const int V = dtype == SAUNET_BF16 ? 8 : 4;
+    a.rpb = rows_per_block(a.Po * 4, C, V, &blocks); a.rpb = (a.rpb + 3) / 4; blocks = (int)((a.Po + a.rpb - 1) / a.rpb);
+    const size_t lds = 2 * (size_t)C * sizeof(double);
+    if (dtype == SAUNET_BF16) hipLaunchKernelGGL((bn_relu_avgpool2_bwd_kernel<u16, 8>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((bn_relu_avgpool2_bwd_kernel<float, 4>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
+    CHECK_LAUNCH_TV("bn_relu_avgpool2_bwd", dtype, true);
+    return SAUNET_OK;
 }
 
 }  // extern "C"

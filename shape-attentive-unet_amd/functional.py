@@ -2006,6 +2006,19 @@ def dense_block(x0, layers, training):
     return buf, stats
 
 
+# Transition with the average pool in front of the 1x1 convolution (round 6): the two commute, so conv, data gradient and weight gradient run on
+# a quarter of the pixels and the full-resolution C/2 tensor never exists (saunet_bn_relu_avgpool2 / _backward).  SAUNET_TRANSITION_POOL_FIRST=0
+# restores conv -> pool (A/B, tests).
+TRANSITION_POOL_FIRST = os.environ.get("SAUNET_TRANSITION_POOL_FIRST", "1") != "0"
+
+
+def _pool_first_ok(buf):
+    epc = 8 if buf.dtype == torch.bfloat16 else 4
+    n, c, h, w = buf.shape
+    return (TRANSITION_POOL_FIRST and buf.is_cuda and buf.dtype in (torch.bfloat16, torch.float32) and h % 2 == 0 and w % 2 == 0 and c % epc == 0
+            and c <= 2048 and ld_of(buf) % epc == 0 and buf.data_ptr() % 16 == 0)
+
+
 class _Transition(torch.autograd.Function):
     """BN-ReLU-conv1x1(C -> C/2)-AvgPool2 over a dense block's concat buffer (statistics already known)."""
 
@@ -2015,24 +2028,51 @@ class _Transition(torch.autograd.Function):
         n, c, h, w = buf.shape
         count = n * h * w
         p = bn_finalize(stats if training else None, count, gamma, beta, rmean, rvar, momentum, eps, training)
-        z = conv_forward_raw(buf, weight, None, 1, 0, pro=(p.scale, p.shift, True))
-        if reserve and reserve > z.shape[1]:            # the pooled output is the first slice of the next dense block's concat buffer
-            y = reserve_dense_input(n, z.shape[1], h // 2, w // 2, reserve, z.dtype, z.device)
+        co = weight.shape[0]
+        if reserve and reserve > co:            # the pooled output is the first slice of the next dense block's concat buffer
+            y = reserve_dense_input(n, co, h // 2, w // 2, reserve, buf.dtype, buf.device)
         else:
-            y = new_act(n, z.shape[1], h // 2, w // 2, z.dtype, z.device)
+            y = new_act(n, co, h // 2, w // 2, buf.dtype, buf.device)
+        if _pool_first_ok(buf):
+            a = new_act(n, c, h // 2, w // 2, buf.dtype, buf.device)
+            L.call("saunet_bn_relu_avgpool2", L.dtype_code(buf), buf.data_ptr(), ld_of(buf), p.scale.data_ptr(), p.shift.data_ptr(), a.data_ptr(), ld_of(a),
+                   n, h, w, c, L.stream())
+            conv_forward_raw(a, weight, None, 1, 0, out=y)
+            ctx.save_for_backward(buf, weight, p.buf, a)
+            ctx.meta = (count, training, bool(fold), True)
+            return y
+        z = conv_forward_raw(buf, weight, None, 1, 0, pro=(p.scale, p.shift, True))
         L.call("saunet_pool2x2_forward", L.dtype_code(z), 0, z.data_ptr(), n, h, w, z.shape[1], ld_of(z), y.data_ptr(), ld_of(y), L.stream())
-        ctx.save_for_backward(buf, weight, p.buf)
-        ctx.meta = (count, training, bool(fold))
+        ctx.save_for_backward(buf, weight, p.buf, buf.new_empty(0))
+        ctx.meta = (count, training, bool(fold), False)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        buf, weight, pbuf = ctx.saved_tensors
-        count, training, fold = ctx.meta
+        buf, weight, pbuf, a = ctx.saved_tensors
+        count, training, fold, pool_first = ctx.meta
         p = BNParams.__new__(BNParams); p.buf = pbuf
         dy = nhwc(dy)
         n, c, h, w = buf.shape
         co = weight.shape[0]
+        if pool_first:
+            dw = conv_wgrad_raw(a, dy, weight, 1, 0)                       # quarter-resolution operands, no prologue: `a` is the pooled activation
+            dap = conv_dgrad_raw(dy, weight, a.shape, 1, 0)
+            sb = new_stats(c, buf.device)
+            folded = bool(fold and training and DENSE_BWD_FUSED and DENSE_TRANSITION_FOLD)
+            da = new_act(n, c, h, w, buf.dtype, buf.device)
+            L.call("saunet_bn_relu_avgpool2_backward", L.dtype_code(buf), dap.data_ptr(), ld_of(dap), buf.data_ptr(), ld_of(buf), p.scale.data_ptr(),
+                   p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), 1 if folded else 0, da.data_ptr(), ld_of(da),
+                   sb.data_ptr(), sb.shape[0], sb.stride(0), n, h, w, c, L.stream())
+            if folded:
+                ab = new_stats(c, buf.device)
+                dgb = torch.empty(2, c, dtype=torch.float32, device=buf.device)
+                L.call("saunet_bn_backward_coeff_ab", c, sb.data_ptr(), sb.shape[0], sb.stride(0), p.scale.data_ptr(), ab.data_ptr(), c,
+                       dgb[0].data_ptr(), dgb[1].data_ptr(), L.stream())
+                _PENDING_AB[buf.data_ptr()] = ab
+                return da, None, dgb[0], dgb[1], None, None, dw, None, None, None, None, None
+            dbuf, _, dg, db = bn_backward(da, buf, p, True, count, training, dx=da, presums=sb)
+            return dbuf, None, dg, db, None, None, dw, None, None, None, None, None
         dz = new_act(n, co, h, w, dy.dtype, dy.device)
         L.call("saunet_pool2x2_backward", L.dtype_code(dy), 0, None, dy.data_ptr(), n, h, w, co, 0, ld_of(dy), dz.data_ptr(), ld_of(dz), 0, L.stream())
         dw = conv_wgrad_raw(buf, dz, weight, 1, 0, pro=(p.scale, p.shift, True))

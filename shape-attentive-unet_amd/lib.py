@@ -117,6 +117,8 @@ _SIGS = {
                                  vp, i32, vp, i32, vp, vp, i64, i32, vp],
     "saunet_affine_act_bn": [i32, vp, i32, C.POINTER(BnPrologue), vp, vp, i32, i32, vp, i32, i64, i32, vp, vp],
     "saunet_affine_act_pool_bn": [i32, vp, i32, C.POINTER(BnPrologue), vp, i32, vp, i32, i64, i32, vp, i32, vp],
+    "saunet_bn_relu_avgpool2": [i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "saunet_bn_relu_avgpool2_backward": [i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],
     "saunet_affine_act_mask": [i32, vp, i32, vp, vp, vp, i32, vp, i32, i64, i32, vp, vp],
     "saunet_bn_backward_reduce_masked": [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp],
     "saunet_bn_backward_apply_masked": [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, f64, i32, i32,

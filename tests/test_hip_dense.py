@@ -714,3 +714,69 @@ def test_transition_folds_only_behind_the_block_that_tagged_its_statistics():
     with pytest.raises(RuntimeError, match="never settled"):
         HF.begin_step()
     HF.begin_step()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,shape,c", [(torch.float32, (2, 32, 32), 64), (torch.bfloat16, (4, 64, 64), 256), (torch.bfloat16, (3, 16, 48), 96)])
+def test_transition_with_the_pool_in_front_of_the_conv_matches_conv_then_pool(dtype, shape, c):
+    """round 6: AvgPool2d(2, 2) and the transition's 1x1 convolution commute, so the transition runs as  pool(relu(bn(x))) -> conv  on a quarter of the
+    pixels (saunet_bn_relu_avgpool2 / _backward).  Against float64 of torchvision's order (norm -> relu -> conv -> pool,
+    /root/reference/models/models.py:271) and against the library's own conv -> pool path (SAUNET_TRANSITION_POOL_FIRST=0): output, input gradient,
+    weight / gamma / beta gradients.  float32: 1e-5 of the tensor scale; bf16: no further from float64 than 1.5x the conv -> pool path (+ 2e-3)."""
+    import saunet_amd as S
+    HF = S.functional
+    S.set_compute_dtype(dtype)
+    try:
+        n, h, w = shape
+        torch.manual_seed(c + h)
+        trans = S.modules._Transition(c, c // 2).cuda().train()
+        with torch.no_grad():
+            trans.norm.weight.uniform_(0.5, 1.5); trans.norm.bias.uniform_(-0.3, 0.3)
+        x0 = torch.randn(n, c, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+        cot = torch.randn(n, c // 2, h // 2, w // 2, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+        res, saved, calls, orig = {}, HF.TRANSITION_POOL_FIRST, [], S.lib.call
+
+        def traced(name, *a):
+            calls.append(name); return orig(name, *a)
+        try:
+            for mode in (True, False):
+                HF.TRANSITION_POOL_FIRST = mode
+                HF.begin_step()
+                trans.zero_grad(set_to_none=True)
+                x = x0.clone().requires_grad_(True)
+                st = HF.bn_stats(x)
+                del calls[:]
+                S.lib.call = traced
+                try:
+                    y = trans(x, st)
+                    (y.float() * cot.float()).sum().backward()
+                finally:
+                    S.lib.call = orig
+                torch.cuda.synchronize()
+                assert ("saunet_bn_relu_avgpool2" in calls) == mode and ("saunet_bn_relu_avgpool2_backward" in calls) == mode, calls
+                assert ("saunet_pool2x2_forward" in calls) == (not mode)
+                res[mode] = {"y": y.detach().double().cpu(), "dx": x.grad.double().cpu(), **{k: v.grad.double().cpu() for k, v in trans.named_parameters()}}
+        finally:
+            HF.TRANSITION_POOL_FIRST = saved
+        # float64 reference in torchvision's order on the same (rounded) operands
+        xd = x0.double().cpu().requires_grad_(True)
+        wt = trans.conv.weight.detach().double().cpu().requires_grad_(True)
+        if dtype == torch.bfloat16:
+            wq = trans.conv.weight.detach().to(torch.bfloat16).double().cpu()
+            wt = wq.requires_grad_(True)
+        g = trans.norm.weight.detach().double().cpu().requires_grad_(True); b = trans.norm.bias.detach().double().cpu().requires_grad_(True)
+        mean = xd.mean((0, 2, 3), keepdim=True); var = xd.var((0, 2, 3), unbiased=False, keepdim=True)
+        a = torch.relu((xd - mean) / torch.sqrt(var + trans.norm.eps) * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1))
+        yr = torch.nn.functional.avg_pool2d(torch.nn.functional.conv2d(a, wt), 2)
+        (yr * cot.double().cpu()).sum().backward()
+        ref = {"y": yr.detach(), "dx": xd.grad, "conv.weight": wt.grad, "norm.weight": g.grad, "norm.bias": b.grad}
+        for k in ref:
+            sc = float(ref[k].abs().max())
+            e_new = float((res[True][k] - ref[k]).abs().max()) / sc
+            e_old = float((res[False][k] - ref[k]).abs().max()) / sc
+            if dtype == torch.float32:
+                assert e_new < 2e-5, (k, e_new, e_old)
+            else:
+                assert e_new < 1.5 * e_old + 2e-3, (k, e_new, e_old)
+    finally:
+        S.set_compute_dtype(torch.float32)
