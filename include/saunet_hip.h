@@ -59,7 +59,7 @@ const char* saunet_last_error(void);
  * `workspace` / `workspace_bytes`, the saunet_dense_layer_* entries) -- that round still answered 1; 3 = round 6.  A caller built
  * against another header must refuse to run:  if (saunet_version() != SAUNET_ABI_VERSION) abort();  -- the library reads every descriptor
  * field of ITS header, a shorter struct from an older header would be read past its end. */
-#define SAUNET_ABI_VERSION 3
+#define SAUNET_ABI_VERSION 4
 int saunet_version(void);
 /* names of the kernels the calling thread's API calls have launched since the previous call of this function, joined by '+' (a name is the
  * kernel's symbol without "_kernel", e.g. "conv_igemm_fwd", "bn_bwd_correct_ab+dense_dgrad3"); thread-local, valid until the next call.
@@ -98,6 +98,9 @@ typedef struct saunet_bn_epilogue {
     const float* scale; const float* shift; const float* mean; const float* invstd;
     double* sums;
     int32_t sums_replicas, sums_rstride;   /* replicated like the statistics (0/1 = single copy) */
+    const uint8_t* relu_mask;              /* ABI 4: optional ReLU decisions as bits (saunet_affine_act_mask layout, pixels * Cout / 8 bytes) used INSTEAD of
+                                            * bn_x*scale+shift > 0 -- the output of a residual block, whose pre-activation also has the skip tensor in it
+                                            * (/root/reference/models/resnet.py:54-59).  1x1 data gradients on the implicit-GEMM path, bf16 only. */
 } saunet_bn_epilogue;
 int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const void* w_packed, const float* bias,
                              const float* pro_scale, const float* pro_shift, void* y,

@@ -784,6 +784,8 @@ int saunet_conv2d_forward_ex(const saunet_conv_desc* d, const void* x, const voi
     }
     if (mm_fwd_supported(d, x, w, y, ps, epi)) return mm_forward(d, x, w, bias, y, ssum, ssq, st);
     if (mm_convt_supported(d, x, w, y, ps, epi)) return mm_convt_forward(d, x, w, bias, y, ssum, ssq, st);
+    if (epi && epi->relu_mask && !(igemm_supported(d) && !tile_fwd_supported(d) && !d->transposed && d->dtype == SAUNET_BF16 && d->Cout % 8 == 0))
+        return set_error(SAUNET_UNSUPPORTED, "conv: the bit-mask BN epilogue is implemented for bf16 1x1 data gradients on the implicit-GEMM path");
     if (igemm_supported(d)) {
         if (epi && (((uintptr_t)epi->bn_x & 15) || epi->ld_bn_x % (d->dtype == SAUNET_BF16 ? 8 : 4)))
             return set_error(SAUNET_BAD_ALIGN, "conv: bn epilogue tensor must be 16-byte aligned");

@@ -317,9 +317,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void conv_igemm_fwd_
             float g[EPC], xv[EPC];
             Vec16<T>::unpack(v, g);
             Vec16<T>::unpack(xr[i], xv);
+            unsigned bits = 0xffu;          // ReLU decisions handed in as bits (a residual block's output): one byte per 8-channel chunk
+            if constexpr (EPC == 8) { if (a.epi.relu_mask && okv[i]) bits = a.epi.relu_mask[opixv[i] * (size_t)(a.Cout >> 3) + (colv >> 3)]; }
 #pragma unroll
             for (int j = 0; j < EPC; ++j) {
-                if (a.epi.relu && !(fmaf(xv[j], esc[j], esh[j]) > 0.f)) g[j] = 0.f;
+                if (EPC == 8 && a.epi.relu_mask) { if (!((bits >> j) & 1u)) g[j] = 0.f; }
+                else if (a.epi.relu && !(fmaf(xv[j], esc[j], esh[j]) > 0.f)) g[j] = 0.f;
                 if (!okv[i]) g[j] = 0.f;
                 e1[j] += g[j];
                 e2[j] = fmaf(g[j], (xv[j] - emu[j]) * eis[j], e2[j]);

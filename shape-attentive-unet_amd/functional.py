@@ -429,6 +429,7 @@ def conv_dgrad_raw(dy, weight, x_shape, stride, pad, transposed=False, out=None,
         e = L.BnEpilogue()
         e.bn_x, e.ld_bn_x, e.relu = bx.data_ptr(), ld_of(bx), 1 if relu else 0
         e.accumulate = int(bn_epi[4]) if len(bn_epi) > 4 and bn_epi[4] else 0          # 1: y += scale * g; 2: y = scale * g
+        e.relu_mask = bn_epi[5].data_ptr() if len(bn_epi) > 5 and bn_epi[5] is not None else None      # ReLU decisions as bits (a residual block's output)
         e.scale, e.shift, e.mean, e.invstd = p.scale.data_ptr(), p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr()
         e.sums = sums.data_ptr()
         e.sums_replicas, e.sums_rstride = (sums.shape[0], sums.stride(0)) if sums.dim() == 3 else (1, 0)
@@ -1011,6 +1012,85 @@ class _BasicBlock(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad_raw(dz1, w1, x.shape, 1, 1, out=dres, accumulate=True)      # on top of the skip branch's gradient
         return dx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None, None
+
+
+class _BasicBlockConv(torch.autograd.Function):
+    """conv1x1_k(BasicBlock(x)) as ONE autograd node (round 6).  In the shape stream every residual block feeds exactly one biased 1x1 convolution
+    (res1 -> d1, res2 -> d2, res3 -> d3: /root/reference/models/models.py:337-356), so the gradient of the block's output has a single producer: the
+    data gradient of that convolution.  Its epilogue applies the block's ReLU decisions (the bits kept by saunet_affine_act_mask) and takes the two
+    BatchNorm-backward sums of bn2 while the tile is on chip (saunet_bn_epilogue.relu_mask), so bn2's reduce pass over (dy, z2) disappears, and the
+    masked gradient it writes IS the skip branch's gradient: the apply pass no longer writes a second copy.  Three full-resolution tensor passes
+    fewer per block than _BasicBlock + _Conv.  Forward = _BasicBlock.forward followed by the convolution."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, mom1, eps1, mom2, eps2, training, wk, bk):
+        x = nhwc(x)
+        c = w1.shape[0]
+        st1 = new_stats(c, x.device) if training else None
+        z1 = conv_forward_raw(x, w1, None, 1, 1, stats=st1)
+        count = z1.shape[0] * z1.shape[2] * z1.shape[3]
+        st2 = new_stats(c, x.device) if training else None
+        p1 = bn_finalize(st1, count, g1, b1, rm1, rv1, mom1, eps1, training)
+        z2 = conv_forward_raw(z1, w2, None, 1, 1, pro=(p1.scale, p1.shift, True), stats=st2)
+        mask = torch.empty(z2.numel() // 8, dtype=torch.uint8, device=x.device)
+        if training:
+            y, p2 = bn_affine_act(z2, st2, count, g2, b2, rm2, rv2, mom2, eps2, True, x, mask=mask)
+        else:
+            p2 = bn_finalize(st2, count, g2, b2, rm2, rv2, mom2, eps2, training)
+            y = affine_act(z2, p2.scale, p2.shift, True, x, mask=mask)
+        out = conv_forward_raw(y, wk, bk, 1, 0)
+        ctx.save_for_backward(x, w1, w2, z1, z2, p1.buf, p2.buf, mask, y, wk)
+        ctx.cfg = (training, count, bk is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w1, w2, z1, z2, p1b, p2b, mask, y, wk = ctx.saved_tensors
+        training, count, has_bias = ctx.cfg
+        p1 = BNParams.__new__(BNParams); p1.buf = p1b
+        p2 = BNParams.__new__(BNParams); p2.buf = p2b
+        dout = nhwc(dout)
+        both = conv_wgrad_bias_raw(y, dout, wk, 1, 0) if has_bias else None
+        if both is not None:
+            dwk, dbk = both
+        else:
+            dwk = conv_wgrad_raw(y, dout, wk, 1, 0)
+            dbk = channel_sum(dout) if has_bias else None
+        # the 1x1 data gradient with bn2's backward reduction in its epilogue: g = dy * [block output > 0] (the skip branch's gradient), sum g, sum g * xhat2
+        s2 = new_stats(z2.shape[1], z2.device)
+        g = conv_dgrad_raw(dout, wk, y.shape, 1, 0, bn_epi=(z2, p2, True, s2, 0, mask))
+        dz2, _, dg2, db2 = bn_backward(g, z2, p2, True, count, training, presums=s2)
+        dw2 = conv_wgrad_raw(z1, dz2, w2, 1, 1, pro=(p1.scale, p1.shift, True))
+        s1 = new_stats(z1.shape[1], z1.device)
+        da1 = conv_dgrad_raw(dz2, w2, z1.shape, 1, 1, bn_epi=(z1, p1, True, s1))
+        dz1, _, dg1, db1 = bn_backward(da1, z1, p1, True, count, training, dx=da1, presums=s1)
+        dw1 = conv_wgrad_raw(x, dz1, w1, 1, 1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_dgrad_raw(dz1, w1, x.shape, 1, 1, out=g, accumulate=True)        # on top of the skip branch's gradient (g is not read again)
+        return dx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None, None, dwk, dbk
+
+
+BLOCK_CONV_FUSED = os.environ.get("SAUNET_BLOCK_CONV_FUSED", "1") != "0"     # residual block + the 1x1 convolution behind it as one node (A/B, tests)
+
+
+def basic_block_conv1x1(x, blk, conv):
+    """conv(blk(x)) for a BasicBlock module and the biased 1x1 nn.Conv2d that is its ONLY consumer; one fused node where the library serves it
+    (bf16 storage, 8-channel chunks, local batch statistics), else the two calls."""
+    x = nhwc(x)
+    c, ck = blk.conv1.weight.shape[0], conv.weight.shape[0]
+    synced = getattr(blk.bn1, "sync", False) and blk.bn1.training and torch.distributed.is_available() and torch.distributed.is_initialized() \
+        and torch.distributed.get_world_size() > 1
+    ok = (BLOCK_CONV_FUSED and FUSED_BASIC_BLOCK and RELU_MASK and not synced and x.is_cuda and x.dtype == torch.bfloat16
+          and (blk.bn1.training or torch.is_grad_enabled()) and blk.bn1.training == blk.bn2.training and torch.is_grad_enabled()
+          and tuple(conv.weight.shape[2:]) == (1, 1) and conv.stride == (1, 1) and c % 8 == 0 and ck % 8 == 0 and c >= 8 and ck >= 8
+          and ld_of(x) % 8 == 0 and x.data_ptr() % 16 == 0 and blk.conv1.weight.shape[1] == c)
+    if not ok:
+        return conv2d(blk(x), conv.weight, conv.bias)
+    _bump(blk.bn1); _bump(blk.bn2)
+    return _BasicBlockConv.apply(x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.bn1.running_mean, blk.bn1.running_var, blk.conv2.weight,
+                                 blk.bn2.weight, blk.bn2.bias, blk.bn2.running_mean, blk.bn2.running_var, blk.bn1.momentum, blk.bn1.eps,
+                                 blk.bn2.momentum, blk.bn2.eps, blk.bn1.training, conv.weight, conv.bias)
 
 
 # Default since round 3 (FUSED_BASIC_BLOCK = False restores the two conv_bn_act calls).  Rounds 1 and 2 measured it SLOWER (33.45 -> 33.86 ms per

@@ -24,7 +24,8 @@ class ConvDesc(C.Structure):
 class BnEpilogue(C.Structure):
     _fields_ = [("bn_x", C.c_void_p), ("ld_bn_x", C.c_int32), ("relu", C.c_int32), ("accumulate", C.c_int32), ("reserved", C.c_int32),
                 ("scale", C.c_void_p), ("shift", C.c_void_p),
-                ("mean", C.c_void_p), ("invstd", C.c_void_p), ("sums", C.c_void_p), ("sums_replicas", C.c_int32), ("sums_rstride", C.c_int32)]
+                ("mean", C.c_void_p), ("invstd", C.c_void_p), ("sums", C.c_void_p), ("sums_replicas", C.c_int32), ("sums_rstride", C.c_int32),
+                ("relu_mask", C.c_void_p)]
 
 
 class BnPrologue(C.Structure):
@@ -180,7 +181,7 @@ _SIGS = {
     "saunet_adam_step": [C.POINTER(TensorList), vp, vp],
     "saunet_bucket_copy": [C.POINTER(TensorList), i32, f32, vp],
 }
-ABI_VERSION = 3          # include/saunet_hip.h: SAUNET_ABI_VERSION (the struct layouts below mirror that header)
+ABI_VERSION = 4          # include/saunet_hip.h: SAUNET_ABI_VERSION (the struct layouts below mirror that header)
 EXPORTS = sorted(list(_SIGS) + ["saunet_last_error", "saunet_version", "saunet_launch_log"])
 
 _lib = None

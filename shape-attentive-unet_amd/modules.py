@@ -473,13 +473,15 @@ class SAUNet(nn.Module):
         def conv(m, t):
             return HF.conv2d(t, m.weight, m.bias)
 
-        ss = self.res1(up(conv(self.d0, conv2), size))
+        # (every residual block of the shape stream feeds exactly one 1x1 convolution: block + convolution are one autograd node, see
+        # functional._BasicBlockConv)
+        ss = HF.basic_block_conv1x1(up(conv(self.d0, conv2), size), self.res1, self.d1)
         c3 = up(conv(self.c3, conv3), size)
-        ss, g1 = self.gate1(conv(self.d1, ss), c3)
-        ss = conv(self.d2, self.res2(ss))
+        ss, g1 = self.gate1(ss, c3)
+        ss = HF.basic_block_conv1x1(ss, self.res2, self.d2)
         c4 = up(conv(self.c4, conv4), size)
         ss, g2 = self.gate2(ss, c4)
-        ss = conv(self.d3, self.res3(ss))
+        ss = HF.basic_block_conv1x1(ss, self.res3, self.d3)
         c5 = up(conv(self.c5, conv5), size)
         ss, g3 = self.gate3(ss, c5)
         # the one/two-channel edge head stays in float32 whatever the storage dtype: a bf16 sigmoid saturates to

@@ -230,3 +230,59 @@ def test_consumer_side_bn_finalize_matches_the_separate_launch(dtype):
             assert float((a[5][k] - b[5][k]).abs().max()) <= 1e-6 * float(b[5][k].abs().max()) + 1e-9, k
     finally:
         S.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ch,ck,shape", [(64, 32, (2, 32, 48)), (16, 8, (1, 32, 32)), (32, 16, (3, 16, 32))])
+def test_basic_block_and_its_1x1_consumer_as_one_node(ch, ck, shape):
+    """functional._BasicBlockConv (round 6): the data gradient of the 1x1 convolution behind a residual block applies the block's ReLU bits and takes
+    bn2's two backward sums in its epilogue (saunet_bn_epilogue.relu_mask), and the masked gradient it writes is the skip branch's gradient.  Against
+    the two separate nodes (SAUNET_BLOCK_CONV_FUSED=0): same forward (identical), input / parameter gradients to summation order; the fused path
+    must not call saunet_bn_backward_reduce* at all."""
+    import saunet_amd as S
+    HF = S.functional
+    S.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(ch + ck)
+        blk = S.BasicBlock(ch, ch).cuda().train()
+        conv = torch.nn.Conv2d(ch, ck, 1).cuda()
+        with torch.no_grad():
+            for m in blk.modules():
+                if hasattr(m, "running_mean") and m.weight is not None and m.weight.dim() == 1:
+                    m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+        state0 = {k: v.clone() for k, v in blk.state_dict().items()}
+        n, h, w = shape
+        x0 = torch.randn(n, ch, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        cot = torch.randn(n, ck, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        res, saved, calls, orig = {}, HF.BLOCK_CONV_FUSED, [], S.lib.call
+
+        def traced(name, *a):
+            calls.append(name); return orig(name, *a)
+        try:
+            for mode in (True, False):
+                HF.BLOCK_CONV_FUSED = mode
+                blk.load_state_dict(state0); HF.notify_params_changed(); blk.zero_grad(set_to_none=True); conv.zero_grad(set_to_none=True)
+                x = x0.clone().requires_grad_(True)
+                del calls[:]
+                S.lib.call = traced
+                try:
+                    y = HF.basic_block_conv1x1(x, blk, conv)
+                    (y * cot).sum().backward()
+                finally:
+                    S.lib.call = orig
+                torch.cuda.synchronize()
+                assert any(c.startswith("saunet_bn_backward_reduce") for c in calls) == (not mode), calls
+                res[mode] = (y.detach().clone(), x.grad.clone(), {k: v.grad.clone() for mod in (blk, conv) for k, v in mod.named_parameters()},
+                             {k: v.clone() for k, v in blk.state_dict().items() if "running" in k})
+        finally:
+            HF.BLOCK_CONV_FUSED = saved
+        (ya, dxa, ga, ra), (yb, dxb, gb, rb) = res[True], res[False]
+        assert torch.equal(ya, yb)
+        def rel(a, b): return float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-30))
+        assert rel(dxa, dxb) < 2e-2, rel(dxa, dxb)          # (bf16 tensors: one ulp of the largest element is 4e-3)
+        for k in ga:
+            assert rel(ga[k], gb[k]) < 2e-3, (k, rel(ga[k], gb[k]))
+        for k in ra:
+            assert torch.equal(ra[k], rb[k]), k
+    finally:
+        S.set_compute_dtype(torch.float32)
