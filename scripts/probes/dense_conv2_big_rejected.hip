@@ -1,0 +1,211 @@
+// REJECTED (round 6) -- kept with its measurement, not part of the library.  To rebuild: paste into csrc/dense_fwd.hip in front of the closing
+// `}  // namespace saunet`, declare dense_conv2_big_supported / _forward in conv.hip and call them from saunet_conv2d_forward_bnpro.
+//
+// DenseNet conv2 (3x3, 128 -> 32) forward on the large maps as a persistent LDS-DMA kernel: resident weights (one DMA at kernel start), the
+// 18 x 18 x 64-channel halo of a (tile, channel half) unit double-buffered by LDS-DMA, BN + ReLU in place in the LDS by the requesting wave,
+// one barrier per unit, transposed product with a permlane32_swap epilogue (no staging tile), statistics in registers.  162 VGPRs, no scratch,
+// 157 KB LDS.  Measured (scripts/dense_chain_micro.py, graph of the whole block, same box, SAUNET_DENSE_CONV2_BIG=0/1 in a variant build):
+//     block 1 forward 168.3 -> 169.0 us per layer, block 2 68.8 -> 72.3.
+// The register-staged resident kernel of conv_tile.hip (conv3x3_res_fwd_kernel<32, 32, 32, 8>) is therefore NOT bound by its staging: both
+// kernels issue the same 72 ds_read_b128 fragment pairs per wave and tile (1.15 MB of LDS reads per 256 pixels), which at the ~64 B/clk a CU
+// sustains on 16-byte reads is 18k of the 22k cycles a tile takes.  What would help is fewer fragment reads per MFMA (two pixel groups per
+// weight fragment: 32 x 16 tiles with 32-channel units; or the kw = 0 / 2 pixel fragments derived from the kw = 1 one by DPP row shifts).
+// Parity was not established (the measurement came first).
+
+// =====================================================================================================================================
+// dense_conv2_big_kernel (round 6): the same layer on the LARGE maps (blocks 1 / 2: at least one 16 x 16 pixel tile per CU).  The resident 3x3
+// kernel of conv_tile.hip stages every (tile, 64-channel block) unit through registers (global -> VGPR -> BN + ReLU -> LDS, two barriers per
+// unit, the transform serial in front of the MFMAs): 22k cycles per tile where HBM needs 11k and the LDS fragment reads 9k
+// (profiles/r06_step_pmc_summary.txt: 2.7 TB/s of real traffic).  Here:
+//   * one persistent 8-wave workgroup per CU; all 32 x 9 x 128 weights arrive ONCE by LDS-DMA (72 KB, XOR layout of the small-map kernel);
+//   * unit = (tile, channel half): the 18 x 18 x 64-channel halo (41 pieces of 1 KB: 8 pixels x 128 B) lands by LDS-DMA in one of TWO buffers
+//     while the matrix cores work on the other; slot s of pixel hp holds chunk  s ^ (hp & 7)  -- 8 consecutive pixels of a fragment read cover
+//     the 8 bank groups, and the chunk a lane delivers is the same in every piece ((lane & 7) ^ (lane >> 3 & 7));
+//   * BN + ReLU (and the zero padding of the ACTIVATED tensor) in place in the LDS by the wave that requested the piece, one barrier per unit;
+//   * the product is taken TRANSPOSED (A = weights, B = pixels): a lane ends up with channels of ONE pixel, permlane32_swap makes them two
+//     16-byte row pieces (dense_dgrad3_kernel's epilogue), no staging tile; the statistics of the 32 new channels stay in registers for the
+//     workgroup's lifetime and are folded once.
+constexpr int C2B_PIECES = (18 * 18 * 8 + 63) / 64;                       // 41
+constexpr int C2B_BUF = C2B_PIECES * 1024;                                // 41984
+constexpr int C2B_OFF_W = 2 * C2B_BUF;                                    // weights: [32][144] chunks, 73728 B
+constexpr int C2B_OFF_PRO = C2B_OFF_W + C2_W_PIECES * 1024;               // float[2][128]
+constexpr int C2B_OFF_SUM = C2B_OFF_PRO + 1024;                           // float[8 waves][2][32]
+constexpr int C2B_LDS = C2B_OFF_SUM + 8 * 2 * 32 * 4;                     // 160768
+static_assert(C2B_LDS <= 160 * 1024, "dense_conv2_big: LDS");
+
+__global__ __launch_bounds__(512, 1) void dense_conv2_big_kernel(DenseConv2Args a)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 31, lh = lane >> 5;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    float* s_pro = (float*)(smem + C2B_OFF_PRO);
+    const unsigned ntile = (unsigned)a.N * a.tiles_x * a.tiles_y;
+    const int chl = (lane & 7) ^ ((lane >> 3) & 7);                       // the chunk (of the unit's 8) this lane delivers / transforms in every piece
+
+    // halo requests of unit (tile t, half h) into buffer b; piece = wave + 8 j
+    auto issue = [&](unsigned t, int h, int b) {
+        const unsigned txi = t % a.tiles_x, r1 = t / a.tiles_x, tyi = r1 % a.tiles_y, n = r1 / a.tiles_y;
+        const unsigned char* img = (const unsigned char*)(a.z + (size_t)n * a.H * a.W * a.ldz);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int piece = wave + 8 * j;
+            if (piece < C2B_PIECES) {
+                const int hp = piece * 8 + (lane >> 3);
+                const int hy = hp / 18, hx = hp - hy * 18;
+                const int iy = (int)tyi * 16 + hy - 1, ix = (int)txi * 16 + hx - 1;
+                const bool ok = hp < 324 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const unsigned char* src = ok ? img + ((size_t)(iy * a.W + ix) * a.ldz + (h * 8 + chl) * 8) * 2 : (const unsigned char*)g_c2_zeros + (lane & 3) * 16;
+                mm_dma16(src, lds0 + b * C2B_BUF + piece * 1024);
+            }
+        }
+    };
+    unsigned t_req = blockIdx.x; int h_req = 0;                           // request cursor (one unit ahead of the multiply cursor)
+    if (t_req < ntile) issue(t_req, 0, 0);
+    // weights (once): as in dense_conv2_fwd_kernel
+#pragma unroll
+    for (int j = 0; j < C2_W_PIECES / 8; ++j) {
+        const int q = (wave + 8 * j) * 64 + lane, row = q / 144, sl = q - row * 144;
+        const int c = (sl & ~15) | ((sl & 15) ^ (row & 15));
+        mm_dma16(a.w + (size_t)row * 1152 + c * 8, lds0 + C2B_OFF_W + (wave + 8 * j) * 1024);
+    }
+    bn_prologue_fill<512>(a.bnp, 128, 128, s_pro, blockIdx.x == 0);
+    __syncthreads();
+
+    float st1[16], st2[16];                                               // statistics of this lane's 16 channels (16 r + 8 lh + j), all its pixels
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st1[i] = st2[i] = 0.f;
+    f32x16 acc;
+    const int prow = 2 * wave + (lr >> 4), pcol = lr & 15;               // this lane's pixel inside the tile
+    const unsigned char* sw = smem + C2B_OFF_W + lr * (144 * 16);         // weight row co = lr
+    int buf = 0;
+    for (unsigned t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const unsigned txi = t % a.tiles_x, r1 = t / a.tiles_x, tyi = r1 % a.tiles_y, n = r1 / a.tiles_y;
+#pragma unroll
+        for (int h = 0; h < 2; ++h, buf ^= 1) {
+            mm_wait_vm<0>();
+            // ---- BN + ReLU in place on this wave's own pieces of the landed unit
+            {
+                float sc[8], sh[8];
+                const int c0 = (h * 8 + chl) * 8;
+                const f32x4 a0 = *(const f32x4*)(s_pro + c0), a1 = *(const f32x4*)(s_pro + c0 + 4);
+                const f32x4 b0 = *(const f32x4*)(s_pro + 128 + c0), b1 = *(const f32x4*)(s_pro + 128 + c0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sc[e] = a0[e]; sc[4 + e] = a1[e]; sh[e] = b0[e]; sh[4 + e] = b1[e]; }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int piece = wave + 8 * j;
+                    if (piece < C2B_PIECES) {
+                        const int hp = piece * 8 + (lane >> 3);
+                        const int hy = hp / 18, hx = hp - hy * 18;
+                        const int iy = (int)tyi * 16 + hy - 1, ix = (int)txi * 16 + hx - 1;
+                        const bool ok = hp < 324 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                        unsigned char* q = smem + buf * C2B_BUF + piece * 1024 + lane * 16;
+                        float f[8];
+                        Vec16<u16>::unpack(*(const u32x4*)q, f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = fmaxf(fmaf(f[e], sc[e], sh[e]), 0.f);
+                        if (ok) *(u32x4*)q = Vec16<u16>::pack(f);           // (padding pixels came from the zero page and stay zero)
+                    }
+                }
+            }
+            mm_barrier();                                                 // the unit is activated; everybody is done with the other buffer
+            // ---- request the next unit into the other buffer
+            {
+                unsigned tn = t; int hn = h + 1;
+                if (hn == 2) { hn = 0; tn = t + gridDim.x; }
+                if (tn < ntile) issue(tn, hn, buf ^ 1);
+            }
+            if (h == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            }
+            // ---- 9 taps x 4 k-steps: A = weights (row co = lr, k half lh), B = pixels (this lane's pixel shifted by the tap, k half lh)
+            const unsigned char* hb = smem + buf * C2B_BUF;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int hp = (prow + tap / 3) * 18 + pcol + tap % 3;
+                const unsigned char* hpx = hb + hp * 128;
+                const int key = hp & 7;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const u32x4 pf = *(const u32x4*)(hpx + (((2 * ks + lh) ^ key) << 4));
+                    const int bc = tap * 16 + h * 8 + 2 * ks + lh;
+                    const u32x4 wf = *(const u32x4*)(sw + (((bc & ~15) | ((bc & 15) ^ (lr & 15))) << 4));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, pf), acc, 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue of the tile: channels of this lane's pixel as two 16-byte row pieces (16 r + 8 lh .. + 8), statistics in registers
+        u16* yrow = a.y + ((size_t)(n * a.H + tyi * 16 + prow) * a.W + txi * 16 + pcol) * a.ldy + 8 * lh;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float G[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const auto swp = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * r + q]), __float_as_uint(acc[8 * r + 4 + q]), false, false);
+                G[q] = __uint_as_float(swp[0]); G[4 + q] = __uint_as_float(swp[1]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { st1[8 * r + e] += G[e]; st2[8 * r + e] = fmaf(G[e], G[e], st2[8 * r + e]); }
+            *(u32x4*)(yrow + 16 * r) = Vec16<u16>::pack(G);
+        }
+    }
+    if (a.stat_sum != nullptr) {
+        // lanes of equal lh hold the same channels: xor tree over the 32 pixel lanes, one slot per wave, fixed-order fold over the waves
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { st1[i] += __shfl_xor(st1[i], o, 64); st2[i] += __shfl_xor(st2[i], o, 64); }
+        float* s_sum = (float*)(smem + C2B_OFF_SUM);
+        if (lr == 0) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s_sum[(wave * 2) * 32 + 16 * r + 8 * lh + e] = st1[8 * r + e];
+                    s_sum[(wave * 2 + 1) * 32 + 16 * r + 8 * lh + e] = st2[8 * r + e];
+                }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) { t1 += s_sum[(w8 * 2) * 32 + tid]; t2 += s_sum[(w8 * 2 + 1) * 32 + tid]; }
+            const size_t ro = (size_t)(blockIdx.x % a.stat_replicas) * a.stat_rstride;
+            atomicAdd(&a.stat_sum[ro + tid], (double)t1);
+            atomicAdd(&a.stat_sumsq[ro + tid], (double)t2);
+        }
+    }
+}
+
+bool dense_conv2_big_supported(const saunet_conv_desc* d, const void* x, const void* w, const void* y, const float* bias)
+{
+    static const bool on = ab_env_on("SAUNET_DENSE_CONV2_BIG");         // A/B switch (variant builds only)
+    const long tiles = (long)d->N * (d->H / 16) * (d->W / 16);
+    return on && d->dtype == SAUNET_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->transposed && d->Cin == 128 && d->Cout == 32 &&
+           d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->H % 16 == 0 && d->W % 16 == 0 && d->Ho == d->H && d->Wo == d->W && bias == nullptr && !d->epi_relu &&
+           d->pro_relu && tiles >= 256 && !(((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) && (long)d->N * d->H * d->W * (d->ldx > d->ldy ? d->ldx : d->ldy) < (1L << 31);
+}
+
+int dense_conv2_big_forward(const saunet_conv_desc* d, const void* x, const void* w, void* y, double* ssum, double* ssq, const saunet_bn_prologue* bnp,
+                            hipStream_t st)
+{
+    DenseConv2Args a;
+    a.z = (const u16*)x; a.ldz = d->ldx; a.w = (const u16*)w; a.y = (u16*)y; a.ldy = d->ldy;
+    a.stat_sum = ssum; a.stat_sumsq = ssq; a.stat_replicas = d->stat_replicas > 1 ? d->stat_replicas : 1; a.stat_rstride = d->stat_rstride;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.tiles_x = d->W / 16; a.tiles_y = d->H / 16;
+    a.bnp = *bnp;
+    static DeviceOnce attr;
+    if (attr.first()) (void)hipFuncSetAttribute((const void*)dense_conv2_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C2B_LDS);
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        (void)hipGetLastError();
+    }
+    const long ntile = (long)a.N * a.tiles_x * a.tiles_y;
+    hipLaunchKernelGGL(dense_conv2_big_kernel, dim3((unsigned)(ntile < cus ? ntile : cus)), dim3(512), C2B_LDS, st, a);
+    SAUNET_CHECK_LAUNCH("dense_conv2_big_kernel");
+    return SAUNET_OK;
+}
+
