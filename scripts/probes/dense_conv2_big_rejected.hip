@@ -6,10 +6,8 @@
 // one barrier per unit, transposed product with a permlane32_swap epilogue (no staging tile), statistics in registers.  162 VGPRs, no scratch,
 // 157 KB LDS.  Measured (scripts/dense_chain_micro.py, graph of the whole block, same box, SAUNET_DENSE_CONV2_BIG=0/1 in a variant build):
 //     block 1 forward 168.3 -> 169.0 us per layer, block 2 68.8 -> 72.3.
-// The register-staged resident kernel of conv_tile.hip (conv3x3_res_fwd_kernel<32, 32, 32, 8>) is therefore NOT bound by its staging: both
-// kernels issue the same 72 ds_read_b128 fragment pairs per wave and tile (1.15 MB of LDS reads per 256 pixels), which at the ~64 B/clk a CU
-// sustains on 16-byte reads is 18k of the 22k cycles a tile takes.  What would help is fewer fragment reads per MFMA (two pixel groups per
-// weight fragment: 32 x 16 tiles with 32-channel units; or the kw = 0 / 2 pixel fragments derived from the kw = 1 one by DPP row shifts).
+// The register-staged resident kernel of conv_tile.hip (conv3x3_res_fwd_kernel<32, 32, 32, 8>) is therefore not improved by taking the staging off
+// the waves (its phase stamps: profiles/r06_phase_timing_raw.txt conv2fwd).
 // Parity was not established for this first form (the measurement came first).
 //
 // SECOND FORM (below the first): 32-channel units in a RING OF THREE buffers, the next unit's BN + ReLU interleaved between this unit's MFMAs (the
