@@ -964,6 +964,33 @@ def conv_bn_act(x, weight, bias, bn, relu=True, residual=None, stride=1, padding
                             transposed, relu, bn.momentum, bn.eps, bn.training, group, sync_bufs, out, pool)
 
 
+def _sync_finalize(stats, count_local, gamma, beta, rmean, rvar, momentum, eps, group, sync_bufs):
+    """SynchronizedBatchNorm finalize (lib/nn/modules/batchnorm.py:98-139) from local raw statistics: all-reduce of (sum, sumsq), global count,
+    the reference's (_tmp_running_*, _running_iter) moving average.  -> (BNParams, global count)"""
+    c = gamma.shape[0]
+    flat = collapse_stats(stats)
+    torch.distributed.all_reduce(flat, group=group)
+    SYNCBN_ALLREDUCES["count"] += 1
+    count = count_local * torch.distributed.get_world_size(group)
+    p = BNParams(c, gamma.device)
+    tm, tv, it = sync_bufs if sync_bufs is not None else (None, None, None)
+    PACKS.generation += 1
+    L.call("saunet_syncbn_finalize", c, flat[:c].data_ptr(), flat[c:].data_ptr(), 1, 0, float(count), gamma.data_ptr(),
+           beta.data_ptr(), float(eps), float(momentum), L.ptr(tm), L.ptr(tv), L.ptr(it), L.ptr(rmean), L.ptr(rvar),
+           p.scale.data_ptr(), p.shift.data_ptr(), p.mean.data_ptr(), p.invstd.data_ptr(), L.stream())
+    return p, count
+
+
+def _sync_args(bn1, bn2):
+    """(process group, bn1's accumulator buffers, bn2's) when the block's SynchronizedBatchNorm layers have to exchange statistics, else (None, None, None)"""
+    synced = getattr(bn1, "sync", False) and bn1.training and torch.distributed.is_available() and torch.distributed.is_initialized() \
+        and torch.distributed.get_world_size() > 1
+    if not synced:
+        return None, None, None
+    return (torch.distributed.group.WORLD, (bn1._tmp_running_mean, bn1._tmp_running_var, bn1._running_iter),
+            (bn2._tmp_running_mean, bn2._tmp_running_var, bn2._running_iter))
+
+
 class _BasicBlock(torch.autograd.Function):
     """relu(bn2(conv2(relu(bn1(conv1(x))))) + x), 3x3 stride-1 convolutions (models/resnet.py:30-60, the shape stream's res1-3), with bn1 + ReLU
     applied in conv2's operand load: the activated intermediate is never materialised (forward: one read + one write of the full-resolution
@@ -971,7 +998,7 @@ class _BasicBlock(torch.autograd.Function):
     only: SynchronizedBatchNorm across ranks keeps the unfused path (it needs the all-reduce between reduce and apply)."""
 
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, mom1, eps1, mom2, eps2, training):
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, mom1, eps1, mom2, eps2, training, group=None, sb1=None, sb2=None):
         x = nhwc(x)
         c = w1.shape[0]
         st1 = new_stats(c, x.device) if training else None
@@ -980,38 +1007,45 @@ class _BasicBlock(torch.autograd.Function):
         st2 = new_stats(c, x.device) if training else None
         # (measured and rejected, round 6: bn1's finalize in conv2's operand-load prologue -- saunet_conv2d_forward_bnpro -- and the same for the
         # transitions' 1x1: step +0.05 ms same-box; thousands of full-resolution workgroups each repeat the replica sums before their first load)
-        p1 = bn_finalize(st1, count, g1, b1, rm1, rv1, mom1, eps1, training)
+        sync = group is not None and training
+        if sync:         # SynchronizedBatchNorm across ranks: the statistics are all-reduced between the convolution and its BatchNorm
+            p1, gcount = _sync_finalize(st1, count, g1, b1, rm1, rv1, mom1, eps1, group, sb1)
+        else:
+            p1, gcount = bn_finalize(st1, count, g1, b1, rm1, rv1, mom1, eps1, training), count
         z2 = conv_forward_raw(z1, w2, None, 1, 1, pro=(p1.scale, p1.shift, True), stats=st2)
         # the ReLU decisions of the block's output as bits (1/16 of the tensor): bn2's backward passes then read them instead of the skip tensor
         mask = torch.empty(z2.numel() // 8, dtype=torch.uint8, device=x.device) if relu_mask_ok(z2, x) else None
-        if training:
+        if sync:
+            p2, _ = _sync_finalize(st2, count, g2, b2, rm2, rv2, mom2, eps2, group, sb2)
+            y = affine_act(z2, p2.scale, p2.shift, True, x, mask=mask)
+        elif training:
             y, p2 = bn_affine_act(z2, st2, count, g2, b2, rm2, rv2, mom2, eps2, True, x, mask=mask)
         else:
             p2 = bn_finalize(st2, count, g2, b2, rm2, rv2, mom2, eps2, training)
             y = affine_act(z2, p2.scale, p2.shift, True, x, mask=mask)
         ctx.save_for_backward(x, w1, w2, z1, z2, p1.buf, p2.buf, mask if mask is not None else z2.new_empty(0))
-        ctx.cfg = (training, count, mask is not None)
+        ctx.cfg = (training, gcount, mask is not None, group if sync else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w1, w2, z1, z2, p1b, p2b, mask = ctx.saved_tensors
-        training, count, masked = ctx.cfg
+        training, count, masked, group = ctx.cfg
         p1 = BNParams.__new__(BNParams); p1.buf = p1b
         p2 = BNParams.__new__(BNParams); p2.buf = p2b
         if masked and nhwc(dy).data_ptr() % 16 == 0 and ld_of(nhwc(dy)) % 8 == 0:
-            dz2, dres, dg2, db2 = bn_backward(dy, z2, p2, True, count, training, None, want_dres=True, mask=mask)
+            dz2, dres, dg2, db2 = bn_backward(dy, z2, p2, True, count, training, None, want_dres=True, mask=mask, sync_group=group)
         else:
-            dz2, dres, dg2, db2 = bn_backward(dy, z2, p2, True, count, training, x, want_dres=True)
+            dz2, dres, dg2, db2 = bn_backward(dy, z2, p2, True, count, training, x, want_dres=True, sync_group=group)
         dw2 = conv_wgrad_raw(z1, dz2, w2, 1, 1, pro=(p1.scale, p1.shift, True))
         s1 = new_stats(z1.shape[1], z1.device)
         da1 = conv_dgrad_raw(dz2, w2, z1.shape, 1, 1, bn_epi=(z1, p1, True, s1))
-        dz1, _, dg1, db1 = bn_backward(da1, z1, p1, True, count, training, dx=da1, presums=s1)
+        dz1, _, dg1, db1 = bn_backward(da1, z1, p1, True, count, training, dx=da1, presums=s1, sync_group=group)
         dw1 = conv_wgrad_raw(x, dz1, w1, 1, 1)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad_raw(dz1, w1, x.shape, 1, 1, out=dres, accumulate=True)      # on top of the skip branch's gradient
-        return dx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None, None
+        return dx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None, None, None, None, None
 
 
 class _BasicBlockConv(torch.autograd.Function):
@@ -1023,30 +1057,37 @@ class _BasicBlockConv(torch.autograd.Function):
     fewer per block than _BasicBlock + _Conv.  Forward = _BasicBlock.forward followed by the convolution."""
 
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, mom1, eps1, mom2, eps2, training, wk, bk):
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, mom1, eps1, mom2, eps2, training, wk, bk, group=None, sb1=None, sb2=None):
         x = nhwc(x)
         c = w1.shape[0]
         st1 = new_stats(c, x.device) if training else None
         z1 = conv_forward_raw(x, w1, None, 1, 1, stats=st1)
         count = z1.shape[0] * z1.shape[2] * z1.shape[3]
         st2 = new_stats(c, x.device) if training else None
-        p1 = bn_finalize(st1, count, g1, b1, rm1, rv1, mom1, eps1, training)
+        sync = group is not None and training
+        if sync:         # SynchronizedBatchNorm across ranks: the statistics are all-reduced between the convolution and its BatchNorm
+            p1, gcount = _sync_finalize(st1, count, g1, b1, rm1, rv1, mom1, eps1, group, sb1)
+        else:
+            p1, gcount = bn_finalize(st1, count, g1, b1, rm1, rv1, mom1, eps1, training), count
         z2 = conv_forward_raw(z1, w2, None, 1, 1, pro=(p1.scale, p1.shift, True), stats=st2)
         mask = torch.empty(z2.numel() // 8, dtype=torch.uint8, device=x.device)
-        if training:
+        if sync:
+            p2, _ = _sync_finalize(st2, count, g2, b2, rm2, rv2, mom2, eps2, group, sb2)
+            y = affine_act(z2, p2.scale, p2.shift, True, x, mask=mask)
+        elif training:
             y, p2 = bn_affine_act(z2, st2, count, g2, b2, rm2, rv2, mom2, eps2, True, x, mask=mask)
         else:
             p2 = bn_finalize(st2, count, g2, b2, rm2, rv2, mom2, eps2, training)
             y = affine_act(z2, p2.scale, p2.shift, True, x, mask=mask)
         out = conv_forward_raw(y, wk, bk, 1, 0)
         ctx.save_for_backward(x, w1, w2, z1, z2, p1.buf, p2.buf, mask, y, wk)
-        ctx.cfg = (training, count, bk is not None)
+        ctx.cfg = (training, gcount, bk is not None, group if sync else None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, w1, w2, z1, z2, p1b, p2b, mask, y, wk = ctx.saved_tensors
-        training, count, has_bias = ctx.cfg
+        training, count, has_bias, group = ctx.cfg
         p1 = BNParams.__new__(BNParams); p1.buf = p1b
         p2 = BNParams.__new__(BNParams); p2.buf = p2b
         dout = nhwc(dout)
@@ -1059,18 +1100,22 @@ class _BasicBlockConv(torch.autograd.Function):
         # the 1x1 data gradient with bn2's backward reduction in its epilogue: g = dy * [block output > 0] (the skip branch's gradient), sum g, sum g * xhat2
         s2 = new_stats(z2.shape[1], z2.device)
         g = conv_dgrad_raw(dout, wk, y.shape, 1, 0, bn_epi=(z2, p2, True, s2, 0, mask))
-        dz2, _, dg2, db2 = bn_backward(g, z2, p2, True, count, training, presums=s2)
+        dz2, _, dg2, db2 = bn_backward(g, z2, p2, True, count, training, presums=s2, sync_group=group)
         dw2 = conv_wgrad_raw(z1, dz2, w2, 1, 1, pro=(p1.scale, p1.shift, True))
         s1 = new_stats(z1.shape[1], z1.device)
         da1 = conv_dgrad_raw(dz2, w2, z1.shape, 1, 1, bn_epi=(z1, p1, True, s1))
-        dz1, _, dg1, db1 = bn_backward(da1, z1, p1, True, count, training, dx=da1, presums=s1)
+        dz1, _, dg1, db1 = bn_backward(da1, z1, p1, True, count, training, dx=da1, presums=s1, sync_group=group)
         dw1 = conv_wgrad_raw(x, dz1, w1, 1, 1)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad_raw(dz1, w1, x.shape, 1, 1, out=g, accumulate=True)        # on top of the skip branch's gradient (g is not read again)
-        return dx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None, None, dwk, dbk
+        return dx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, None, None, None, None, None, dwk, dbk, None, None, None
 
 
+# SynchronizedBatchNorm inside the fused residual block (round 6): the statistic exchanges of bn1 / bn2 sit between the fused launches exactly where the
+# unfused conv_bn_act pair has them (forward: after each convolution; backward: between the sums and the apply pass), so N > 1 runs keep the fused
+# block's passes.  SAUNET_SYNC_BLOCK_FUSED=0 restores the two conv_bn_act calls under SyncBN (A/B, tests).
+SYNC_BLOCK_FUSED = os.environ.get("SAUNET_SYNC_BLOCK_FUSED", "1") != "0"
 BLOCK_CONV_FUSED = os.environ.get("SAUNET_BLOCK_CONV_FUSED", "1") != "0"     # residual block + the 1x1 convolution behind it as one node (A/B, tests)
 
 
@@ -1079,9 +1124,8 @@ def basic_block_conv1x1(x, blk, conv):
     (bf16 storage, 8-channel chunks, local batch statistics), else the two calls."""
     x = nhwc(x)
     c, ck = blk.conv1.weight.shape[0], conv.weight.shape[0]
-    synced = getattr(blk.bn1, "sync", False) and blk.bn1.training and torch.distributed.is_available() and torch.distributed.is_initialized() \
-        and torch.distributed.get_world_size() > 1
-    ok = (BLOCK_CONV_FUSED and FUSED_BASIC_BLOCK and RELU_MASK and not synced and x.is_cuda and x.dtype == torch.bfloat16
+    group, sb1, sb2 = _sync_args(blk.bn1, blk.bn2)
+    ok = (BLOCK_CONV_FUSED and FUSED_BASIC_BLOCK and RELU_MASK and (group is None or SYNC_BLOCK_FUSED) and x.is_cuda and x.dtype == torch.bfloat16
           and (blk.bn1.training or torch.is_grad_enabled()) and blk.bn1.training == blk.bn2.training and torch.is_grad_enabled()
           and tuple(conv.weight.shape[2:]) == (1, 1) and conv.stride == (1, 1) and c % 8 == 0 and ck % 8 == 0 and c >= 8 and ck >= 8
           and ld_of(x) % 8 == 0 and x.data_ptr() % 16 == 0 and blk.conv1.weight.shape[1] == c)
@@ -1090,7 +1134,7 @@ def basic_block_conv1x1(x, blk, conv):
     _bump(blk.bn1); _bump(blk.bn2)
     return _BasicBlockConv.apply(x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.bn1.running_mean, blk.bn1.running_var, blk.conv2.weight,
                                  blk.bn2.weight, blk.bn2.bias, blk.bn2.running_mean, blk.bn2.running_var, blk.bn1.momentum, blk.bn1.eps,
-                                 blk.bn2.momentum, blk.bn2.eps, blk.bn1.training, conv.weight, conv.bias)
+                                 blk.bn2.momentum, blk.bn2.eps, blk.bn1.training, conv.weight, conv.bias, group, sb1, sb2)
 
 
 # Default since round 3 (FUSED_BASIC_BLOCK = False restores the two conv_bn_act calls).  Rounds 1 and 2 measured it SLOWER (33.45 -> 33.86 ms per
@@ -1101,14 +1145,14 @@ FUSED_BASIC_BLOCK = True
 
 def basic_block(x, conv1, bn1, conv2, bn2):
     """BasicBlock forward; the fused form when it applies (training or grad mode on the GPU, batch statistics local to this process)."""
-    synced = getattr(bn1, "sync", False) and bn1.training and torch.distributed.is_available() and torch.distributed.is_initialized() \
-        and torch.distributed.get_world_size() > 1
-    if not FUSED_BASIC_BLOCK or synced or not x.is_cuda or not (bn1.training or torch.is_grad_enabled()) or bn1.training != bn2.training:
+    group, sb1, sb2 = _sync_args(bn1, bn2)
+    if not FUSED_BASIC_BLOCK or (group is not None and not SYNC_BLOCK_FUSED) or not x.is_cuda or not (bn1.training or torch.is_grad_enabled()) \
+            or bn1.training != bn2.training:
         out = conv_bn_act(x, conv1.weight, None, bn1, relu=True, padding=1)
         return conv_bn_act(out, conv2.weight, None, bn2, relu=True, residual=x, padding=1)
     _bump(bn1); _bump(bn2)
     return _BasicBlock.apply(x, conv1.weight, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, conv2.weight, bn2.weight, bn2.bias,
-                             bn2.running_mean, bn2.running_var, bn1.momentum, bn1.eps, bn2.momentum, bn2.eps, bn1.training)
+                             bn2.running_mean, bn2.running_var, bn1.momentum, bn1.eps, bn2.momentum, bn2.eps, bn1.training, group, sb1, sb2)
 
 
 class _BNAct(torch.autograd.Function):
